@@ -1,0 +1,222 @@
+/*
+  ref_driver.c -- TEST INFRASTRUCTURE ONLY (oracle side, never shipped).
+
+  A small main() of our own that drives the *reference's* enhanced-suffix-array
+  engine through its library seam:
+    GtEncseqEncoder / GtEncseqLoader      src/core/encseq_api.h:223-448
+    gt_recommendedprefixlength            src/match/sfx-apfxlen.h
+    gt_Outlcpinfo_new                     src/match/sfx-lcpvalues.h:102
+    gt_Sfxiterator_new_withadditionalvalues / _next / _longest / _delete
+                                          src/match/sfx-suffixer.h:32-70
+    gt_suffixsortspace_to_file            src/match/sfx-suffixgetset.h
+    gt_outprjfile                         src/match/sfx-outprj.h
+  i.e. the same call sequence as gt_runsuffixerator (src/match/sfx-run.c:428-717)
+  for the options  -dna|-protein -suf [-lcp] [-bwt] -db FILE -indexname IDX
+  without the option parser (src/core/option.c needs the generated gt_config.h,
+  which we neither have nor fake).
+
+  All reference sources are compiled where they lie under /root/reference by
+  oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
+
+  usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
+                    -db FASTA -indexname IDX [-time]
+*/
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "core/alphabet_api.h"
+#include "core/class_alloc_lock.h"
+#include "core/combinatorics.h"
+#include "core/defined-types.h"
+#include "core/encseq_api.h"
+#include "core/error_api.h"
+#include "core/fa.h"
+#include "core/log.h"
+#include "core/ma.h"
+#include "core/str_array_api.h"
+#include "core/symbol.h"
+#include "core/chardef.h"
+#include "core/yarandom.h"
+#include "match/esa-fileend.h"
+#include "match/sfx-apfxlen.h"
+#include "match/sfx-lcpvalues.h"
+#include "match/sfx-outprj.h"
+#include "match/sfx-strategy.h"
+#include "match/sfx-suffixer.h"
+
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+static FILE *open_tab(const char *indexname, const char *suffix)
+{
+  char path[4096];
+  FILE *fp;
+  snprintf(path, sizeof path, "%s%s", indexname, suffix);
+  fp = fopen(path, "wb");
+  if (fp == NULL) { perror(path); exit(EXIT_FAILURE); }
+  return fp;
+}
+
+int main(int argc, char **argv)
+{
+  const char *db = NULL, *indexname = NULL;
+  bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
+       showtime = false, haserr = false;
+  unsigned int userpl = 0, dc = 0, prefixlength, numofchars;
+  int i;
+  GtError *err;
+  GtEncseqEncoder *ee;
+  GtEncseqLoader *el;
+  GtEncseq *encseq = NULL;
+  GtStrArray *dbs;
+  GtOutlcpinfo *outlcpinfo = NULL;
+  Sfxstrategy strategy;
+  Sfxiterator *sfi;
+  FILE *fpsuf = NULL, *fpbwt = NULL;
+  GtUword numberofallsortedsuffixes = 0, totallength;
+  Definedunsignedlong longest;
+  double t0, t_encode, t_esa;
+
+  for (i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-dna")) dna = true;
+    else if (!strcmp(argv[i], "-protein")) dna = false;
+    else if (!strcmp(argv[i], "-suf")) want_suf = true;
+    else if (!strcmp(argv[i], "-lcp")) want_lcp = true;
+    else if (!strcmp(argv[i], "-bwt")) want_bwt = true;
+    else if (!strcmp(argv[i], "-time")) showtime = true;
+    else if (!strcmp(argv[i], "-pl") && i + 1 < argc)
+      userpl = (unsigned int) atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-dc") && i + 1 < argc)
+      dc = (unsigned int) atoi(argv[++i]);
+    else if (!strcmp(argv[i], "-db") && i + 1 < argc) db = argv[++i];
+    else if (!strcmp(argv[i], "-indexname") && i + 1 < argc)
+      indexname = argv[++i];
+    else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+  }
+  if (db == NULL || indexname == NULL) {
+    fprintf(stderr, "need -db and -indexname\n");
+    return 2;
+  }
+
+  /* the parts of gt_lib_init (src/core/init.c:100-123) that do not need the
+     option parser */
+  gt_ma_init(false);
+  gt_fa_init();
+  gt_log_init();
+  gt_symbol_init();
+  gt_class_alloc_lock_init();
+  gt_ya_rand_init(0);
+  gt_combinatorics_init();
+
+  err = gt_error_new();
+  t0 = now_s();
+  ee = gt_encseq_encoder_new();
+  if (dna) gt_encseq_encoder_set_input_dna(ee);
+  else gt_encseq_encoder_set_input_protein(ee);
+  dbs = gt_str_array_new();
+  gt_str_array_add_cstr(dbs, db);
+  if (gt_encseq_encoder_encode(ee, dbs, indexname, err) != 0) haserr = true;
+  gt_encseq_encoder_delete(ee);
+  gt_str_array_delete(dbs);
+  if (!haserr) {
+    el = gt_encseq_loader_new();
+    gt_encseq_loader_disable_autosupport(el);
+    gt_encseq_loader_do_not_require_des_tab(el);
+    gt_encseq_loader_do_not_require_sds_tab(el);
+    gt_encseq_loader_do_not_require_ssp_tab(el);
+    encseq = gt_encseq_loader_load(el, indexname, err);
+    gt_encseq_loader_delete(el);
+    if (encseq == NULL) haserr = true;
+  }
+  t_encode = now_s() - t0;
+  if (haserr) {
+    fprintf(stderr, "gt suffixerator: error: %s\n", gt_error_get(err));
+    return EXIT_FAILURE;
+  }
+  totallength = gt_encseq_total_length(encseq);
+  numofchars = gt_alphabet_num_of_chars(gt_encseq_alphabet(encseq));
+  prefixlength = userpl > 0
+                   ? userpl
+                   : gt_recommendedprefixlength(numofchars, totallength,
+                                     GT_RECOMMENDED_MULTIPLIER_DEFAULT, true);
+  defaultsfxstrategy(&strategy,
+                     gt_encseq_bitwise_cmp_ok(encseq) ? false : true);
+  strategy.differencecover = dc;
+
+  t0 = now_s();
+  if (want_lcp) {
+    outlcpinfo = gt_Outlcpinfo_new(indexname, numofchars, prefixlength,
+                                   false, false, NULL, NULL, err);
+    if (outlcpinfo == NULL) haserr = true;
+  }
+  if (want_suf) fpsuf = open_tab(indexname, GT_SUFTABSUFFIX);
+  if (want_bwt) fpbwt = open_tab(indexname, GT_BWTTABSUFFIX);
+  longest.defined = false;
+  longest.valueunsignedlong = 0;
+  sfi = haserr ? NULL
+               : gt_Sfxiterator_new_withadditionalvalues(encseq,
+                     GT_READMODE_FORWARD, prefixlength, 1U, 0UL, outlcpinfo,
+                     NULL, &strategy, NULL, false, NULL, err);
+  if (sfi == NULL) haserr = true;
+  while (!haserr) {
+    GtUword numberofsuffixes, pos;
+    bool specialsuffixes = false;
+    const GtSuffixsortspace *sssp
+      = gt_Sfxiterator_next(&numberofsuffixes, &specialsuffixes, sfi);
+    if (sssp == NULL) break;
+    if (fpsuf != NULL)
+      gt_suffixsortspace_to_file(fpsuf, sssp, numberofsuffixes);
+    if (fpbwt != NULL) {
+      /* same rule as bwttab2file, src/match/sfx-run.c:173-210 */
+      for (pos = 0; pos < numberofsuffixes; pos++) {
+        GtUword startpos = gt_suffixsortspace_getdirect(sssp, pos);
+        GtUchar cc = startpos == 0
+                       ? (GtUchar) UNDEFBWTCHAR
+                       : gt_encseq_get_encoded_char(encseq, startpos - 1,
+                                                    GT_READMODE_FORWARD);
+        fputc((int) cc, fpbwt);
+      }
+    }
+    numberofallsortedsuffixes += numberofsuffixes;
+  }
+  if (!haserr) {
+    longest.defined = true;
+    longest.valueunsignedlong = gt_Sfxiterator_longest(sfi);
+  }
+  if (sfi != NULL && gt_Sfxiterator_delete(sfi, err) != 0) haserr = true;
+  if (fpsuf != NULL) fclose(fpsuf);
+  if (fpbwt != NULL) fclose(fpbwt);
+  if (!haserr) {
+    GtUword numoflargelcpvalues = 0, maxbranchdepth = 0;
+    double averagelcp = 0.0;
+    if (outlcpinfo != NULL) {
+      /* src/match/sfx-run.c:671-681 */
+      numoflargelcpvalues = gt_Outlcpinfo_numoflargelcpvalues(outlcpinfo);
+      maxbranchdepth = gt_Outlcpinfo_maxbranchdepth(outlcpinfo);
+      averagelcp = gt_Outlcpinfo_lcptabsum(outlcpinfo) /
+                   numberofallsortedsuffixes;
+    }
+    if (gt_outprjfile(indexname, GT_READMODE_FORWARD, encseq,
+                      numberofallsortedsuffixes, prefixlength,
+                      numoflargelcpvalues, averagelcp, maxbranchdepth,
+                      &longest, err) != 0)
+      haserr = true;
+  }
+  gt_Outlcpinfo_delete(outlcpinfo);
+  t_esa = now_s() - t0;
+  gt_encseq_delete(encseq);
+  if (haserr) {
+    fprintf(stderr, "gt suffixerator: error: %s\n", gt_error_get(err));
+    return EXIT_FAILURE;
+  }
+  if (showtime)
+    printf("# TIME totallength=" GT_WU " prefixlength=%u encode=%.3f "
+           "esa=%.3f\n", totallength, prefixlength, t_encode, t_esa);
+  gt_error_delete(err);
+  return EXIT_SUCCESS;
+}

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REFERENCE itself (run in the dev container).
+
+For every suffixerator fixture named in the reference's own test suite
+(testsuite/gt_suffixerator_include.rb:119-143 DNA FASTA files, :290-308
+protein files) this runs oracle/_ref/gt_ref_sfx -- the reference's engine
+compiled from /root/reference by oracle/Makefile.ref -- with
+`-suf -lcp -bwt` and stores
+
+  * tests/golden/fixtures/<name>           the input (data file of the
+                                           reference's test suite, <= 120 KB)
+  * tests/golden/tables/<name>.{suf,lcp,llv,bwt}.gz   for inputs <= 16 KB
+  * tests/golden/golden.json               md5 + size of every table and the
+                                           full .prj text, for all inputs
+
+so that the CPU restatement (oracle/) and the HIP path can be checked against
+the reference's real output on machines where /root/reference does not exist.
+Only data is stored: inputs and expected outputs.
+"""
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.environ.get("GT_REFERENCE", "/root/reference")
+BIN = os.path.join(ROOT, "oracle", "_ref", "gt_ref_sfx")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+DNA = ["Arabidopsis-C99826.fna", "Atinsert.fna",
+       "Atinsert_seqrange_13-17_rev.fna", "Atinsert_seqrange_3-7.fna",
+       "Atinsert_single_3.fna", "Atinsert_single_3_rev.fna",
+       "Copysorttest.fna", "Duplicate.fna", "Ecoli-section1.fna",
+       "Ecoli-section2.fna", "Random-Small.fna", "Random.fna",
+       "Random159.fna", "Random160.fna", "RandomN.fna", "Reads1.fna",
+       "Reads2.fna", "Reads3.fna", "Repfind-example.fna", "TTTN.fna",
+       "Small.fna", "Smalldup.fna", "TTT-small.fna", "trna_glutamine.fna",
+       "Verysmall.fna"]
+PROTEIN = ["sw100K1.fsa", "sw100K2.fsa"]
+MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
+MAX_TABLES = 16 * 1024       # store full tables only for small inputs
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def main():
+    if not os.path.exists(BIN):
+        sys.exit("build oracle/_ref first: make -f oracle/Makefile.ref")
+    os.makedirs(os.path.join(OUT, "fixtures"), exist_ok=True)
+    os.makedirs(os.path.join(OUT, "tables"), exist_ok=True)
+    golden = {}
+    for name, flag in [(f, "-dna") for f in DNA] + [(f, "-protein") for f in PROTEIN]:
+        src = os.path.join(REF, "testdata", name)
+        if not os.path.exists(src):
+            print("missing", src)
+            continue
+        size = os.path.getsize(src)
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            subprocess.run([BIN, flag, "-suf", "-lcp", "-bwt", "-db", src,
+                            "-indexname", idx], check=True)
+            entry = {"alphabet": flag[1:], "input_bytes": size,
+                     "input_md5": md5(src),
+                     "fixture": size <= MAX_FIXTURE, "tables": {}}
+            for ext in ("suf", "lcp", "llv", "bwt"):
+                p = idx + "." + ext
+                entry["tables"][ext] = {"md5": md5(p), "bytes": os.path.getsize(p)}
+            with open(idx + ".prj") as f:
+                entry["prj"] = f.read()
+            if size <= MAX_FIXTURE:
+                shutil.copyfile(src, os.path.join(OUT, "fixtures", name))
+            if size <= MAX_TABLES:
+                for ext in ("suf", "lcp", "llv", "bwt"):
+                    with open(idx + "." + ext, "rb") as fi, \
+                         gzip.GzipFile(os.path.join(OUT, "tables", name + "." + ext + ".gz"),
+                                       "wb", mtime=0) as fo:
+                        fo.write(fi.read())
+        golden[name] = entry
+        print(name, entry["tables"]["suf"]["md5"])
+    with open(os.path.join(OUT, "golden.json"), "w") as f:
+        json.dump(golden, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""Build and load the HIP engine (libgtamd_esa.so) through its C ABI.
+
+The library is built in-tree (next to this file) so that it travels to the GPU
+box with the repository snapshot.  There is no fallback: if it cannot be
+loaded, everything that needs it raises.
+"""
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
+SOURCES = [os.path.join(HERE, "csrc", f) for f in
+           ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip")]
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h")] + \
+          [os.path.join(ROOT, "include", "gtamd_esa.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> genometools_amd/libgtamd_esa.so"""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+           "-shared", "-Wall", "-Wno-unused-function", "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+class EsaStats(ctypes.Structure):
+    _fields_ = [("totallength", ctypes.c_uint64),
+                ("numberofallsortedsuffixes", ctypes.c_uint64),
+                ("longest", ctypes.c_uint64),
+                ("largelcpvalues", ctypes.c_uint64),
+                ("maxbranchdepth", ctypes.c_uint64),
+                ("lcptabsum", ctypes.c_uint64),
+                ("prefixlength", ctypes.c_uint32),
+                ("refine_rounds", ctypes.c_uint32),
+                ("tied_suffixes", ctypes.c_uint64)]
+
+
+class EsaTiming(ctypes.Structure):
+    _fields_ = [("total_ms", ctypes.c_float),
+                ("keygen_ms", ctypes.c_float),
+                ("sort_ms", ctypes.c_float),
+                ("finalize_ms", ctypes.c_float),
+                ("refine_ms", ctypes.c_float),
+                ("tie_fix_ms", ctypes.c_float),
+                ("scatter_ms", ctypes.c_float),
+                ("scatter_launches", ctypes.c_uint32),
+                ("scatter_items", ctypes.c_uint64)]
+
+
+# every symbol include/gtamd_esa.h declares: (restype, argtypes)
+_P = ctypes.c_void_p
+_U64 = ctypes.c_uint64
+_U32 = ctypes.c_uint32
+_INT = ctypes.c_int
+ABI = {
+    "gtamd_device_count": (_INT, []),
+    "gtamd_esa_last_error": (ctypes.c_char_p, []),
+    "gtamd_recommended_prefixlength": (_U32, [_U32, _U64]),
+    "gtamd_esa_create": (_P, [_INT, _U64, _U32]),
+    "gtamd_esa_destroy": (None, [_P]),
+    "gtamd_esa_set_part": (_INT, [_P, _U32, _U32]),
+    "gtamd_esa_set_sequence_bytes": (_INT, [_P, _P, _U64, _INT]),
+    "gtamd_esa_set_sequence_packed": (_INT, [_P, _P, _P, _U64]),
+    "gtamd_esa_run": (_INT, [_P, _U32]),
+    "gtamd_esa_table_entries": (_U64, [_P, _INT]),
+    "gtamd_esa_table_offset": (_U64, [_P]),
+    "gtamd_esa_table_device": (_P, [_P, _INT]),
+    "gtamd_esa_table_copy": (_INT, [_P, _INT, _P, _U64, _U64]),
+    "gtamd_esa_get_stats": (_INT, [_P, ctypes.POINTER(EsaStats)]),
+    "gtamd_esa_get_timing": (_INT, [_P, ctypes.POINTER(EsaTiming)]),
+    "gtamd_esa_build": (_INT, [_P, _U64, _U32, _U32, _P, _P, _P, _P, _U64,
+                               ctypes.POINTER(_U64), ctypes.POINTER(EsaStats)]),
+    "gtamd_synth_bytes": (_INT, [_INT, _INT, _U64, _U64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """ctypes handle with typed entry points; raises if the library is absent"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (needs hipcc); there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in ABI.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class EsaError(RuntimeError):
+    """mirrors a GtError message: 'gt suffixerator: error: <message>'"""
+
+
+def check(rc):
+    if rc != 0:
+        raise EsaError(load().gtamd_esa_last_error().decode())

@@ -1,0 +1,61 @@
+// esa_common.h -- shared declarations of the MI355X ESA engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+#define WAVE 64
+
+// error plumbing: every launcher returns 0 / -1 and leaves a message in the
+// thread-local buffer that gtamd_esa_last_error() hands out (GtError style).
+void gtamd_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      gtamd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                      __FILE__, __LINE__);                                    \
+      return -1;                                                              \
+    }                                                                         \
+  } while (0)
+
+#define TRY(expr)                                                             \
+  do {                                                                        \
+    if ((expr) != 0) return -1;                                               \
+  } while (0)
+
+static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// ---- key layout ------------------------------------------------------------
+// One 64-bit sort key per suffix:
+//   [ prefix: KEY_SYMS symbols x BITS ][ dcode ][ payload: symbol before the
+//   suffix ]
+// dcode = 0: no special among the first KEY_SYMS symbols;
+// dcode = KEY_SYMS - d (1..KEY_SYMS-1): first special after d letters (the
+//   prefix is padded with 1-bits behind the d letters, so the suffix sorts
+//   behind every suffix that continues with letters; a shorter run of letters
+//   gives a larger dcode and sorts later, equal runs fall back to the text
+//   position through the stable sort) -- this is the order the reference gets
+//   from "specials are unique symbols 256+position" (src/core/encseq.h:640);
+// dcode = all ones: the suffix starts with a special (tail of the table).
+// The payload rides along unsorted and yields the BWT symbol for free.
+template <int BITS> struct KeyLayout;
+template <> struct KeyLayout<2> {
+  static constexpr int KEY_SYMS = 28;       // 56 bits
+  static constexpr int DCODE_BITS = 5;
+  static constexpr int PAYLOAD_BITS = 3;
+  static constexpr int SYMS_PER_WORD = 32;
+};
+template <> struct KeyLayout<5> {
+  static constexpr int KEY_SYMS = 11;       // 55 bits
+  static constexpr int DCODE_BITS = 4;
+  static constexpr int PAYLOAD_BITS = 5;
+  static constexpr int SYMS_PER_WORD = 12;  // 60 bits used, 4 low bits idle
+};

@@ -1,0 +1,1089 @@
+// esa_engine.hip -- the hot path of `gt suffixerator` re-designed for MI355X:
+// suffix array + LCP + BWT of an encoded sequence, everything resident in HBM.
+//
+// Pipeline (one stream, no host round trips except two scalar read-backs):
+//   pack      bytes -> 2-bit (or 5-bit) words + special-position bitmap
+//   keygen    one 64-bit key per suffix (KEY_SYMS symbols + special code +
+//             preceding symbol), position as the 32-bit value
+//   sort      stable LSD radix sort of (key, position)        [esa_prims.hip]
+//   finalize  widen positions to .suf, LCP from clz(key xor key'), BWT from
+//             the key payload, mark suffixes tied on the whole key
+//   refine    only for tied suffixes: prefix doubling on a rank table
+//             (rank of suffix p+h decides among suffixes equal on h symbols)
+//   fixtied   LCP (direct word compare on the packed text) and BWT of the
+//             tied suffixes, .llv pairs
+//
+// What the reference does instead (for the record, not followed): bucket by a
+// k-mer prefix (src/match/sfx-suffixer.c:1703,2012), then sort each bucket with
+// a multikey quicksort family on 32-base words (src/match/sfx-bentsedg.c:1095),
+// LCP as a side output (src/match/sfx-lcpvalues.c:622).  The tables are
+// algorithm independent; only the order relation
+// (src/core/encseq.c:6449-6530, src/match/sfx-bentsedg.c:75-80) is shared.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../include/gtamd_esa.h"
+#include "esa_prims.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+void gtamd_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+extern "C" const char *gtamd_esa_last_error(void) { return g_err; }
+
+extern "C" int gtamd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ---------------------------------------------------------------------------
+// packed text access
+// ---------------------------------------------------------------------------
+struct Text {
+  const u64 *tb;   // packed symbols
+  const u64 *sp;   // special bitmap, bit (p & 63) of word p >> 6; bit n set
+  u64 n;           // totallength
+  u64 nw_tb, nw_sp;
+};
+
+__device__ __forceinline__ u64 tb_word(const Text &t, u64 w) {
+  return w < t.nw_tb ? t.tb[w] : 0ull;
+}
+__device__ __forceinline__ u64 sp_word(const Text &t, u64 w) {
+  return w < t.nw_sp ? t.sp[w] : 0ull;
+}
+// bit j = "position p + j is special", 64 positions
+__device__ __forceinline__ u64 sp_window(const Text &t, u64 p) {
+  const u64 w = p >> 6;
+  const int o = (int) (p & 63);
+  u64 r = sp_word(t, w) >> o;
+  if (o) r |= sp_word(t, w + 1) << (64 - o);
+  return r;
+}
+__device__ __forceinline__ bool is_special(const Text &t, u64 p) {
+  return (sp_word(t, p >> 6) >> (p & 63)) & 1ull;
+}
+
+template <int BITS> struct Sym;
+template <> struct Sym<2> {
+  static constexpr int WIN = 32;  // symbols delivered by window()
+  // 32 symbols starting at p, first symbol in the top bits
+  static __device__ __forceinline__ u64 window(const Text &t, u64 p) {
+    const u64 w = p >> 5;
+    const int o = (int) (p & 31) * 2;
+    const u64 hi = tb_word(t, w);
+    if (o == 0) return hi;
+    return (hi << o) | (tb_word(t, w + 1) >> (64 - o));
+  }
+  static __device__ __forceinline__ u32 at(const Text &t, u64 p) {
+    return (u32) (tb_word(t, p >> 5) >> (62 - 2 * (int) (p & 31))) & 3u;
+  }
+};
+template <> struct Sym<5> {
+  static constexpr int WIN = 11;  // at least 11 valid symbols
+  static __device__ __forceinline__ u64 window(const Text &t, u64 p) {
+    const u64 w = p / 12;
+    const int r = (int) (p - w * 12);
+    const u64 hi = tb_word(t, w) << (5 * r);
+    if (r <= 1) return hi;
+    return hi | (tb_word(t, w + 1) >> (5 * (12 - r)));
+  }
+  static __device__ __forceinline__ u32 at(const Text &t, u64 p) {
+    const u64 w = p / 12;
+    const int r = (int) (p - w * 12);
+    return (u32) (tb_word(t, w) >> (59 - 5 * r)) & 31u;
+  }
+};
+
+template <int BITS> struct Pay {
+  static constexpr u32 PB = KeyLayout<BITS>::PAYLOAD_BITS;
+  static constexpr u32 WILD = (1u << PB) - 3u, SEP = (1u << PB) - 2u,
+                       UNDEF = (1u << PB) - 1u;
+  // code of the symbol in front of suffix p
+  static __device__ __forceinline__ u32 before(const Text &t, u64 p) {
+    if (p == 0) return UNDEF;
+    const u32 c = Sym<BITS>::at(t, p - 1);
+    if (is_special(t, p - 1)) return (c & 1u) ? SEP : WILD;
+    return c;
+  }
+  // .bwt byte, src/match/sfx-run.c:173-210
+  static __device__ __forceinline__ u8 to_bwt(u32 code) {
+    if (code == SEP) return (u8) GTAMD_SEPARATOR;
+    if (code >= WILD) return (u8) GTAMD_WILDCARD;  // wildcard, or UNDEFBWTCHAR
+    return (u8) code;
+  }
+};
+
+template <int BITS> struct Key {
+  using L = KeyLayout<BITS>;
+  static constexpr int SYMS = L::KEY_SYMS;
+  static constexpr int PFX_BITS = SYMS * BITS;
+  static constexpr int LOW_BITS = 64 - PFX_BITS;          // dcode + payload
+  static constexpr u32 DMAX = (1u << L::DCODE_BITS) - 1u;  // suffix starts special
+  static constexpr u64 PAY_MASK = (1ull << L::PAYLOAD_BITS) - 1ull;
+  static __device__ __forceinline__ u32 dcode(u64 key) {
+    return (u32) (key >> L::PAYLOAD_BITS) & DMAX;
+  }
+  // number of letters in front of the first special, capped at SYMS
+  static __device__ __forceinline__ u32 letters(u64 key) {
+    const u32 dc = dcode(key);
+    return dc == 0 ? (u32) SYMS : (dc == DMAX ? 0u : (u32) SYMS - dc);
+  }
+};
+
+// common prefix of two suffixes p, q known to share l symbols: compare the
+// packed text word by word, stop at the first special on either side
+// (specials never match: src/core/encseq.c:6449-6530, sfx-linlcp.c:93,162)
+template <int BITS>
+__device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l) {
+  constexpr int S = Sym<BITS>::WIN;
+  for (;;) {
+    u64 x = Sym<BITS>::window(t, p + l) ^ Sym<BITS>::window(t, q + l);
+    if (BITS * S < 64) x &= ~0ull << (64 - BITS * S);
+    int m = x ? __clzll((long long) x) / BITS : S;
+    u64 s = sp_window(t, p + l) | sp_window(t, q + l);
+    if (S < 64) s &= (1ull << S) - 1ull;
+    const int ds = s ? __ffsll((unsigned long long) s) - 1 : S;
+    const int step = m < ds ? m : ds;
+    l += (u64) step;
+    if (step < S) return l;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// pack: bytes -> packed words + special bitmap
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void k_pack_symbols(
+    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ tb, u64 nwords) {
+  constexpr int SPW = KeyLayout<BITS>::SYMS_PER_WORD;
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 base = w * SPW;
+  u64 word = 0;
+#pragma unroll
+  for (int i = 0; i < SPW; i++) {
+    const u64 p = base + i;
+    u64 c = 0;
+    if (p < n) {
+      const u32 b = enc[p];
+      // a special keeps its kind in the low bit: 0 wildcard, 1 separator
+      c = b >= GTAMD_WILDCARD ? (b == GTAMD_SEPARATOR ? 1u : 0u) : b;
+    }
+    word |= c << (64 - BITS * (i + 1));
+  }
+  tb[w] = word;
+}
+
+__global__ __launch_bounds__(256) void k_pack_specials(
+    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ sp, u64 nwords) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 base = w * 64;
+  u64 word = 0;
+  if (base + 64 <= n && (((uintptr_t) (enc + base)) & 15) == 0) {
+    const uint4 *v = reinterpret_cast<const uint4 *>(enc + base);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint4 q = v[k];
+      const u32 parts[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if (((parts[a] >> (8 * b)) & 255u) >= GTAMD_WILDCARD)
+            word |= 1ull << (k * 16 + a * 4 + b);
+    }
+  } else {
+    for (int i = 0; i < 64; i++) {
+      const u64 p = base + i;
+      if (p < n ? enc[p] >= GTAMD_WILDCARD : p == n) word |= 1ull << i;
+    }
+  }
+  if (base <= n && n < base + 64) word |= 1ull << (n - base);  // virtual end
+  sp[w] = word;
+}
+
+// ---------------------------------------------------------------------------
+// keygen
+// ---------------------------------------------------------------------------
+template <int BITS>
+__device__ __forceinline__ u64 make_key(const Text &t, u64 p) {
+  using K = Key<BITS>;
+  constexpr int SYMS = K::SYMS;
+  const u32 pay = Pay<BITS>::before(t, p);
+  u64 s = sp_window(t, p) & ((1ull << SYMS) - 1ull);
+  const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+  if (d == 0)  // suffix starts with a special (or is the virtual end)
+    return (~0ull << KeyLayout<BITS>::PAYLOAD_BITS) | pay;
+  u64 pre = Sym<BITS>::window(t, p) >> K::LOW_BITS;  // SYMS symbols
+  u32 dc = 0;
+  if (d < SYMS) {
+    pre |= (1ull << (BITS * (SYMS - d))) - 1ull;  // pad behind the d letters
+    dc = (u32) (SYMS - d);
+  }
+  return (pre << K::LOW_BITS) | ((u64) dc << KeyLayout<BITS>::PAYLOAD_BITS) | pay;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
+                                                u64 *__restrict__ keys,
+                                                u32 *__restrict__ vals) {
+  const u64 base = (u64) blockIdx.x * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u64 p = base + (u64) j * 256 + threadIdx.x;
+    if (p < N) {
+      keys[p] = make_key<BITS>(t, p);
+      vals[p] = (u32) p;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// finalize
+// ---------------------------------------------------------------------------
+struct Stats {          // device-side accumulators
+  unsigned long long numties;     // entries tied with their predecessor
+  unsigned long long lcpsum;      // masked sum
+  unsigned long long numlarge;    // lcp >= 255
+  unsigned long long longest;     // index of suffix 0
+  u32 maxlcp;
+  u32 count;                      // generic counter (compaction totals)
+};
+
+constexpr int FIN_THREADS = 256;
+constexpr int FIN_PER_THREAD = 4;
+constexpr int FIN_TILE = FIN_THREADS * FIN_PER_THREAD * 4;  // 4096 entries
+
+// Each thread owns 4 consecutive entries so that .lcp/.bwt leave as one
+// 32-bit store and .suf as two 16-byte stores per lane.
+template <int BITS>
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(
+    const u64 *__restrict__ keys, const u32 *__restrict__ pos, u64 N,
+    u32 prefixlength, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    u8 *__restrict__ bwt, u64 *__restrict__ tiebits, Stats *stats) {
+  using K = Key<BITS>;
+  __shared__ unsigned long long s_sum[FIN_THREADS / 64];
+  __shared__ unsigned long long s_ties[FIN_THREADS / 64];
+  __shared__ u32 s_max[FIN_THREADS / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long sum = 0, ties = 0;
+  u32 mx = 0;
+#pragma unroll
+  for (int r = 0; r < FIN_PER_THREAD; r++) {
+    const u64 i0 = (u64) blockIdx.x * FIN_TILE +
+                   ((u64) r * FIN_THREADS + threadIdx.x) * 4;
+    u64 k[4];
+    u32 p[4];
+    if (i0 + 4 <= N) {
+      const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + i0);
+      const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
+      k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
+      const uint4 q = *reinterpret_cast<const uint4 *>(pos + i0);
+      p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        k[c] = i0 + c < N ? keys[i0 + c] : ~0ull;
+        p[c] = i0 + c < N ? pos[i0 + c] : 0u;
+      }
+    }
+    // predecessor key: previous lane's last key, or a global load at the
+    // wave's left edge
+    u64 prevk = __shfl_up(k[3], 1, 64);
+    if (lane == 0) prevk = (i0 > 0 && i0 < N + 4) ? keys[i0 - 1] : ~0ull;
+    u32 lcpv[4], tiemask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const u64 i = i0 + c;
+      const u64 a = c == 0 ? prevk : k[c - 1], b = k[c];
+      const u32 da = K::letters(a), db = K::letters(b);
+      const u64 x = (a ^ b) >> K::LOW_BITS;
+      u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / BITS
+                : (u32) K::SYMS;
+      u32 l = m < da ? m : da;
+      l = l < db ? l : db;
+      bool tie = (m == (u32) K::SYMS) && (K::dcode(a) == 0) && (K::dcode(b) == 0);
+      if (i == 0 || i >= N) { l = 0; tie = false; }
+      lcpv[c] = l;
+      if (tie) { tiemask |= 1u << c; ties++; }
+      else if (i < N) {
+        mx = l > mx ? l : mx;
+        if (db >= prefixlength) sum += l;
+        if (p[c] == 0) stats->longest = i;
+      }
+    }
+    if (i0 + 4 <= N) {
+      if (suf != nullptr) {
+        ulonglong2 s0, s1;
+        s0.x = p[0]; s0.y = p[1]; s1.x = p[2]; s1.y = p[3];
+        *reinterpret_cast<ulonglong2 *>(suf + i0) = s0;
+        *reinterpret_cast<ulonglong2 *>(suf + i0 + 2) = s1;
+      }
+      if (lcp != nullptr)
+        *reinterpret_cast<u32 *>(lcp + i0) =
+            lcpv[0] | (lcpv[1] << 8) | (lcpv[2] << 16) | (lcpv[3] << 24);
+      if (bwt != nullptr) {
+        u32 bw = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          bw |= (u32) Pay<BITS>::to_bwt((u32) (k[c] & K::PAY_MASK)) << (8 * c);
+        *reinterpret_cast<u32 *>(bwt + i0) = bw;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        if (i0 + c < N) {
+          if (suf != nullptr) suf[i0 + c] = p[c];
+          if (lcp != nullptr) lcp[i0 + c] = (u8) lcpv[c];
+          if (bwt != nullptr)
+            bwt[i0 + c] = Pay<BITS>::to_bwt((u32) (k[c] & K::PAY_MASK));
+        }
+      }
+    }
+    // tie bits: 4 per lane, 16 lanes per 64-bit word
+    u64 tw = (u64) tiemask << (4 * (lane & 15));
+    tw |= __shfl_xor(tw, 1, 64);
+    tw |= __shfl_xor(tw, 2, 64);
+    tw |= __shfl_xor(tw, 4, 64);
+    tw |= __shfl_xor(tw, 8, 64);
+    if ((lane & 15) == 0 && i0 < N) tiebits[i0 >> 6] = tw;
+  }
+  // block reduction of the statistics, one atomic each per block
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    ties += __shfl_xor(ties, d, 64);
+    const u32 o = __shfl_xor(mx, d, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) { s_sum[w] = sum; s_ties[w] = ties; s_max[w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long S = 0, T = 0;
+    u32 M = 0;
+    for (int i = 0; i < FIN_THREADS / 64; i++) {
+      S += s_sum[i]; T += s_ties[i]; M = s_max[i] > M ? s_max[i] : M;
+    }
+    if (S) atomicAdd(&stats->lcpsum, S);
+    if (T) atomicAdd(&stats->numties, T);
+    if (M) atomicMax(&stats->maxlcp, M);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tied suffixes: unresolved list, group heads, rank table
+// ---------------------------------------------------------------------------
+// per 64-entry word: unresolved mask count and the highest "not tied" index
+__global__ __launch_bounds__(256) void k_tie_words(
+    const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
+    u32 *__restrict__ headw) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  const u64 u = t | (t >> 1) | (nx << 63);
+  cnt[w] = (u32) __popcll(u);
+  const u64 z = ~t;
+  headw[w] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : 0u;
+}
+
+// head (first index) of the tie group that entry i belongs to
+__device__ __forceinline__ u32 group_head(const u64 *tiebits, const u32 *carry,
+                                          u64 i) {
+  const u64 w = i >> 6;
+  const int b = (int) (i & 63);
+  const u64 below = b == 63 ? ~0ull : ((2ull << b) - 1ull);
+  const u64 z = ~tiebits[w] & below;
+  return z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carry[w];
+}
+
+__global__ __launch_bounds__(256) void k_unres_emit(
+    const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
+    const u32 *__restrict__ carry, const u32 *__restrict__ sa32,
+    u32 *__restrict__ uidx0, u32 *__restrict__ uidx, u32 *__restrict__ upos,
+    u32 *__restrict__ ugrp) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  u64 u = t | (t >> 1) | (nx << 63);
+  u32 j = off[w];
+  while (u) {
+    const int b = __ffsll((unsigned long long) u) - 1;
+    u &= u - 1;
+    const u64 i = w * 64 + b;
+    uidx0[j] = (u32) i;
+    uidx[j] = (u32) i;
+    upos[j] = sa32[i];
+    ugrp[j] = group_head(tiebits, carry, i);
+    j++;
+  }
+}
+
+// rank[sa[i]] = head of i's group, for every entry (the "ISA" of the first
+// sort; refined in place by the doubling rounds)
+__global__ __launch_bounds__(256) void k_rank_init(
+    const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
+    const u32 *__restrict__ sa32, u64 N, u32 *__restrict__ rank) {
+  const u64 base = (u64) blockIdx.x * 1024;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const u64 i = base + (u64) j * 256 + threadIdx.x;
+    if (i < N) rank[sa32[i]] = group_head(tiebits, carry, i);
+  }
+}
+
+// composite key (group, rank of the suffix h symbols further on)
+__global__ __launch_bounds__(256) void k_round_gather(
+    const u32 *__restrict__ upos, const u32 *__restrict__ ugrp, u64 m, u64 h,
+    u64 n, const u32 *__restrict__ rank, u64 *__restrict__ ckey,
+    u32 *__restrict__ cval) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const u32 p = upos[j];
+  u64 q = (u64) p + h;
+  if (q > n) q = n;  // cannot happen for a tied suffix; keeps the load in range
+  ckey[j] = ((u64) ugrp[j] << 32) | rank[q];
+  cval[j] = p;
+}
+
+__global__ __launch_bounds__(256) void k_round_heads(
+    const u64 *__restrict__ ckey, const u32 *__restrict__ uidx, u64 m,
+    u32 *__restrict__ hv) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const bool head = j == 0 || ckey[j] != ckey[j - 1];
+  hv[j] = head ? uidx[j] : 0u;
+}
+
+// write the round's result back: positions into the suffix array, new group
+// heads into the rank table; flag what is still tied
+__global__ __launch_bounds__(256) void k_round_apply(
+    const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
+    const u32 *__restrict__ uidx, u64 m, u32 *__restrict__ sa32,
+    u32 *__restrict__ rank, u32 *__restrict__ keep) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const u32 p = cval[j], g = gnew[j], i = uidx[j];
+  sa32[i] = p;
+  rank[p] = g;
+  const bool head = g == i;
+  const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
+  keep[j] = (head && nexthead) ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(256) void k_round_compact(
+    const u32 *__restrict__ keep, const u32 *__restrict__ off,
+    const u32 *__restrict__ uidx, const u32 *__restrict__ cval,
+    const u32 *__restrict__ gnew, u64 m, u32 *__restrict__ uidx2,
+    u32 *__restrict__ upos2, u32 *__restrict__ ugrp2, Stats *stats) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  if (keep[j]) {
+    const u32 o = off[j];
+    uidx2[o] = uidx[j];
+    upos2[o] = cval[j];
+    ugrp2[o] = gnew[j];
+  }
+  if (j + 1 == m) stats->count = off[j] + keep[j];
+}
+
+// total of an exclusively scanned count array (last offset + last count)
+__global__ void k_total(const u32 *__restrict__ off, const u32 *__restrict__ cnt,
+                        u64 n, Stats *stats) {
+  stats->count = n ? off[n - 1] + cnt[n - 1] : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// tied suffixes: final LCP / BWT / .suf entries and .llv
+// ---------------------------------------------------------------------------
+template <int BITS>
+__global__ __launch_bounds__(256) void k_fix_tied(
+    Text t, const u32 *__restrict__ uidx0, u64 m0,
+    const u64 *__restrict__ tiebits, const u32 *__restrict__ sa32,
+    u32 prefixlength, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    u8 *__restrict__ bwt, u32 *__restrict__ lcpu, u32 *__restrict__ large,
+    bool want_lcp, Stats *stats) {
+  __shared__ unsigned long long s_sum[4], s_large[4];
+  __shared__ u32 s_max[4];
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long sum = 0, nlarge = 0;
+  u32 mx = 0;
+  if (j < m0) {
+    const u64 i = uidx0[j];
+    const u64 p = sa32[i];
+    if (suf != nullptr) suf[i] = p;
+    if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
+    if (p == 0) stats->longest = i;
+    u32 l = 0, isl = 0;
+    if (want_lcp && ((tiebits[i >> 6] >> (i & 63)) & 1ull)) {
+      const u64 q = sa32[i - 1];
+      u64 lv = lcp_extend<BITS>(t, q, p, (u64) Key<BITS>::SYMS);
+      l = (u32) lv;
+      if (lcp != nullptr)
+        lcp[i] = (u8) (l < GTAMD_LCPOVERFLOW ? l : GTAMD_LCPOVERFLOW);
+      isl = l >= GTAMD_LCPOVERFLOW;
+      mx = l;
+      sum = l;   // tied suffixes have >= KEY_SYMS >= prefixlength letters
+      nlarge = isl;
+    }
+    lcpu[j] = l;
+    large[j] = isl;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    nlarge += __shfl_xor(nlarge, d, 64);
+    const u32 o = __shfl_xor(mx, d, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) { s_sum[w] = sum; s_large[w] = nlarge; s_max[w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long S = 0, Lg = 0;
+    u32 M = 0;
+    for (int i = 0; i < 4; i++) {
+      S += s_sum[i]; Lg += s_large[i]; M = s_max[i] > M ? s_max[i] : M;
+    }
+    if (S) atomicAdd(&stats->lcpsum, S);
+    if (Lg) atomicAdd(&stats->numlarge, Lg);
+    if (M) atomicMax(&stats->maxlcp, M);
+  }
+  (void) prefixlength;
+}
+
+// .llv pairs in index order: (index into the lcp table, value),
+// src/match/sfx-lcpvalues.c:402-411
+__global__ __launch_bounds__(256) void k_llv_emit(
+    const u32 *__restrict__ uidx0, const u32 *__restrict__ lcpu,
+    const u32 *__restrict__ large, const u32 *__restrict__ off, u64 m0,
+    u64 index_offset, u64 *__restrict__ llv) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m0 || !large[j]) return;
+  const u64 o = off[j];
+  llv[2 * o] = index_offset + uidx0[j];
+  llv[2 * o + 1] = lcpu[j];
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct gtamd_esa_ctx {
+  int device;
+  u32 sigma;
+  int bits;                // 2 or 5
+  u64 max_n, n, N;         // N = n + 1 entries
+  hipStream_t st;
+  // resident sequence
+  u64 *tb_own, *sp_own;
+  Text text;
+  bool have_text;
+  // sort buffers
+  u64 *k0, *k1;
+  u32 *v0, *v1;
+  u32 *rws;                // radix / scan workspace
+  u64 rws_words;
+  // outputs
+  u64 *suf;
+  u8 *lcp, *bwt;
+  u64 *llv;
+  u64 llv_pairs, llv_cap;
+  u64 *tiebits;
+  Stats *d_stats, *h_stats;   // h_stats: pinned host mirror
+  // refinement arena (grow-only)
+  void *arena;
+  u64 arena_bytes;
+  // results
+  u32 want;
+  bool ran;
+  gtamd_esa_stats stats;
+  gtamd_esa_timing timing;
+  // events
+  hipEvent_t ev[8];
+  hipEvent_t ev_scatter[2 * 16];
+};
+
+static void free_dev(void *p) { if (p != nullptr) (void) hipFree(p); }
+
+extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
+  if (c == nullptr) return;
+  (void) hipSetDevice(c->device);
+  if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
+  free_dev(c->tb_own); free_dev(c->sp_own);
+  free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
+  free_dev(c->rws); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
+  free_dev(c->llv); free_dev(c->tiebits); free_dev(c->d_stats);
+  free_dev(c->arena);
+  if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
+  for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
+  for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
+  if (c->st != nullptr) (void) hipStreamDestroy(c->st);
+  delete c;
+}
+
+#define CTX_TRY(expr)                                                         \
+  do {                                                                        \
+    hipError_t e_ = (expr);                                                   \
+    if (e_ != hipSuccess) {                                                   \
+      gtamd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                      __FILE__, __LINE__);                                    \
+      gtamd_esa_destroy(c);                                                   \
+      return nullptr;                                                         \
+    }                                                                         \
+  } while (0)
+
+extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
+                                           uint32_t numofchars) {
+  if (gtamd_device_count() <= device || device < 0) {
+    gtamd_set_error("no HIP device %d available (this library has no CPU "
+                    "fallback)", device);
+    return nullptr;
+  }
+  if (numofchars < 2 || numofchars > 28) {
+    gtamd_set_error("alphabet size %u not supported (2..28)", numofchars);
+    return nullptr;
+  }
+  if (max_n + 1 >= (1ull << 32) - 4096) {
+    gtamd_set_error("sequence of %llu symbols exceeds the 32-bit position "
+                    "range of a single-device build",
+                    (unsigned long long) max_n);
+    return nullptr;
+  }
+  gtamd_esa_ctx *c = new gtamd_esa_ctx();
+  memset((void *) c, 0, sizeof *c);
+  c->device = device;
+  c->sigma = numofchars;
+  c->bits = numofchars <= 4 ? 2 : 5;
+  c->max_n = max_n;
+  const u64 N = max_n + 1;
+  CTX_TRY(hipSetDevice(device));
+  CTX_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+  const u64 spw = c->bits == 2 ? 32 : 12;
+  CTX_TRY(hipMalloc(&c->tb_own, (div_up(N, spw) + 2) * 8));
+  CTX_TRY(hipMalloc(&c->sp_own, (div_up(N, 64) + 2) * 8));
+  const u64 Npad = N + 8;
+  CTX_TRY(hipMalloc(&c->k0, Npad * 8));
+  CTX_TRY(hipMalloc(&c->k1, Npad * 8));
+  CTX_TRY(hipMalloc(&c->v0, Npad * 4));
+  CTX_TRY(hipMalloc(&c->v1, Npad * 4));
+  c->rws_words = radix_workspace_words(N) + 4 * (div_up(N, 64) + 64) +
+                 scan_workspace_words(div_up(N, 64)) + 64;
+  CTX_TRY(hipMalloc(&c->rws, c->rws_words * 4));
+  CTX_TRY(hipMalloc(&c->suf, Npad * 8));
+  CTX_TRY(hipMalloc(&c->lcp, Npad));
+  CTX_TRY(hipMalloc(&c->bwt, Npad));
+  CTX_TRY(hipMalloc(&c->tiebits, (div_up(N, 64) + 2) * 8));
+  CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
+  CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
+  for (auto &e : c->ev) CTX_TRY(hipEventCreate(&e));
+  for (auto &e : c->ev_scatter) CTX_TRY(hipEventCreate(&e));
+  return c;
+}
+
+extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
+                                  uint32_t numparts) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  if (numparts != 1 || part != 0) {
+    gtamd_set_error("part builds (%u of %u) are not implemented yet", part,
+                    numparts);
+    return -1;
+  }
+  return 0;
+}
+
+static int set_n(gtamd_esa_ctx *c, u64 n) {
+  if (n > c->max_n) {
+    gtamd_set_error("sequence length %llu exceeds the context capacity %llu",
+                    (unsigned long long) n, (unsigned long long) c->max_n);
+    return -1;
+  }
+  c->n = n;
+  c->N = n + 1;
+  c->ran = false;
+  return 0;
+}
+
+extern "C" int gtamd_esa_set_sequence_bytes(gtamd_esa_ctx *c,
+                                            const uint8_t *enc, uint64_t n,
+                                            int is_device) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  TRY(set_n(c, n));
+  HIP_TRY(hipSetDevice(c->device));
+  const u8 *d_enc = enc;
+  u8 *staged = nullptr;
+  if (!is_device && n > 0) {
+    // stage through the (not yet used) key buffer
+    staged = reinterpret_cast<u8 *>(c->k1);
+    HIP_TRY(hipMemcpyAsync(staged, enc, n, hipMemcpyHostToDevice, c->st));
+    d_enc = staged;
+  }
+  const u64 spw = c->bits == 2 ? 32 : 12;
+  const u64 nw_tb = div_up(c->N, spw), nw_sp = div_up(c->N, 64);
+  if (c->bits == 2)
+    k_pack_symbols<2><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(
+        d_enc, n, c->tb_own, nw_tb);
+  else
+    k_pack_symbols<5><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(
+        d_enc, n, c->tb_own, nw_tb);
+  HIP_TRY(hipGetLastError());
+  k_pack_specials<<<(u32) div_up(nw_sp, 256), 256, 0, c->st>>>(d_enc, n,
+                                                              c->sp_own, nw_sp);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->st));
+  c->text.tb = c->tb_own; c->text.sp = c->sp_own; c->text.n = n;
+  c->text.nw_tb = nw_tb; c->text.nw_sp = nw_sp;
+  c->have_text = true;
+  return 0;
+}
+
+extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
+                                             const uint64_t *twobit,
+                                             const uint64_t *specialbits,
+                                             uint64_t n) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  if (c->bits != 2) {
+    gtamd_set_error("packed input is defined for the 2-bit DNA layout only");
+    return -1;
+  }
+  TRY(set_n(c, n));
+  c->text.tb = twobit; c->text.sp = specialbits; c->text.n = n;
+  c->text.nw_tb = div_up(n, 32); c->text.nw_sp = div_up(n + 1, 64);
+  c->have_text = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// the run
+// ---------------------------------------------------------------------------
+static int ensure_arena(gtamd_esa_ctx *c, u64 bytes) {
+  if (bytes <= c->arena_bytes) return 0;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  free_dev(c->arena);
+  c->arena = nullptr;
+  c->arena_bytes = 0;
+  bytes += bytes / 8 + (1 << 20);
+  if (hipMalloc(&c->arena, bytes) != hipSuccess) {
+    gtamd_set_error("cannot allocate %llu bytes of device memory for the "
+                    "refinement of tied suffixes",
+                    (unsigned long long) bytes);
+    (void) hipGetLastError();
+    return -1;
+  }
+  c->arena_bytes = bytes;
+  return 0;
+}
+
+static int fetch_stats(gtamd_esa_ctx *c) {
+  HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats),
+                         hipMemcpyDeviceToHost, c->st));
+  HIP_TRY(hipStreamSynchronize(c->st));
+  return 0;
+}
+
+static int bits_for(u64 maxvalue) {
+  int b = 1;
+  while (b < 64 && (maxvalue >> b) != 0) b++;
+  return b;
+}
+
+template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
+  using K = Key<BITS>;
+  const u64 N = c->N, n = c->n;
+  hipStream_t st = c->st;
+  const bool want_suf = want & GTAMD_WANT_SUF, want_lcp = want & GTAMD_WANT_LCP,
+             want_bwt = want & GTAMD_WANT_BWT;
+  const u32 prefixlength = gtamd_recommended_prefixlength(c->sigma, n);
+  if (prefixlength > (u32) K::SYMS) {
+    gtamd_set_error("prefixlength %u exceeds the key width %d", prefixlength,
+                    K::SYMS);
+    return -1;
+  }
+  memset(&c->timing, 0, sizeof c->timing);
+  memset(&c->stats, 0, sizeof c->stats);
+  c->llv_pairs = 0;
+  HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
+  HIP_TRY(hipEventRecord(c->ev[0], st));
+
+  // keygen
+  k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[1], st));
+
+  // first sort: all key bits above the payload
+  int shifts[16], widths[16], np = 0;
+  for (int b = KeyLayout<BITS>::PAYLOAD_BITS; b < 64; b += 8) {
+    shifts[np] = b;
+    widths[np] = 64 - b < 8 ? 64 - b : 8;
+    np++;
+  }
+  int nev = 0;
+  TRY(radix_sort_pairs<u32>(c->k0, c->v0, c->k1, c->v1, N, shifts, widths, np,
+                            c->rws, st, c->ev_scatter, &nev));
+  u64 *skey = (np & 1) ? c->k1 : c->k0;   // sorted keys
+  u32 *sa32 = (np & 1) ? c->v1 : c->v0;   // positions in suffix order
+  u64 *fkey = (np & 1) ? c->k0 : c->k1;   // free key-sized buffer
+  u32 *rank = (np & 1) ? c->v0 : c->v1;   // free value-sized buffer
+  HIP_TRY(hipEventRecord(c->ev[2], st));
+
+  // finalize
+  k_finalize<BITS><<<(u32) div_up(N, FIN_TILE), FIN_THREADS, 0, st>>>(
+      skey, sa32, N, prefixlength, want_suf ? c->suf : nullptr,
+      want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, c->tiebits,
+      c->d_stats);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[3], st));
+  TRY(fetch_stats(c));
+  const u64 numties = c->h_stats->numties;
+  u32 rounds = 0;
+  u64 m0 = 0;
+  HIP_TRY(hipEventRecord(c->ev[4], st));
+  HIP_TRY(hipEventRecord(c->ev[5], st));
+  if (numties > 0) {
+    // ---- unresolved list and group heads
+    const u64 nwords = div_up(N, 64);
+    u32 *cntw = c->rws;                    // radix workspace is idle now
+    u32 *headw = cntw + nwords + 16;
+    u32 *offw = headw + nwords + 16;
+    u32 *carry = offw + nwords + 16;
+    u32 *scanws = carry + nwords + 16;
+    k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(c->tiebits, nwords,
+                                                          cntw, headw);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
+    TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
+    k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
+    HIP_TRY(hipGetLastError());
+    TRY(fetch_stats(c));
+    m0 = c->h_stats->count;
+    // arena layout (u32 units unless noted)
+    const u64 mp = m0 + 64;
+    const u64 need = mp * 4 * 12 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
+                     scan_workspace_words(m0) * 4 + 4096;
+    TRY(ensure_arena(c, need));
+    u32 *a32 = reinterpret_cast<u32 *>(c->arena);
+    u64 *ckey_a = reinterpret_cast<u64 *>(a32); a32 += 2 * mp;
+    u64 *ckey_b = reinterpret_cast<u64 *>(a32); a32 += 2 * mp;
+    u32 *uidx0 = a32; a32 += mp;
+    u32 *uidx = a32; a32 += mp;
+    u32 *upos = a32; a32 += mp;
+    u32 *ugrp = a32; a32 += mp;
+    u32 *uidx2 = a32; a32 += mp;
+    u32 *upos2 = a32; a32 += mp;
+    u32 *ugrp2 = a32; a32 += mp;
+    u32 *cval_a = a32; a32 += mp;
+    u32 *cval_b = a32; a32 += mp;
+    u32 *hv = a32; a32 += mp;      // head values -> new group ids
+    u32 *keep = a32; a32 += mp;
+    u32 *koff = a32; a32 += mp;
+    u32 *rws2 = a32;               // radix + scan workspace for the rounds
+    u32 *scanws2 = rws2 + radix_workspace_words(m0);
+    k_unres_emit<<<(u32) div_up(nwords, 256), 256, 0, st>>>(
+        c->tiebits, nwords, offw, carry, sa32, uidx0, uidx, upos, ugrp);
+    HIP_TRY(hipGetLastError());
+    k_rank_init<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->tiebits, carry, sa32,
+                                                      N, rank);
+    HIP_TRY(hipGetLastError());
+    // ---- doubling rounds
+    const int nb = bits_for(N - 1);
+    int cs[16], cw[16], cnp = 0;
+    for (int part = 0; part < 2; part++)
+      for (int b = 0; b < nb; b += 8) {
+        cs[cnp] = part * 32 + b;
+        cw[cnp] = nb - b < 8 ? nb - b : 8;
+        cnp++;
+      }
+    u64 m = m0, h = (u64) K::SYMS;
+    while (m > 0) {
+      if (++rounds > 64) {
+        gtamd_set_error("prefix doubling did not converge after 64 rounds");
+        return -1;
+      }
+      const u32 g = (u32) div_up(m, 256);
+      k_round_gather<<<g, 256, 0, st>>>(upos, ugrp, m, h, n, rank, ckey_a, cval_a);
+      HIP_TRY(hipGetLastError());
+      TRY(radix_sort_pairs<u32>(ckey_a, cval_a, ckey_b, cval_b, m, cs, cw, cnp,
+                                rws2, st, nullptr, nullptr));
+      const u64 *ck = (cnp & 1) ? ckey_b : ckey_a;
+      const u32 *cv = (cnp & 1) ? cval_b : cval_a;
+      k_round_heads<<<g, 256, 0, st>>>(ck, uidx, m, hv);
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_MAX, hv, hv, m, true, scanws2, st));
+      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, m, sa32, rank, keep);
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, keep, koff, m, false, scanws2, st));
+      k_round_compact<<<g, 256, 0, st>>>(keep, koff, uidx, cv, hv, m, uidx2,
+                                         upos2, ugrp2, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      TRY(fetch_stats(c));
+      m = c->h_stats->count;
+      u32 *t;
+      t = uidx; uidx = uidx2; uidx2 = t;
+      t = upos; upos = upos2; upos2 = t;
+      t = ugrp; ugrp = ugrp2; ugrp2 = t;
+      h *= 2;
+    }
+    HIP_TRY(hipEventRecord(c->ev[5], st));
+    // ---- final entries of the tied suffixes
+    u32 *lcpu = cval_a, *large = cval_b, *loff = keep;
+    k_fix_tied<BITS><<<(u32) div_up(m0, 256), 256, 0, st>>>(
+        c->text, uidx0, m0, c->tiebits, sa32, prefixlength,
+        want_suf ? c->suf : nullptr, want_lcp ? c->lcp : nullptr,
+        want_bwt ? c->bwt : nullptr, lcpu, large, want_lcp, c->d_stats);
+    HIP_TRY(hipGetLastError());
+    if (want_lcp) {
+      TRY(scan_u32(SCAN_SUM, large, loff, m0, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(loff, large, m0, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      TRY(fetch_stats(c));
+      const u64 pairs = c->h_stats->count;
+      if (pairs > c->llv_cap) {
+        free_dev(c->llv);
+        c->llv = nullptr;
+        c->llv_cap = 0;
+        HIP_TRY(hipMalloc(&c->llv, (pairs + pairs / 4 + 1024) * 16));
+        c->llv_cap = pairs + pairs / 4 + 1024;
+      }
+      if (pairs > 0) {
+        k_llv_emit<<<(u32) div_up(m0, 256), 256, 0, st>>>(uidx0, lcpu, large,
+                                                         loff, m0, 0, c->llv);
+        HIP_TRY(hipGetLastError());
+      }
+      c->llv_pairs = pairs;
+    }
+  }
+  HIP_TRY(hipEventRecord(c->ev[6], st));
+  TRY(fetch_stats(c));
+  (void) fkey;
+
+  // results
+  c->stats.totallength = n;
+  c->stats.numberofallsortedsuffixes = N;
+  c->stats.longest = c->h_stats->longest;
+  c->stats.largelcpvalues = want_lcp ? c->h_stats->numlarge : 0;
+  c->stats.maxbranchdepth = want_lcp ? c->h_stats->maxlcp : 0;
+  c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum : 0;
+  c->stats.prefixlength = prefixlength;
+  c->stats.refine_rounds = rounds;
+  c->stats.tied_suffixes = m0;
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); c->timing.total_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->timing.keygen_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); c->timing.sort_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[2], c->ev[3])); c->timing.finalize_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); c->timing.refine_ms = ms;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev[5], c->ev[6])); c->timing.tie_fix_ms = ms;
+  float sc = 0;
+  for (int i = 0; i < nev; i++) {
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev_scatter[2 * i], c->ev_scatter[2 * i + 1]));
+    sc += ms;
+  }
+  c->timing.scatter_ms = sc;
+  c->timing.scatter_launches = (u32) nev;
+  c->timing.scatter_items = N;
+  c->want = want;
+  c->ran = true;
+  return 0;
+}
+
+extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  if (!c->have_text) { gtamd_set_error("no sequence set"); return -1; }
+  if ((want & 7u) == 0) { gtamd_set_error("nothing requested"); return -1; }
+  HIP_TRY(hipSetDevice(c->device));
+  return c->bits == 2 ? run_impl<2>(c, want) : run_impl<5>(c, want);
+}
+
+// ---------------------------------------------------------------------------
+// outputs
+// ---------------------------------------------------------------------------
+extern "C" uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *c,
+                                            gtamd_table which) {
+  if (c == nullptr || !c->ran) return 0;
+  return which == GTAMD_TAB_LLV ? c->llv_pairs : c->N;
+}
+extern "C" uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *c) {
+  (void) c;
+  return 0;
+}
+extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
+                                              gtamd_table which) {
+  if (c == nullptr || !c->ran) return nullptr;
+  switch (which) {
+    case GTAMD_TAB_SUF: return (c->want & GTAMD_WANT_SUF) ? c->suf : nullptr;
+    case GTAMD_TAB_LCP: return (c->want & GTAMD_WANT_LCP) ? c->lcp : nullptr;
+    case GTAMD_TAB_BWT: return (c->want & GTAMD_WANT_BWT) ? c->bwt : nullptr;
+    case GTAMD_TAB_LLV: return (c->want & GTAMD_WANT_LCP) ? c->llv : nullptr;
+  }
+  return nullptr;
+}
+extern "C" int gtamd_esa_table_copy(gtamd_esa_ctx *c, gtamd_table which,
+                                    void *dst, uint64_t first, uint64_t count) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  const void *src = gtamd_esa_table_device(c, which);
+  const u64 entries = gtamd_esa_table_entries(c, which);
+  if (count == 0) return 0;
+  if (src == nullptr || first + count > entries) {
+    gtamd_set_error("table %d not available or range [%llu,+%llu) outside its "
+                    "%llu entries", (int) which, (unsigned long long) first,
+                    (unsigned long long) count, (unsigned long long) entries);
+    return -1;
+  }
+  const u64 esz = which == GTAMD_TAB_SUF ? 8 : (which == GTAMD_TAB_LLV ? 16 : 1);
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(dst, (const u8 *) src + first * esz, count * esz,
+                    hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int gtamd_esa_get_stats(const gtamd_esa_ctx *c, gtamd_esa_stats *s) {
+  if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
+  *s = c->stats;
+  return 0;
+}
+extern "C" int gtamd_esa_get_timing(const gtamd_esa_ctx *c, gtamd_esa_timing *t) {
+  if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
+  *t = c->timing;
+  return 0;
+}
+
+extern "C" int gtamd_esa_build(const uint8_t *enc, uint64_t n,
+                               uint32_t numofchars, uint32_t want,
+                               uint64_t *suf, uint8_t *lcp, uint8_t *bwt,
+                               uint64_t *llv, uint64_t llv_capacity,
+                               uint64_t *llv_pairs, gtamd_esa_stats *st) {
+  gtamd_esa_ctx *c = gtamd_esa_create(0, n, numofchars);
+  if (c == nullptr) return -1;
+  int rc = gtamd_esa_set_sequence_bytes(c, enc, n, 0);
+  if (rc == 0) rc = gtamd_esa_run(c, want);
+  if (rc == 0 && suf != nullptr && (want & GTAMD_WANT_SUF))
+    rc = gtamd_esa_table_copy(c, GTAMD_TAB_SUF, suf, 0, n + 1);
+  if (rc == 0 && lcp != nullptr && (want & GTAMD_WANT_LCP))
+    rc = gtamd_esa_table_copy(c, GTAMD_TAB_LCP, lcp, 0, n + 1);
+  if (rc == 0 && bwt != nullptr && (want & GTAMD_WANT_BWT))
+    rc = gtamd_esa_table_copy(c, GTAMD_TAB_BWT, bwt, 0, n + 1);
+  if (rc == 0 && (want & GTAMD_WANT_LCP)) {
+    const u64 pairs = gtamd_esa_table_entries(c, GTAMD_TAB_LLV);
+    if (llv_pairs != nullptr) *llv_pairs = pairs;
+    if (llv != nullptr) {
+      if (pairs > llv_capacity) {
+        gtamd_set_error(".llv needs %llu pairs, caller provided room for %llu",
+                        (unsigned long long) pairs,
+                        (unsigned long long) llv_capacity);
+        rc = -1;
+      } else
+        rc = gtamd_esa_table_copy(c, GTAMD_TAB_LLV, llv, 0, pairs);
+    }
+  }
+  if (rc == 0 && st != nullptr) rc = gtamd_esa_get_stats(c, st);
+  gtamd_esa_destroy(c);
+  return rc;
+}

@@ -1,0 +1,25 @@
+// esa_prims.h -- device-wide primitives (scan, radix sort) of the ESA engine.
+#pragma once
+#include "esa_common.h"
+
+enum { SCAN_SUM = 0, SCAN_MAX = 1 };
+
+// workspace (in u32 words) a scan of n elements needs
+u64 scan_workspace_words(u64 n);
+// out[i] = op over in[0..i) (exclusive) or in[0..i] (inclusive); in == out ok
+int scan_u32(int op, const u32 *in, u32 *out, u64 n, bool inclusive, u32 *ws,
+             hipStream_t st);
+
+// workspace (u32 words) for sorting n pairs
+u64 radix_workspace_words(u64 n);
+// Stable LSD radix sort of (key, value) pairs on the digits
+// (key >> shifts[p]) & ((1 << widths[p]) - 1), p = 0..npasses-1 (least
+// significant digit first, widths <= 8).  Ping-pongs between (a) and (b); the
+// result is in (a) if npasses is even, else in (b).  If ev_pairs != NULL, a
+// start/stop event pair is recorded around every scatter launch
+// (ev_pairs[2*i], ev_pairs[2*i+1]) and *n_ev is advanced.
+template <typename V>
+int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
+                     const int *shifts, const int *widths, int npasses,
+                     u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
+                     int *n_ev);

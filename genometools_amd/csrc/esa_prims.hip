@@ -1,0 +1,329 @@
+// esa_prims.hip -- device-wide primitives of the ESA engine, hand-written for
+// gfx950 (wave64): u32 scans (sum / max), and a stable LSD radix sort of
+// (u64 key, u32 value) pairs built from LDS-staged digit histograms and
+// wavefront ballot ranking.  No rocPRIM/hipCUB.
+#include "esa_prims.h"
+
+// ===========================================================================
+// scans
+// ===========================================================================
+namespace {
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_ITEMS = 16;
+constexpr int SC_TILE = SC_THREADS * SC_ITEMS;  // 4096
+
+template <int OP> __device__ __forceinline__ u32 sc_op(u32 a, u32 b) {
+  return OP == SCAN_SUM ? a + b : (a > b ? a : b);
+}
+
+// inclusive scan across the 64 lanes of a wave
+template <int OP> __device__ __forceinline__ u32 wave_scan_incl(u32 v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    u32 o = __shfl_up(v, d, 64);
+    if (lane >= d) v = sc_op<OP>(v, o);
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads);
+// returns the exclusive prefix, *total gets the block total
+template <int OP>
+__device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *total, u32 *lds4) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 inc = wave_scan_incl<OP>(v);
+  if (lane == 63) lds4[w] = inc;
+  __syncthreads();
+  u32 carry = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SC_THREADS / 64; i++) {
+    u32 s = lds4[i];
+    if (i < w) carry = sc_op<OP>(carry, s);
+    tot = sc_op<OP>(tot, s);
+  }
+  __syncthreads();
+  *total = tot;
+  u32 prev = __shfl_up(inc, 1, 64);
+  if (lane == 0) prev = 0;
+  return sc_op<OP>(carry, prev);
+}
+
+template <int OP>
+__global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(
+    const u32 *__restrict__ in, u64 n, u32 *__restrict__ blocksum) {
+  __shared__ u32 lds4[4];
+  const u64 base = (u64) blockIdx.x * SC_TILE + (u64) threadIdx.x * SC_ITEMS;
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; i++) {
+    u64 idx = base + i;
+    if (idx < n) acc = sc_op<OP>(acc, in[idx]);
+  }
+  u32 tot;
+  (void) block_scan_excl<OP>(acc, &tot, lds4);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+// scans one tile per block; carry-in from blockprefix (exclusive prefix of the
+// block sums) when not NULL
+template <int OP, bool INCLUSIVE>
+__global__ __launch_bounds__(SC_THREADS) void k_scan_tile(
+    const u32 *__restrict__ in, u32 *__restrict__ out, u64 n,
+    const u32 *__restrict__ blockprefix) {
+  __shared__ u32 lds4[4];
+  const u64 base = (u64) blockIdx.x * SC_TILE + (u64) threadIdx.x * SC_ITEMS;
+  u32 v[SC_ITEMS];
+  u32 acc = 0;
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; i++) {
+    u64 idx = base + i;
+    v[i] = idx < n ? in[idx] : 0;
+    acc = sc_op<OP>(acc, v[i]);
+  }
+  u32 tot;
+  u32 pre = block_scan_excl<OP>(acc, &tot, lds4);
+  if (blockprefix != nullptr) pre = sc_op<OP>(pre, blockprefix[blockIdx.x]);
+#pragma unroll
+  for (int i = 0; i < SC_ITEMS; i++) {
+    u64 idx = base + i;
+    u32 incl = sc_op<OP>(pre, v[i]);
+    if (idx < n) out[idx] = INCLUSIVE ? incl : pre;
+    pre = incl;
+  }
+}
+
+}  // namespace
+
+u64 scan_workspace_words(u64 n) {
+  u64 words = 0;
+  while (n > SC_TILE) {
+    n = div_up(n, SC_TILE);
+    words += n + 16;
+  }
+  return words + 16;
+}
+
+template <int OP>
+static int scan_rec(const u32 *in, u32 *out, u64 n, bool inclusive, u32 *ws,
+                    hipStream_t st) {
+  if (n == 0) return 0;
+  const u64 nblocks = div_up(n, SC_TILE);
+  if (nblocks == 1) {
+    if (inclusive)
+      k_scan_tile<OP, true><<<1, SC_THREADS, 0, st>>>(in, out, n, nullptr);
+    else
+      k_scan_tile<OP, false><<<1, SC_THREADS, 0, st>>>(in, out, n, nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  u32 *sums = ws;
+  k_scan_reduce<OP><<<(u32) nblocks, SC_THREADS, 0, st>>>(in, n, sums);
+  HIP_TRY(hipGetLastError());
+  TRY(scan_rec<OP>(sums, sums, nblocks, false, ws + nblocks + 16, st));
+  if (inclusive)
+    k_scan_tile<OP, true><<<(u32) nblocks, SC_THREADS, 0, st>>>(in, out, n, sums);
+  else
+    k_scan_tile<OP, false><<<(u32) nblocks, SC_THREADS, 0, st>>>(in, out, n, sums);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int scan_u32(int op, const u32 *in, u32 *out, u64 n, bool inclusive, u32 *ws,
+             hipStream_t st) {
+  return op == SCAN_SUM ? scan_rec<SCAN_SUM>(in, out, n, inclusive, ws, st)
+                        : scan_rec<SCAN_MAX>(in, out, n, inclusive, ws, st);
+}
+
+// ===========================================================================
+// radix sort
+// ===========================================================================
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ITEMS = 16;
+constexpr int RS_TILE = RS_THREADS * RS_ITEMS;       // 4096 pairs per block
+constexpr int RS_WAVE_CHUNK = RS_ITEMS * 64;         // 1024 consecutive pairs
+constexpr int RADIX = 256;
+
+// Per-tile digit histogram.  hist is digit-major: hist[d * ntiles + tile], so
+// that one exclusive scan over the whole array yields every tile's global
+// write base for every digit.
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
+    const u64 *__restrict__ keys, u64 n, int shift, u32 mask,
+    u32 *__restrict__ hist, u32 ntiles) {
+  __shared__ u32 h[RS_WAVES][RADIX];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 base = (u64) blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    u64 idx = base + (u64) j * RS_THREADS + tid;
+    if (idx < n) {
+      u32 d = (u32) (keys[idx] >> shift) & mask;
+      atomicAdd(&h[w][d], 1u);
+    }
+  }
+  __syncthreads();
+  u32 c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
+  hist[(u64) tid * ntiles + blockIdx.x] = c;
+}
+
+// lanes of this wave that hold the same 8-bit digit (all 64 lanes active)
+__device__ __forceinline__ u64 match_digit(u32 d) {
+  u64 m = ~0ull;
+#pragma unroll
+  for (int b = 0; b < 8; b++) {
+    const bool bit = (d >> b) & 1u;
+    const u64 bal = __ballot(bit);
+    m &= bit ? bal : ~bal;
+  }
+  return m;
+}
+
+// Stable scatter of one tile.  Wave w owns the 1024 consecutive pairs
+// [w*1024, w*1024+1024) of the tile; item j of lane l is pair w*1024+j*64+l,
+// so every load is a fully coalesced 512-byte (keys) / 256-byte (values)
+// wave access and the (wave, item, lane) order is the input order.  Ranking:
+// ballot match inside the wave + a per-wave running digit counter in LDS.
+// The tile is then staged in LDS in digit order and written out so that
+// neighbouring lanes write neighbouring addresses of the same digit run.
+template <typename V>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
+    const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
+    u64 *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
+    u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles) {
+  __shared__ u64 s_key[RS_TILE];
+  __shared__ V s_val[RS_TILE];
+  __shared__ u32 s_cnt[RS_WAVES][RADIX];   // running counters, then wave prefix
+  __shared__ u32 s_dbase[RADIX];           // tile-local start of each digit run
+  __shared__ u32 s_obase[RADIX];           // global base minus local start
+  __shared__ u32 s_scan[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u64 tile_base = (u64) blockIdx.x * RS_TILE;
+  const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
+                                                            : (u64) RS_TILE);
+  for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
+    (&s_cnt[0][0])[i] = 0;
+
+  u64 key[RS_ITEMS];
+  V val[RS_ITEMS];
+  u32 rk[RS_ITEMS];   // rank inside the wave's stream << 8 | digit
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    if (e < valid) {
+      key[j] = keys_in[tile_base + e];
+      val[j] = vals_in[tile_base + e];
+    } else {
+      key[j] = ~0ull;
+      val[j] = 0;
+    }
+  }
+  __syncthreads();
+  const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    // out-of-range pairs go to the last digit; being the last pairs of the
+    // tile they end up behind all valid ones and are never written
+    const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
+    const u64 m = match_digit(d);
+    const u32 intra = (u32) __popcll(m & lt);
+    const int leader = __ffsll((unsigned long long) m) - 1;
+    u32 old = 0;
+    if (lane == leader) {
+      old = s_cnt[w][d];
+      s_cnt[w][d] = old + (u32) __popcll(m);
+    }
+    old = __shfl(old, leader, 64);
+    rk[j] = ((old + intra) << 8) | d;
+  }
+  __syncthreads();
+  // digit totals over the 4 waves, wave-exclusive prefixes, tile-local bases
+  {
+    u32 c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid],
+        c3 = s_cnt[3][tid];
+    u32 tot = c0 + c1 + c2 + c3, blocktot;
+    s_cnt[0][tid] = 0;
+    s_cnt[1][tid] = c0;
+    s_cnt[2][tid] = c0 + c1;
+    s_cnt[3][tid] = c0 + c1 + c2;
+    u32 dbase = block_scan_excl<SCAN_SUM>(tot, &blocktot, s_scan);
+    s_dbase[tid] = dbase;
+    s_obase[tid] = hist_scanned[(u64) tid * ntiles + blockIdx.x] - dbase;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 d = rk[j] & 255u;
+    const u32 pos = s_dbase[d] + s_cnt[w][d] + (rk[j] >> 8);
+    s_key[pos] = key[j];
+    s_val[pos] = val[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) j * RS_THREADS + tid;
+    if (e < valid) {
+      const u64 k = s_key[e];
+      const u32 d = (u32) (k >> shift) & mask;
+      const u32 g = s_obase[d] + e;
+      keys_out[g] = k;
+      vals_out[g] = s_val[e];
+    }
+  }
+}
+
+}  // namespace
+
+u64 radix_workspace_words(u64 n) {
+  u64 ntiles = div_up(n, RS_TILE);
+  u64 hist = ntiles * RADIX;
+  return hist + scan_workspace_words(hist) + 64;
+}
+
+template <typename V>
+int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
+                     const int *shifts, const int *widths, int npasses,
+                     u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
+                     int *n_ev) {
+  if (n == 0) return 0;
+  if (n >= (1ull << 32)) {
+    gtamd_set_error("radix_sort_pairs: %llu pairs exceed the 32-bit index "
+                    "range of one sort", (unsigned long long) n);
+    return -1;
+  }
+  const u32 ntiles = (u32) div_up(n, RS_TILE);
+  u32 *hist = ws;
+  u32 *scanws = ws + (u64) ntiles * RADIX;
+  u64 *kin = keys_a, *kout = keys_b;
+  V *vin = vals_a, *vout = vals_b;
+  for (int p = 0; p < npasses; p++) {
+    const u32 mask = (1u << widths[p]) - 1u;
+    k_rs_hist<<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
+                                             ntiles);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
+    if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
+    k_rs_scatter<V><<<ntiles, RS_THREADS, 0, st>>>(kin, vin, kout, vout, n,
+                                                   shifts[p], mask, hist,
+                                                   ntiles);
+    HIP_TRY(hipGetLastError());
+    if (ev_pairs != nullptr) {
+      HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));
+      (*n_ev)++;
+    }
+    u64 *tk = kin; kin = kout; kout = tk;
+    V *tv = vin; vin = vout; vout = tv;
+  }
+  return 0;
+}
+
+template int radix_sort_pairs<u32>(u64 *, u32 *, u64 *, u32 *, u64, const int *,
+                                   const int *, int, u32 *, hipStream_t,
+                                   hipEvent_t *, int *);

@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's ESA construction interface over the C ABI.
+
+The reference's seam is the Sfxiterator (src/match/sfx-suffixer.h:32-72):
+``gt_Sfxiterator_new_withadditionalvalues`` / ``_next`` / ``_longest`` /
+``_delete`` plus the LCP and BWT sinks of src/match/sfx-run.c.  `EsaEngine`
+is the coarse-grained equivalent (one run, all tables resident on the device);
+`Sfxiterator` below keeps the reference's call shape on top of it.
+
+Everything here goes through genometools_amd/libgtamd_esa.so (HIP); there is
+no CPU implementation in this package.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import EsaError, EsaStats, EsaTiming, check  # noqa: F401
+
+WANT_SUF, WANT_LCP, WANT_BWT = 1, 2, 4
+TAB_SUF, TAB_LCP, TAB_BWT, TAB_LLV = 0, 1, 2, 3
+
+_TAB_DTYPE = {TAB_SUF: np.uint64, TAB_LCP: np.uint8, TAB_BWT: np.uint8,
+              TAB_LLV: np.uint64}
+
+
+@dataclass
+class EsaResult:
+    """the tables of one index, as the files .suf/.lcp/.llv/.bwt hold them"""
+    suf: np.ndarray = None
+    lcp: np.ndarray = None
+    llv: np.ndarray = None
+    bwt: np.ndarray = None
+    stats: dict = None
+    timing: dict = None
+
+
+def _struct_dict(s):
+    return {name: getattr(s, name) for name, _ in s._fields_}
+
+
+class EsaEngine:
+    """Device context: workspace for sequences of up to `max_n` symbols over
+    an alphabet of `numofchars` letters (4 = DNA, 20 = protein)."""
+
+    def __init__(self, max_n, numofchars=4, device=0):
+        self._lib = _lib.load()
+        self._ctx = self._lib.gtamd_esa_create(device, max_n, numofchars)
+        if not self._ctx:
+            raise EsaError(self._lib.gtamd_esa_last_error().decode())
+        self.max_n = max_n
+        self.numofchars = numofchars
+        self.device = device
+        self.n = None
+
+    def close(self):
+        if self._ctx:
+            self._lib.gtamd_esa_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- input ------------------------------------------------------------
+    def set_sequence(self, enc):
+        """encoded symbols (numpy uint8: 0..sigma-1, 254, 255) from the host"""
+        enc = np.ascontiguousarray(enc, dtype=np.uint8)
+        check(self._lib.gtamd_esa_set_sequence_bytes(
+            self._ctx, enc.ctypes.data_as(ctypes.c_void_p), enc.size, 0))
+        self.n = int(enc.size)
+
+    def set_sequence_device(self, ptr, n):
+        """encoded symbols already resident on the device (raw pointer)"""
+        check(self._lib.gtamd_esa_set_sequence_bytes(self._ctx, ptr, n, 1))
+        self.n = int(n)
+
+    # -- hot path ---------------------------------------------------------
+    def run(self, want=WANT_SUF | WANT_LCP | WANT_BWT):
+        check(self._lib.gtamd_esa_run(self._ctx, want))
+        self.want = want
+
+    # -- output -----------------------------------------------------------
+    def entries(self, which):
+        return int(self._lib.gtamd_esa_table_entries(self._ctx, which))
+
+    def device_pointer(self, which):
+        return self._lib.gtamd_esa_table_device(self._ctx, which)
+
+    def table(self, which, first=0, count=None):
+        total = self.entries(which)
+        count = total - first if count is None else count
+        width = 2 if which == TAB_LLV else 1
+        out = np.empty(count * width, dtype=_TAB_DTYPE[which])
+        if count:
+            check(self._lib.gtamd_esa_table_copy(
+                self._ctx, which, out.ctypes.data_as(ctypes.c_void_p), first,
+                count))
+        return out.reshape(-1, 2) if which == TAB_LLV else out
+
+    def stats(self):
+        s = EsaStats()
+        check(self._lib.gtamd_esa_get_stats(self._ctx, ctypes.byref(s)))
+        return _struct_dict(s)
+
+    def timing(self):
+        t = EsaTiming()
+        check(self._lib.gtamd_esa_get_timing(self._ctx, ctypes.byref(t)))
+        return _struct_dict(t)
+
+    def result(self):
+        r = EsaResult(stats=self.stats(), timing=self.timing())
+        if self.want & WANT_SUF:
+            r.suf = self.table(TAB_SUF)
+        if self.want & WANT_LCP:
+            r.lcp = self.table(TAB_LCP)
+            r.llv = self.table(TAB_LLV)
+        if self.want & WANT_BWT:
+            r.bwt = self.table(TAB_BWT)
+        return r
+
+
+def suffixerator_tables(enc, numofchars=4, want=WANT_SUF | WANT_LCP | WANT_BWT,
+                        device=0):
+    """one-shot: encoded symbols in, EsaResult out"""
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    with EsaEngine(max(int(enc.size), 1), numofchars, device) as eng:
+        eng.set_sequence(enc)
+        eng.run(want)
+        return eng.result()
+
+
+def prj_text(seqstats, esastats, with_lcp=True):
+    """the .prj file of src/match/sfx-outprj.c:38-83 as text; `seqstats` are
+    the encoded-sequence numbers (genometools_amd.encseq.sequence_stats),
+    `esastats` the engine's"""
+    n1 = esastats["numberofallsortedsuffixes"]
+    lines = ["totallength=%d" % seqstats["totallength"]]
+    for k in ("specialcharacters", "specialranges", "realspecialranges",
+              "lengthofspecialprefix", "lengthofspecialsuffix", "wildcards",
+              "wildcardranges", "realwildcardranges", "lengthofwildcardprefix",
+              "lengthofwildcardsuffix"):
+        lines.append("%s=%d" % (k, seqstats[k]))
+    lines += ["numofsequences=%d" % seqstats["numofsequences"],
+              "numofdbsequences=%d" % seqstats["numofsequences"],
+              "numofquerysequences=0",
+              "numberofallsortedsuffixes=%d" % n1,
+              "longest=%d" % esastats["longest"],
+              "prefixlength=%d" % esastats["prefixlength"],
+              "largelcpvalues=%d" % (esastats["largelcpvalues"] if with_lcp else 0),
+              "averagelcp=%.2f" % ((esastats["lcptabsum"] / n1) if with_lcp else 0.0),
+              "maxbranchdepth=%d" % (esastats["maxbranchdepth"] if with_lcp else 0),
+              "integersize=64", "littleendian=1", "readmode=0", "mirrored=0"]
+    return "\n".join(lines) + "\n"

@@ -1,0 +1,168 @@
+/*
+  gtamd_esa.h -- C ABI of the MI355X-native enhanced-suffix-array engine.
+
+  Drop-in boundary for ONE path of GenomeTools: what `gt suffixerator
+  -suf -lcp -bwt` computes between "encoded sequence in memory" and "tables
+  written".  The reference has no plugin ABI; the seam this library replaces is
+  the Sfxiterator library interface plus its two sinks:
+
+    gt_Sfxiterator_new_withadditionalvalues   src/match/sfx-suffixer.h:48-60
+    gt_Sfxiterator_next                       src/match/sfx-suffixer.h:62-64
+    gt_Sfxiterator_longest                    src/match/sfx-suffixer.h:72
+    gt_Sfxiterator_delete                     src/match/sfx-suffixer.h:35
+    GtOutlcpinfo (LCP sink, .lcp/.llv, stats) src/match/sfx-lcpvalues.h:102-137
+    bwttab2file (BWT sink)                    src/match/sfx-run.c:173-210
+    gt_recommendedprefixlength (for .prj)     src/match/sfx-apfxlen.h:24-27
+
+  The reference hands the suffix array out in memory-sized slices because it
+  sorts bucket by bucket on the CPU; on a 288 GB device the whole table is
+  resident, so the iterator collapses into one coarse call (gtamd_esa_run) on a
+  context that owns the device workspace.  Conventions follow GtError: every
+  function returns 0 on success and -1 on failure, with a message available
+  from gtamd_esa_last_error() (the text a GtToolfunc shim would pass to
+  gt_error_set).
+
+  Plain C: only pointers, sizes and PODs cross this boundary.  There is no CPU
+  fallback: without a HIP device every compute entry point fails with -1.
+*/
+#ifndef GTAMD_ESA_H
+#define GTAMD_ESA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GTAMD_WILDCARD   254u  /* src/core/chardef.h:33 */
+#define GTAMD_SEPARATOR  255u  /* src/core/chardef.h:34 */
+#define GTAMD_UNDEFBWT   254u  /* src/core/chardef.h:65 */
+#define GTAMD_LCPOVERFLOW 255u /* src/match/lcpoverflow.h:24 */
+
+/* which tables to produce: the -suf / -lcp / -bwt switches of
+   src/match/index_options.c:298-338 */
+#define GTAMD_WANT_SUF 1u
+#define GTAMD_WANT_LCP 2u
+#define GTAMD_WANT_BWT 4u
+
+/* table selectors for gtamd_esa_table_* */
+typedef enum {
+  GTAMD_TAB_SUF = 0,  /* (n+1) x uint64, native endian  (.suf) */
+  GTAMD_TAB_LCP = 1,  /* (n+1) x uint8                  (.lcp) */
+  GTAMD_TAB_BWT = 2,  /* (n+1) x uint8                  (.bwt) */
+  GTAMD_TAB_LLV = 3   /* numlargelcp x (uint64 index, uint64 value) (.llv) */
+} gtamd_table;
+
+/* numbers the reference prints into .prj (src/match/sfx-outprj.c:38-83) that
+   depend on the tables */
+typedef struct {
+  uint64_t totallength;                /* n */
+  uint64_t numberofallsortedsuffixes;  /* n + 1 */
+  uint64_t longest;                    /* index i with suf[i] == 0 */
+  uint64_t largelcpvalues;             /* entries of .llv */
+  uint64_t maxbranchdepth;             /* max lcp */
+  uint64_t lcptabsum;                  /* masked sum; averagelcp = sum/(n+1) */
+  uint32_t prefixlength;               /* gt_recommendedprefixlength(sigma,n) */
+  uint32_t refine_rounds;              /* engine statistic: doubling rounds */
+  uint64_t tied_suffixes;              /* engine statistic: suffixes that were
+                                          not separated by the first sort */
+} gtamd_esa_stats;
+
+/* per-stage device time of the last run, measured with HIP events on the
+   context's own stream (milliseconds) */
+typedef struct {
+  float total_ms;      /* text resident -> tables resident */
+  float keygen_ms;
+  float sort_ms;       /* all radix passes of the first sort */
+  float finalize_ms;   /* SA widening + LCP/BWT emission + tie detection */
+  float refine_ms;     /* prefix-doubling rounds incl. rank table build */
+  float tie_fix_ms;    /* LCP/BWT of tied suffixes + .llv */
+  float scatter_ms;    /* sum over the downsweep (scatter) kernel launches */
+  uint32_t scatter_launches;
+  uint64_t scatter_items;  /* elements moved per launch (first sort) */
+} gtamd_esa_timing;
+
+typedef struct gtamd_esa_ctx gtamd_esa_ctx;
+
+/* ---- library ---------------------------------------------------------- */
+/* number of HIP devices visible (0 if none / no driver); never fails */
+int gtamd_device_count(void);
+/* message of the last failure on the calling thread */
+const char *gtamd_esa_last_error(void);
+
+/* arithmetic of src/match/sfx-apfxlen.c:83-109 (host only, no device) */
+uint32_t gtamd_recommended_prefixlength(uint32_t numofchars, uint64_t n);
+
+/* ---- context ---------------------------------------------------------- */
+/* Create an engine on HIP device `device` for sequences of up to max_n
+   symbols over an alphabet of `numofchars` letters (4: 2-bit DNA path,
+   <= 31: 5-bit path).  Allocates the whole workspace once; NULL on failure. */
+gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
+                                uint32_t numofchars);
+void gtamd_esa_destroy(gtamd_esa_ctx *ctx);
+
+/* Restrict the build to the part `part` of `numparts` equal-width (by suffix
+   count) lexicographic ranges, the reference's -parts mechanism
+   (src/match/sfx-partssuf.c:172-347) used here to shard over GPUs.
+   Default 0 of 1. */
+int gtamd_esa_set_part(gtamd_esa_ctx *ctx, uint32_t part, uint32_t numparts);
+
+/* ---- input: the encoded sequence (GtEncseq read side) ------------------ */
+/* One byte per symbol as the reference's encoder delivers them
+   (src/core/encseq.c:249 gt_encseq_get_encoded_char): 0..sigma-1 letters,
+   254 wildcard, 255 separator.  `enc` may be a host or a device pointer
+   (is_device != 0).  The engine packs it on the device into its resident
+   form: 2-bit words, 32 symbols per uint64, first symbol in the two most
+   significant bits as in GtTwobitencoding (src/core/intbits.h:78-83), plus a
+   bitmap of special positions (the reference's GT_ACCESS_TYPE_BITACCESS
+   layout, src/core/encseq.c:2822-2835); 5-bit symbols for larger alphabets. */
+int gtamd_esa_set_sequence_bytes(gtamd_esa_ctx *ctx, const uint8_t *enc,
+                                 uint64_t n, int is_device);
+
+/* Already packed input, device resident: `twobit` = ceil(n/32) words in the
+   GtTwobitencoding layout where a special position holds 0 (wildcard) or 1
+   (separator), `specialbits` = ceil((n+1)/64) words, bit (p & 63) of word
+   p >> 6 set iff position p is special; bit n (the virtual end) must be set.
+   The engine reads the buffers in place; they must outlive the run. */
+int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *ctx, const uint64_t *twobit,
+                                  const uint64_t *specialbits, uint64_t n);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* Build the requested tables (GTAMD_WANT_* mask) from the resident sequence;
+   synchronous: returns when the tables are resident in device memory. */
+int gtamd_esa_run(gtamd_esa_ctx *ctx, uint32_t want);
+
+/* ---- output ------------------------------------------------------------ */
+/* number of entries of a table after a run (n+1, or the .llv pair count; for
+   a part build: the entries of this part's slice) and the slice's offset in
+   the whole table */
+uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *ctx, gtamd_table which);
+uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *ctx);
+/* device pointer of a table (valid until the next run / destroy) */
+const void *gtamd_esa_table_device(const gtamd_esa_ctx *ctx, gtamd_table which);
+/* copy entries [first, first+count) of a table to host memory */
+int gtamd_esa_table_copy(gtamd_esa_ctx *ctx, gtamd_table which, void *dst,
+                         uint64_t first, uint64_t count);
+int gtamd_esa_get_stats(const gtamd_esa_ctx *ctx, gtamd_esa_stats *st);
+int gtamd_esa_get_timing(const gtamd_esa_ctx *ctx, gtamd_esa_timing *tm);
+
+/* ---- one-shot convenience (host buffers in, host buffers out) ---------- */
+/* suf/lcp/bwt may be NULL when not wanted; llv receives up to llv_capacity
+   pairs (2 x uint64 each); *llv_pairs gets the real count. */
+int gtamd_esa_build(const uint8_t *enc, uint64_t n, uint32_t numofchars,
+                    uint32_t want, uint64_t *suf, uint8_t *lcp, uint8_t *bwt,
+                    uint64_t *llv, uint64_t llv_capacity, uint64_t *llv_pairs,
+                    gtamd_esa_stats *st);
+
+/* ---- synthetic sequences for benchmarks and parity tests --------------- */
+/* Fill a device byte buffer with the synthetic sequence `model` of length n
+   (see genometools_amd/synth.py for the definitions, which are pure functions
+   of (model, seed, n, position)).  Returns -1 for an unknown model. */
+int gtamd_synth_bytes(int device, int model, uint64_t seed, uint64_t n,
+                      uint8_t *dst_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

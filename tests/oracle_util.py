@@ -1,0 +1,167 @@
+"""ctypes access to the CPU oracle (oracle/_build/libesa_oracle.so) and to the
+golden vectors.  Test infrastructure only."""
+import ctypes
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libesa_oracle.so")
+ORACLE_CLI = os.path.join(ORACLE_DIR, "_build", "esa_oracle")
+REF_BIN = os.path.join(ORACLE_DIR, "_ref", "gt_ref_sfx")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+class SeqStats(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_uint64) for k in (
+        "totallength", "specialcharacters", "specialranges",
+        "realspecialranges", "lengthofspecialprefix", "lengthofspecialsuffix",
+        "wildcards", "wildcardranges", "realwildcardranges",
+        "lengthofwildcardprefix", "lengthofwildcardsuffix",
+        "numofsequences")] + [("numofchars", ctypes.c_uint32)]
+
+
+class EsaStats(ctypes.Structure):
+    _fields_ = [("numberofallsortedsuffixes", ctypes.c_uint64),
+                ("longest", ctypes.c_uint64),
+                ("largelcpvalues", ctypes.c_uint64),
+                ("maxbranchdepth", ctypes.c_uint64),
+                ("lcptabsum", ctypes.c_double),
+                ("prefixlength", ctypes.c_uint32)]
+
+
+_lib = None
+
+
+def build():
+    src = [os.path.join(ORACLE_DIR, f) for f in
+           ("esa_oracle.c", "esa_oracle.h", "esa_oracle_main.c")]
+    if (not os.path.exists(ORACLE_LIB) or not os.path.exists(ORACLE_CLI) or
+            any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in src)):
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True,
+                       stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(ORACLE_LIB)
+        P, U64, U32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32
+        L.ora_encode_fasta.argtypes = [ctypes.c_char_p, ctypes.c_int,
+                                       ctypes.POINTER(P), ctypes.POINTER(U64),
+                                       ctypes.c_char_p, ctypes.c_size_t]
+        L.ora_seqstats_compute.argtypes = [P, U64, U32, U64, U64,
+                                           ctypes.POINTER(SeqStats)]
+        L.ora_recommended_prefixlength.restype = U32
+        L.ora_recommended_prefixlength.argtypes = [U32, U64]
+        L.ora_suffix_array.argtypes = [P, U64, P]
+        L.ora_lcp_direct.argtypes = [P, U64, P, P]
+        L.ora_lcp_kasai.argtypes = [P, U64, P, P]
+        L.ora_bwt.argtypes = [P, U64, P, P]
+        L.ora_lcp_to_bytes.restype = U64
+        L.ora_lcp_to_bytes.argtypes = [P, U64, P, P]
+        L.ora_esastats_compute.argtypes = [P, U64, P, P, U32,
+                                           ctypes.POINTER(EsaStats)]
+        L.ora_check_suffix_array.argtypes = [P, U64, P, ctypes.POINTER(U64)]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def encode_fasta(path, protein=False):
+    L = lib()
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    err = ctypes.create_string_buffer(1024)
+    rc = L.ora_encode_fasta(path.encode(), int(protein), ctypes.byref(ptr),
+                            ctypes.byref(n), err, 1024)
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    enc = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                shape=(n.value,)).copy()
+    ctypes.CDLL(None).free(ptr)
+    return enc
+
+
+def esa(enc, numofchars=4, kasai=True):
+    """all tables + statistics of the oracle for encoded symbols `enc`"""
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    n = enc.size
+    sa = np.empty(n + 1, dtype=np.uint64)
+    L.ora_suffix_array(_p(enc), n, _p(sa))
+    lcpw = np.empty(n + 1, dtype=np.uint64)
+    (L.ora_lcp_kasai if kasai else L.ora_lcp_direct)(_p(enc), n, _p(sa), _p(lcpw))
+    lcpb = np.empty(n + 1, dtype=np.uint8)
+    pairs = L.ora_lcp_to_bytes(_p(lcpw), n + 1, _p(lcpb), None)
+    llv = np.empty(2 * pairs, dtype=np.uint64)
+    L.ora_lcp_to_bytes(_p(lcpw), n + 1, _p(lcpb), _p(llv))
+    bwt = np.empty(n + 1, dtype=np.uint8)
+    L.ora_bwt(_p(enc), n, _p(sa), _p(bwt))
+    st = EsaStats()
+    k = L.ora_recommended_prefixlength(numofchars, n)
+    L.ora_esastats_compute(_p(enc), n, _p(sa), _p(lcpw), k, ctypes.byref(st))
+    stats = {name: getattr(st, name) for name, _ in st._fields_}
+    return {"suf": sa, "lcp": lcpb, "llv": llv.reshape(-1, 2), "bwt": bwt,
+            "lcpfull": lcpw, "stats": stats}
+
+
+def tables_given_sa(enc, sa):
+    """LCP (Kasai) and BWT of the oracle for an externally supplied suffix
+    array -- used at sizes where the oracle's comparison sort is too slow"""
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    n = enc.size
+    lcpw = np.empty(n + 1, dtype=np.uint64)
+    L.ora_lcp_kasai(_p(enc), n, _p(sa), _p(lcpw))
+    lcpb = np.empty(n + 1, dtype=np.uint8)
+    pairs = L.ora_lcp_to_bytes(_p(lcpw), n + 1, _p(lcpb), None)
+    llv = np.empty(2 * pairs, dtype=np.uint64)
+    L.ora_lcp_to_bytes(_p(lcpw), n + 1, _p(lcpb), _p(llv))
+    bwt = np.empty(n + 1, dtype=np.uint8)
+    L.ora_bwt(_p(enc), n, _p(sa), _p(bwt))
+    return {"lcp": lcpb, "llv": llv.reshape(-1, 2), "bwt": bwt, "lcpfull": lcpw}
+
+
+def check_suffix_array(enc, sa):
+    """0 if `sa` is the suffix array of `enc` under the reference's ordering"""
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    where = ctypes.c_uint64()
+    rc = L.ora_check_suffix_array(_p(enc), enc.size, _p(sa), ctypes.byref(where))
+    return rc, where.value
+
+
+def seqstats(enc, numofchars=4):
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    st = SeqStats()
+    L.ora_seqstats_compute(_p(enc), enc.size, numofchars, 0, 1, ctypes.byref(st))
+    return {name: getattr(st, name) for name, _ in st._fields_}
+
+
+def golden():
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        return json.load(f)
+
+
+def golden_table(name, ext):
+    path = os.path.join(GOLDEN_DIR, "tables", "%s.%s.gz" % (name, ext))
+    if not os.path.exists(path):
+        return None
+    with gzip.open(path, "rb") as f:
+        raw = f.read()
+    return np.frombuffer(raw, dtype=np.uint64 if ext in ("suf", "llv") else np.uint8)
+
+
+def fixture_path(name):
+    return os.path.join(GOLDEN_DIR, "fixtures", name)

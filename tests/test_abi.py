@@ -1,0 +1,77 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/gtamd_esa.h declares; host-only entry points work; compute
+entry points fail loudly without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from genometools_amd import _lib
+
+HEADER = os.path.join(_lib.ROOT, "include", "gtamd_esa.h")
+
+
+def _declared_symbols():
+    with open(HEADER) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gtamd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    _lib.build_library()
+    assert os.path.exists(_lib.LIB_PATH)
+    _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _lib.ABI, "ctypes binding missing for " + name
+    assert sorted(_lib.ABI) == declared
+
+
+def test_prefixlength_matches_reference_values():
+    lib = _lib.load()
+    # values of the reference, SURVEY.md 8a row a5 / BASELINE.md
+    for sigma, n, k in [(4, 11817, 4), (4, 16000000, 9), (4, 256000000, 11),
+                        (4, 3000000000, 13), (4, 24000000000, 14),
+                        (20, 1000000000, 5)]:
+        assert lib.gtamd_recommended_prefixlength(sigma, n) == k, (sigma, n)
+    # and the prefixlength the reference wrote into .prj for each fixture
+    import oracle_util as ou
+    for name, e in ou.golden().items():
+        prj = dict(l.split("=") for l in e["prj"].splitlines())
+        sigma = 20 if e["alphabet"] == "protein" else 4
+        assert lib.gtamd_recommended_prefixlength(sigma, int(prj["totallength"])) \
+            == int(prj["prefixlength"]), name
+
+
+def test_prefixlength_matches_oracle_on_a_sweep():
+    import oracle_util as ou
+    lib, ora = _lib.load(), ou.lib()
+    for sigma in (4, 20):
+        for e in range(0, 36):
+            for n in (1 << e, (1 << e) + 1, 3 * (1 << e) - 1):
+                assert lib.gtamd_recommended_prefixlength(sigma, n) == \
+                    ora.ora_recommended_prefixlength(sigma, n), (sigma, n)
+
+
+def test_no_cpu_fallback():
+    lib = _lib.load()
+    if lib.gtamd_device_count() > 0:
+        pytest.skip("a device is present")
+    assert not lib.gtamd_esa_create(0, 1000, 4)
+    assert b"no HIP device" in lib.gtamd_esa_last_error()
+    enc = np.zeros(10, dtype=np.uint8)
+    suf = np.zeros(11, dtype=np.uint64)
+    rc = lib.gtamd_esa_build(enc.ctypes.data, 10, 4, 1, suf.ctypes.data, None,
+                             None, None, 0, None, None)
+    assert rc == -1
+    from genometools_amd import esa
+    with pytest.raises(esa.EsaError):
+        esa.suffixerator_tables(enc)

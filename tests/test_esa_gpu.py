@@ -1,0 +1,171 @@
+"""Parity of the HIP path (through the C ABI) with the reference's golden
+tables and with the CPU oracle on the same inputs.  Bit-exact: all tables are
+integer/byte/index data."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from genometools_amd import esa, synth
+
+pytestmark = pytest.mark.gpu
+GOLDEN = ou.golden()
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _prj_value(prj, key):
+    for line in prj.splitlines():
+        if line.startswith(key + "="):
+            return line.split("=", 1)[1]
+    raise KeyError(key)
+
+
+def _assert_same_as_oracle(enc, sigma, res, ora=None):
+    ora = ou.esa(enc, sigma) if ora is None else ora
+    assert np.array_equal(res.suf, ora["suf"]), "suf"
+    assert np.array_equal(res.bwt, ora["bwt"]), "bwt"
+    assert np.array_equal(res.lcp, ora["lcp"]), "lcp"
+    assert np.array_equal(res.llv, ora["llv"]), "llv"
+    st = ora["stats"]
+    assert res.stats["longest"] == st["longest"]
+    assert res.stats["largelcpvalues"] == st["largelcpvalues"]
+    assert res.stats["maxbranchdepth"] == st["maxbranchdepth"]
+    assert res.stats["lcptabsum"] == int(st["lcptabsum"])
+    assert res.stats["prefixlength"] == st["prefixlength"]
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_reference_fixtures(gpu, name):
+    """every suffixerator fixture of the reference's test suite
+    (testsuite/gt_suffixerator_include.rb:119-143,290-308)"""
+    e = GOLDEN[name]
+    protein = e["alphabet"] == "protein"
+    enc = ou.encode_fasta(ou.fixture_path(name), protein)
+    res = esa.suffixerator_tables(enc, 20 if protein else 4)
+    assert _md5(res.suf) == e["tables"]["suf"]["md5"]
+    assert _md5(res.lcp) == e["tables"]["lcp"]["md5"]
+    assert _md5(res.llv) == e["tables"]["llv"]["md5"]
+    assert _md5(res.bwt) == e["tables"]["bwt"]["md5"]
+    prj = e["prj"]
+    n1 = res.stats["numberofallsortedsuffixes"]
+    assert str(n1) == _prj_value(prj, "numberofallsortedsuffixes")
+    assert str(res.stats["longest"]) == _prj_value(prj, "longest")
+    assert str(res.stats["prefixlength"]) == _prj_value(prj, "prefixlength")
+    assert str(res.stats["largelcpvalues"]) == _prj_value(prj, "largelcpvalues")
+    assert str(res.stats["maxbranchdepth"]) == _prj_value(prj, "maxbranchdepth")
+    assert "%.2f" % (res.stats["lcptabsum"] / n1) == _prj_value(prj, "averagelcp")
+    ss = ou.seqstats(enc, 20 if protein else 4)
+    assert esa.prj_text(ss, res.stats) == prj
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 27, 28, 29, 31, 32, 33, 63, 64, 65,
+                               255, 256, 1000, 4095, 4096, 4097, 20000])
+def test_uniform_dna_small(gpu, n):
+    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 42, n)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("model,sigma,n,seed", [
+    (synth.MODEL_UNIFORM_DNA, 4, 1 << 20, 1),
+    (synth.MODEL_HUMANLIKE_DNA, 4, 70000, 2),
+    (synth.MODEL_HUMANLIKE_DNA, 4, 600000, 3),
+    (synth.MODEL_PROTEIN, 20, 50000, 4),
+    (synth.MODEL_PROTEIN, 20, 400000, 5),
+])
+def test_synthetic_models(gpu, model, sigma, n, seed):
+    enc = synth.generate(model, seed, n)
+    res = esa.suffixerator_tables(enc, sigma)
+    _assert_same_as_oracle(enc, sigma, res)
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 4, 3000, dtype=np.uint8)
+    yield "all_same_letter", np.zeros(5000, dtype=np.uint8)
+    yield "all_T", np.full(3000, 3, dtype=np.uint8)
+    yield "all_wildcards", np.full(777, 254, dtype=np.uint8)
+    yield "all_separators", np.full(130, 255, dtype=np.uint8)
+    yield "period_2", np.tile(np.array([0, 1], dtype=np.uint8), 4000)
+    yield "period_7", np.tile(np.array([0, 1, 1, 2, 3, 0, 2], dtype=np.uint8), 1500)
+    yield "two_identical_sequences", np.concatenate([a, [255], a]).astype(np.uint8)
+    yield "identical_then_wildcard", np.concatenate([a, [254], a, [254]]).astype(np.uint8)
+    yield "special_prefix_and_suffix", np.concatenate(
+        [[254] * 40, a[:500], [255], [254] * 3, a[:500], [254] * 70]).astype(np.uint8)
+    yield "T_runs_before_specials", np.concatenate(
+        [[3] * 40, [254], [3] * 30, [255], [3] * 28, [254], [3] * 27, [254],
+         [3] * 29]).astype(np.uint8)
+    yield "specials_every_other", np.tile(np.array([2, 254], dtype=np.uint8), 500)
+    # long exact repeat far beyond 255: .llv must carry it
+    b = rng.integers(0, 4, 20000, dtype=np.uint8)
+    yield "long_repeat", np.concatenate([b, a[:10], b, a[:7], b[:5000]]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name,enc", list(_cases()), ids=[c[0] for c in _cases()])
+def test_edge_cases(gpu, name, enc):
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+def test_protein_edge_cases(gpu):
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 20, 2000, dtype=np.uint8)
+    for enc in (np.full(300, 19, dtype=np.uint8),
+                np.concatenate([a, [255], a, [254], a[:100]]).astype(np.uint8),
+                np.tile(np.arange(13, dtype=np.uint8), 200)):
+        res = esa.suffixerator_tables(enc, 20)
+        _assert_same_as_oracle(enc, 20, res)
+
+
+def test_want_subsets_and_reuse(gpu):
+    """-suf only, -lcp only, -bwt only give the same tables; a context can be
+    reused for several sequences"""
+    enc1 = synth.generate(synth.MODEL_HUMANLIKE_DNA, 9, 200000)
+    enc2 = synth.generate(synth.MODEL_UNIFORM_DNA, 10, 50000)
+    with esa.EsaEngine(200000, 4) as eng:
+        for enc in (enc1, enc2, enc1):
+            ora = ou.esa(enc, 4)
+            eng.set_sequence(enc)
+            for want in (esa.WANT_SUF, esa.WANT_LCP, esa.WANT_BWT,
+                         esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT):
+                eng.run(want)
+                r = eng.result()
+                if want & esa.WANT_SUF:
+                    assert np.array_equal(r.suf, ora["suf"])
+                if want & esa.WANT_LCP:
+                    assert np.array_equal(r.lcp, ora["lcp"])
+                    assert np.array_equal(r.llv, ora["llv"])
+                if want & esa.WANT_BWT:
+                    assert np.array_equal(r.bwt, ora["bwt"])
+
+
+def test_large_uniform_properties(gpu):
+    """16 Mbp: the oracle's comparison sort is too slow here, so check the
+    size-independent properties: the linear-time suffix-array checker
+    (sortedness + permutation) and LCP/BWT recomputed by Kasai from the
+    engine's own suffix array"""
+    n = 16 * 1000 * 1000
+    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 42, n)
+    res = esa.suffixerator_tables(enc, 4)
+    rc, where = ou.check_suffix_array(enc, res.suf)
+    assert rc == 0, (rc, where)
+    t = ou.tables_given_sa(enc, res.suf)
+    assert np.array_equal(res.lcp, t["lcp"])
+    assert np.array_equal(res.llv, t["llv"])
+    assert np.array_equal(res.bwt, t["bwt"])
+    assert res.stats["maxbranchdepth"] == int(t["lcpfull"].max())
+
+
+def test_errors(gpu):
+    with pytest.raises(esa.EsaError, match="exceeds the context capacity"):
+        with esa.EsaEngine(100, 4) as eng:
+            eng.set_sequence(np.zeros(101, dtype=np.uint8))
+    with pytest.raises(esa.EsaError, match="no sequence set"):
+        with esa.EsaEngine(100, 4) as eng:
+            eng.run()
+    with pytest.raises(esa.EsaError, match="32-bit position"):
+        esa.EsaEngine(1 << 32, 4)

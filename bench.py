@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Gbp/s of ESA construction (suf+lcp+bwt).
+
+  python bench.py [--gpus N --steps K --warmup W]
+
+A "step" is one complete build of the enhanced suffix array (.suf + .lcp/.llv +
+.bwt, resident in HBM) from the encoded sequence already resident in HBM in
+its packed form.  N=1 workload: BASELINE.json configs[2], 3 Gbp human-like DNA
+(genometools_amd.synth MODEL_HUMANLIKE_DNA, seed 43), -suf -lcp -bwt.
+
+N>1 (one process per GPU, torch.distributed / RCCL): the sequence is replicated
+and the suffix array is sharded by lexicographic range where the engine
+supports it; until then every rank builds the ESA of its own sequence (seed
+43+rank) with no data-path collective and the line says "scaling": "weak".
+
+The JSON line carries, besides the contract fields:
+  roofline      the dominant kernel (radix scatter pass): algorithmic bytes per
+                launch (24 B per (key,position) pair moved: 12 in + 12 out)
+                / average launch duration measured with HIP events on the
+                engine's stream; `job` = whole-build bytes (10.25 B/bp,
+                SURVEY.md 8d) / step time.
+  cpu_baseline  the reference's own engine (oracle/_ref/gt_ref_sfx, kind
+                "reference") or the CPU restatement (kind "port") timed on
+                this host's cores on a bounded sample of the same model.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from genometools_amd import _lib, esa, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+JOB_BYTES_PER_BP = 10.25       # 0.25 text + 8 suf + 1 lcp + 1 bwt
+SCATTER_BYTES_PER_PAIR = 24.0  # 8+4 read, 8+4 written per radix pass
+
+
+def cpu_baseline(model, seed, sample_n):
+    """time the reference engine (or the oracle port) on `sample_n` symbols"""
+    enc = synth.generate(model, seed, sample_n)
+    ref = os.path.join(ROOT, "oracle", "_ref", "gt_ref_sfx")
+    cores = 1
+    if os.path.exists(ref):
+        with tempfile.TemporaryDirectory() as tmp:
+            fa = os.path.join(tmp, "sample.fna")
+            synth.write_fasta(fa, enc, protein=(model == synth.MODEL_PROTEIN))
+            out = subprocess.run(
+                [ref, "-protein" if model == synth.MODEL_PROTEIN else "-dna",
+                 "-suf", "-lcp", "-bwt", "-time", "-db", fa, "-indexname",
+                 os.path.join(tmp, "idx")], check=True, capture_output=True,
+                text=True).stdout
+        esa_s = float(out.split("esa=")[1].split()[0])
+        return {"value": sample_n / esa_s / 1e9, "unit": "Gbp/s", "cores": cores,
+                "kind": "reference",
+                "sample": "%d bp of the same model/seed, reference Sfxiterator "
+                          "-suf -lcp -bwt incl. table writes to tmpfs, %.1f s"
+                          % (sample_n, esa_s)}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as ou
+    t0 = time.time()
+    ou.esa(enc, synth.numofchars(model))
+    dt = time.time() - t0
+    return {"value": sample_n / dt / 1e9, "unit": "Gbp/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d bp of the same model/seed, oracle/ restatement "
+                      "(comparison sort + Kasai), %.1f s" % (sample_n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=float, default=3e9, help="symbols per sequence")
+    ap.add_argument("--model", type=int, default=synth.MODEL_HUMANLIKE_DNA)
+    ap.add_argument("--seed", type=int, default=43)
+    ap.add_argument("--cpu-sample", type=float, default=16e6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank
+    n = int(a.n)
+    sigma = synth.numofchars(a.model)
+    want = esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT
+    lib = _lib.load()
+
+    # synthetic input, generated on the device, packed into its resident form
+    seed = a.seed + rank
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:%d" % dev)
+    _lib.check(lib.gtamd_synth_bytes(dev, a.model, seed, n, buf.data_ptr()))
+    eng = esa.EsaEngine(n, sigma, device=dev)
+    eng.set_sequence_device(buf.data_ptr(), n)
+    del buf
+    torch.cuda.empty_cache()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        eng.run(want)
+    barrier()
+    t0 = time.perf_counter()
+    sc_ms, sc_launches, total_dev_ms = 0.0, 0, 0.0
+    for _ in range(a.steps):
+        eng.run(want)   # synchronous: returns when the tables are resident
+        tm = eng.timing()
+        sc_ms += tm["scatter_ms"]
+        sc_launches += tm["scatter_launches"]
+        total_dev_ms += tm["total_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * n / (dt / a.steps) / 1e9
+        sc_avg_s = sc_ms / max(sc_launches, 1) / 1e3
+        achieved = SCATTER_BYTES_PER_PAIR * (n + 1) / sc_avg_s / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                tj = json.load(f)
+            if tj.get("n") == n and tj.get("model") == a.model:
+                traffic = tj.get("scatter_hbm_bytes_per_launch")
+        line = {
+            "metric": "Gbp/s ESA build (suf+lcp+bwt), 3 Gbp DNA, 1/2/4/8 MI355X; bit-exact vs CPU",
+            "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%s n=%d seed=%d -suf -lcp -bwt (BASELINE.json configs[2])"
+                                   % ({0: "uniform DNA", 1: "human-like DNA (2% N, 24 seqs, repeats)",
+                                       2: "protein"}[a.model], n, a.seed),
+                       "sequences_per_gpu": 1,
+                       "tied_suffixes": st["tied_suffixes"],
+                       "refine_rounds": st["refine_rounds"],
+                       "largelcpvalues": st["largelcpvalues"],
+                       "maxbranchdepth": st["maxbranchdepth"]},
+            "roofline": {"bound": "hbm", "kernel": "k_rs_scatter (radix scatter pass)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launch_ms": sc_avg_s * 1e3,
+                         "launches_per_step": sc_launches // max(a.steps, 1),
+                         "job": {"achieved": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9,
+                                 "frac": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                                 "bytes_per_bp": JOB_BYTES_PER_BP,
+                                 "device_ms_per_step": total_dev_ms / a.steps}},
+        }
+        if not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.model, a.seed, int(a.cpu_sample))
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -506,39 +506,73 @@ __global__ void k_total(const u32 *__restrict__ off, const u32 *__restrict__ cnt
 // ---------------------------------------------------------------------------
 // tied suffixes: final LCP / BWT / .suf entries and .llv
 // ---------------------------------------------------------------------------
+// .suf and .bwt entries of every suffix that took part in the refinement, and
+// the flag "this entry is tied with its predecessor" (needs a real LCP)
 template <int BITS>
-__global__ __launch_bounds__(256) void k_fix_tied(
+__global__ __launch_bounds__(256) void k_fix_basic(
     Text t, const u32 *__restrict__ uidx0, u64 m0,
     const u64 *__restrict__ tiebits, const u32 *__restrict__ sa32,
-    u32 prefixlength, u64 *__restrict__ suf, u8 *__restrict__ lcp,
-    u8 *__restrict__ bwt, u32 *__restrict__ lcpu, u32 *__restrict__ large,
-    bool want_lcp, Stats *stats) {
+    u64 *__restrict__ suf, u8 *__restrict__ bwt, u32 *__restrict__ tied,
+    u32 *__restrict__ lcpu, Stats *stats) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m0) return;
+  const u64 i = uidx0[j];
+  const u64 p = sa32[i];
+  if (suf != nullptr) suf[i] = p;
+  if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
+  if (p == 0) stats->longest = i;
+  tied[j] = (u32) ((tiebits[i >> 6] >> (i & 63)) & 1ull);
+  lcpu[j] = 0;
+}
+
+// (text position, slot in the unresolved list) of the entries that need an LCP
+__global__ __launch_bounds__(256) void k_lcp_pairs(
+    const u32 *__restrict__ tied, const u32 *__restrict__ off,
+    const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32, u64 m0,
+    u64 *__restrict__ pkey, u32 *__restrict__ pval) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m0 || !tied[j]) return;
+  const u32 o = off[j];
+  pkey[o] = sa32[uidx0[j]];
+  pval[o] = (u32) j;
+}
+
+// LCP of the tied entries in TEXT order (the pairs are sorted by position):
+// for consecutive text positions lcp(p+1, pred(p+1)) >= lcp(p, pred(p)) - 1
+// (Kasai et al.; the reference's src/match/sfx-linlcp.c:74-129 walks the whole
+// text this way), so inside a repeat only the first position of a chunk pays
+// for the full extension.  One thread walks LCP_CHUNK consecutive pairs.
+constexpr int LCP_CHUNK = 32;
+template <int BITS>
+__global__ __launch_bounds__(256) void k_lcp_chunks(
+    Text t, const u64 *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
+    const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32,
+    u8 *__restrict__ lcp, u32 *__restrict__ lcpu, Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  const u64 c = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, nlarge = 0;
   u32 mx = 0;
-  if (j < m0) {
+  u64 prevp = ~0ull - 1, l = 0;
+  for (int e = 0; e < LCP_CHUNK; e++) {
+    const u64 s = c * LCP_CHUNK + e;
+    if (s >= m1) break;
+    const u64 p = pkey[s];
+    const u32 j = pval[s];
     const u64 i = uidx0[j];
-    const u64 p = sa32[i];
-    if (suf != nullptr) suf[i] = p;
-    if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
-    if (p == 0) stats->longest = i;
-    u32 l = 0, isl = 0;
-    if (want_lcp && ((tiebits[i >> 6] >> (i & 63)) & 1ull)) {
-      const u64 q = sa32[i - 1];
-      u64 lv = lcp_extend<BITS>(t, q, p, (u64) Key<BITS>::SYMS);
-      l = (u32) lv;
-      if (lcp != nullptr)
-        lcp[i] = (u8) (l < GTAMD_LCPOVERFLOW ? l : GTAMD_LCPOVERFLOW);
-      isl = l >= GTAMD_LCPOVERFLOW;
-      mx = l;
-      sum = l;   // tied suffixes have >= KEY_SYMS >= prefixlength letters
-      nlarge = isl;
-    }
-    lcpu[j] = l;
-    large[j] = isl;
+    const u64 q = sa32[i - 1];
+    u64 from = (u64) Key<BITS>::SYMS;
+    if (p == prevp + 1 && l > from + 1) from = l - 1;
+    l = lcp_extend<BITS>(t, q, p, from);
+    prevp = p;
+    const u32 lv = (u32) l;
+    if (lcp != nullptr)
+      lcp[i] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+    lcpu[j] = lv;
+    sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
+    nlarge += lv >= GTAMD_LCPOVERFLOW;
+    mx = lv > mx ? lv : mx;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -559,7 +593,12 @@ __global__ __launch_bounds__(256) void k_fix_tied(
     if (Lg) atomicAdd(&stats->numlarge, Lg);
     if (M) atomicMax(&stats->maxlcp, M);
   }
-  (void) prefixlength;
+}
+
+__global__ __launch_bounds__(256) void k_large_flags(
+    const u32 *__restrict__ lcpu, u64 m0, u32 *__restrict__ large) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j < m0) large[j] = lcpu[j] >= GTAMD_LCPOVERFLOW;
 }
 
 // .llv pairs in index order: (index into the lcp table, value),
@@ -934,13 +973,37 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     }
     HIP_TRY(hipEventRecord(c->ev[5], st));
     // ---- final entries of the tied suffixes
-    u32 *lcpu = cval_a, *large = cval_b, *loff = keep;
-    k_fix_tied<BITS><<<(u32) div_up(m0, 256), 256, 0, st>>>(
-        c->text, uidx0, m0, c->tiebits, sa32, prefixlength,
-        want_suf ? c->suf : nullptr, want_lcp ? c->lcp : nullptr,
-        want_bwt ? c->bwt : nullptr, lcpu, large, want_lcp, c->d_stats);
+    u32 *lcpu = hv, *large = keep, *loff = koff, *tied = cval_b;
+    const u32 g0 = (u32) div_up(m0, 256);
+    k_fix_basic<BITS><<<g0, 256, 0, st>>>(
+        c->text, uidx0, m0, c->tiebits, sa32, want_suf ? c->suf : nullptr,
+        want_bwt ? c->bwt : nullptr, tied, lcpu, c->d_stats);
     HIP_TRY(hipGetLastError());
     if (want_lcp) {
+      // entries tied with their predecessor, sorted by text position
+      TRY(scan_u32(SCAN_SUM, tied, loff, m0, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(loff, tied, m0, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      TRY(fetch_stats(c));
+      const u64 m1 = c->h_stats->count;
+      k_lcp_pairs<<<g0, 256, 0, st>>>(tied, loff, uidx0, sa32, m0, ckey_a, cval_a);
+      HIP_TRY(hipGetLastError());
+      int ps[8], pw[8], pn = 0;
+      for (int b = 0; b < nb; b += 8) {
+        ps[pn] = b;
+        pw[pn] = nb - b < 8 ? nb - b : 8;
+        pn++;
+      }
+      u32 *pval_b = uidx2;   // the round buffers are free now
+      TRY(radix_sort_pairs<u32>(ckey_a, cval_a, ckey_b, pval_b, m1, ps, pw, pn,
+                                rws2, st, nullptr, nullptr));
+      const u64 *pk = (pn & 1) ? ckey_b : ckey_a;
+      const u32 *pv = (pn & 1) ? pval_b : cval_a;
+      k_lcp_chunks<BITS><<<(u32) div_up(div_up(m1, LCP_CHUNK), 256), 256, 0, st>>>(
+          c->text, pk, pv, m1, uidx0, sa32, c->lcp, lcpu, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      k_large_flags<<<g0, 256, 0, st>>>(lcpu, m0, large);
+      HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, large, loff, m0, false, scanws2, st));
       k_total<<<1, 1, 0, st>>>(loff, large, m0, c->d_stats);
       HIP_TRY(hipGetLastError());
@@ -954,8 +1017,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         c->llv_cap = pairs + pairs / 4 + 1024;
       }
       if (pairs > 0) {
-        k_llv_emit<<<(u32) div_up(m0, 256), 256, 0, st>>>(uidx0, lcpu, large,
-                                                         loff, m0, 0, c->llv);
+        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, lcpu, large, loff, m0, 0, c->llv);
         HIP_TRY(hipGetLastError());
       }
       c->llv_pairs = pairs;

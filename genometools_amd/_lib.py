@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in
            ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h")] + \
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h")] + \
           [os.path.join(ROOT, "include", "gtamd_esa.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -24,6 +24,7 @@
 #include <vector>
 #include "../../include/gtamd_esa.h"
 #include "esa_prims.h"
+#include "esa_devutil.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -257,6 +258,8 @@ struct Stats {          // device-side accumulators
   unsigned long long longest;     // index of suffix 0
   u32 maxlcp;
   u32 count;                      // generic counter (compaction totals)
+  u32 count2;                     // second counter (deferred elements)
+  u32 pad;
 };
 
 constexpr int FIN_THREADS = 256;
@@ -442,27 +445,160 @@ __global__ __launch_bounds__(256) void k_rank_init(
   }
 }
 
-// composite key (group, rank of the suffix h symbols further on)
+// rank of the suffix h symbols further on, for every unresolved suffix
 __global__ __launch_bounds__(256) void k_round_gather(
-    const u32 *__restrict__ upos, const u32 *__restrict__ ugrp, u64 m, u64 h,
-    u64 n, const u32 *__restrict__ rank, u64 *__restrict__ ckey,
-    u32 *__restrict__ cval) {
+    const u32 *__restrict__ upos, u64 m, u64 h, u64 n,
+    const u32 *__restrict__ rank, u32 *__restrict__ k2) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
-  const u32 p = upos[j];
-  u64 q = (u64) p + h;
+  u64 q = (u64) upos[j] + h;
   if (q > n) q = n;  // cannot happen for a tied suffix; keeps the load in range
-  ckey[j] = ((u64) ugrp[j] << 32) | rank[q];
-  cval[j] = p;
+  k2[j] = rank[q];
 }
 
-__global__ __launch_bounds__(256) void k_round_heads(
-    const u64 *__restrict__ ckey, const u32 *__restrict__ uidx, u64 m,
-    u32 *__restrict__ hv) {
+// One doubling round for all tie groups that lie inside one tile of the
+// unresolved list: sort each group by k2 in LDS (bitonic network on the packed
+// key  local group | k2 | slot), derive the new group heads.  Groups that
+// reach across a tile border (or are larger than a tile) are left in place
+// and flagged for the global radix path.
+constexpr int RT_TILE = 2048;
+constexpr int RT_THREADS = 256;
+constexpr int RT_PER = RT_TILE / RT_THREADS;   // 8
+
+__global__ __launch_bounds__(RT_THREADS) void k_round_tile(
+    const u32 *__restrict__ uidx, const u32 *__restrict__ upos,
+    const u32 *__restrict__ ugrp, const u32 *__restrict__ k2, u64 m,
+    u32 *__restrict__ cv, u32 *__restrict__ hv, u32 *__restrict__ flg,
+    Stats *stats) {
+  __shared__ u64 s_key[RT_TILE];
+  __shared__ u32 s_grp[RT_TILE + 1];
+  __shared__ u32 s_pos[RT_TILE];
+  __shared__ u32 s_scan[4];
+  const int tid = threadIdx.x;
+  const u64 base = (u64) blockIdx.x * RT_TILE;
+  const u32 cnt = (u32) ((m - base) < (u64) RT_TILE ? (m - base) : (u64) RT_TILE);
+  // groups that continue in a neighbouring tile
+  const u32 g_first = ugrp[base], g_last = ugrp[base + cnt - 1];
+  const bool first_open = base > 0 && ugrp[base - 1] == g_first;
+  const bool last_open = base + cnt < m && ugrp[base + cnt] == g_last;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u32 e = (u32) c * RT_THREADS + tid;
+    if (e < cnt) {
+      s_grp[e] = ugrp[base + e];
+      s_pos[e] = upos[base + e];
+    } else {
+      s_grp[e] = 0xFFFFFFFFu;   // padding: one trailing pseudo group
+      s_pos[e] = 0;
+    }
+  }
+  __syncthreads();
+  // local group numbers: inclusive count of group starts, thread owns 8
+  // consecutive slots
+  u32 startflags = 0, nstart = 0;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u32 e = (u32) tid * RT_PER + c;
+    const bool st = e == 0 || s_grp[e] != s_grp[e - 1];
+    startflags |= (u32) st << c;
+    nstart += st;
+  }
+  u32 tot;
+  u32 lg = block_scan_excl_sum(nstart, &tot, s_scan);
+  u32 nflag = 0;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u32 e = (u32) tid * RT_PER + c;
+    lg += (startflags >> c) & 1u;
+    const u32 g = s_grp[e];
+    const bool open = e < cnt && ((first_open && g == g_first) ||
+                                  (last_open && g == g_last));
+    const u32 kk = (open || e >= cnt) ? 0u : k2[base + e];
+    s_key[e] = ((u64) lg << 43) | ((u64) kk << 11) | (u64) e;
+    if (e < cnt) flg[base + e] = open;
+    nflag += open;
+  }
+  __syncthreads();
+  // bitonic sort, ascending
+  for (u32 k = 2; k <= (u32) RT_TILE; k <<= 1) {
+    for (u32 j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int c = 0; c < RT_PER / 2; c++) {
+        const u32 idx = (u32) c * RT_THREADS + tid;
+        const u32 lo = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+        const u32 hi = lo + j;
+        const bool up = (lo & k) == 0;
+        const u64 a = s_key[lo], b = s_key[hi];
+        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  // outputs; new group head = first slot of every (group, k2) class
+  u32 hval[RT_PER], hmax = 0;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u32 e = (u32) tid * RT_PER + c;
+    const u64 key = s_key[e];
+    const bool head = e == 0 || (key >> 11) != (s_key[e - 1] >> 11);
+    const u32 v = (head && e < cnt) ? uidx[base + e] : 0u;
+    hval[c] = v;
+    hmax = v > hmax ? v : hmax;
+  }
+  u32 carry = block_scan_excl_max(hmax, &tot, s_scan);
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u32 e = (u32) tid * RT_PER + c;
+    carry = hval[c] > carry ? hval[c] : carry;
+    if (e < cnt) {
+      const u64 key = s_key[e];
+      const u32 src = (u32) (key & 2047u);
+      const u32 g = s_grp[src];
+      const bool open = (first_open && g == g_first) || (last_open && g == g_last);
+      if (!open) {
+        cv[base + e] = s_pos[src];
+        hv[base + e] = carry;
+      }
+    }
+  }
+  // number of deferred elements
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) nflag += __shfl_xor(nflag, d, 64);
+  if ((tid & 63) == 0 && nflag) atomicAdd(&stats->count2, nflag);
+}
+
+// global path for the deferred elements: composite key (group, k2)
+__global__ __launch_bounds__(256) void k_flag_gather(
+    const u32 *__restrict__ flg, const u32 *__restrict__ foff,
+    const u32 *__restrict__ ugrp, const u32 *__restrict__ k2,
+    const u32 *__restrict__ upos, u64 m, u64 *__restrict__ ckey,
+    u32 *__restrict__ cval, u32 *__restrict__ fj) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m) return;
-  const bool head = j == 0 || ckey[j] != ckey[j - 1];
-  hv[j] = head ? uidx[j] : 0u;
+  if (j >= m || !flg[j]) return;
+  const u32 o = foff[j];
+  ckey[o] = ((u64) ugrp[j] << 32) | k2[j];
+  cval[o] = upos[j];
+  fj[o] = (u32) j;
+}
+
+__global__ __launch_bounds__(256) void k_flag_heads(
+    const u64 *__restrict__ ckey, const u32 *__restrict__ uidx,
+    const u32 *__restrict__ fj, u64 nf, u32 *__restrict__ fhv) {
+  const u64 r = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (r >= nf) return;
+  const bool head = r == 0 || ckey[r] != ckey[r - 1];
+  fhv[r] = head ? uidx[fj[r]] : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_flag_scatter(
+    const u32 *__restrict__ cvs, const u32 *__restrict__ fhv,
+    const u32 *__restrict__ fj, u64 nf, u32 *__restrict__ cv,
+    u32 *__restrict__ hv) {
+  const u64 r = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (r >= nf) return;
+  const u32 j = fj[r];
+  cv[j] = cvs[r];
+  hv[j] = fhv[r];
 }
 
 // write the round's result back: positions into the suffix array, new group
@@ -474,11 +610,12 @@ __global__ __launch_bounds__(256) void k_round_apply(
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   const u32 p = cval[j], g = gnew[j], i = uidx[j];
-  sa32[i] = p;
   rank[p] = g;
   const bool head = g == i;
   const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
-  keep[j] = (head && nexthead) ? 0u : 1u;
+  const bool resolved = head && nexthead;
+  if (resolved) sa32[i] = p;   // final place; unresolved ones move again
+  keep[j] = resolved ? 0u : 1u;
 }
 
 __global__ __launch_bounds__(256) void k_round_compact(
@@ -906,7 +1043,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     m0 = c->h_stats->count;
     // arena layout (u32 units unless noted)
     const u64 mp = m0 + 64;
-    const u64 need = mp * 4 * 12 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
+    const u64 need = mp * 4 * 17 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
                      scan_workspace_words(m0) * 4 + 4096;
     TRY(ensure_arena(c, need));
     u32 *a32 = reinterpret_cast<u32 *>(c->arena);
@@ -924,6 +1061,11 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     u32 *hv = a32; a32 += mp;      // head values -> new group ids
     u32 *keep = a32; a32 += mp;
     u32 *koff = a32; a32 += mp;
+    u32 *k2 = a32; a32 += mp;      // rank of the suffix h further on
+    u32 *cvo = a32; a32 += mp;     // positions in the round's new order
+    u32 *flg = a32; a32 += mp;     // deferred to the global path
+    u32 *foff = a32; a32 += mp;
+    u32 *fj = a32; a32 += mp;
     u32 *rws2 = a32;               // radix + scan workspace for the rounds
     u32 *scanws2 = rws2 + radix_workspace_words(m0);
     k_unres_emit<<<(u32) div_up(nwords, 256), 256, 0, st>>>(
@@ -948,15 +1090,32 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         return -1;
       }
       const u32 g = (u32) div_up(m, 256);
-      k_round_gather<<<g, 256, 0, st>>>(upos, ugrp, m, h, n, rank, ckey_a, cval_a);
+      k_round_gather<<<g, 256, 0, st>>>(upos, m, h, n, rank, k2);
       HIP_TRY(hipGetLastError());
-      TRY(radix_sort_pairs<u32>(ckey_a, cval_a, ckey_b, cval_b, m, cs, cw, cnp,
-                                rws2, st, nullptr, nullptr));
-      const u64 *ck = (cnp & 1) ? ckey_b : ckey_a;
-      const u32 *cv = (cnp & 1) ? cval_b : cval_a;
-      k_round_heads<<<g, 256, 0, st>>>(ck, uidx, m, hv);
+      HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
+      k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(
+          uidx, upos, ugrp, k2, m, cvo, hv, flg, c->d_stats);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_MAX, hv, hv, m, true, scanws2, st));
+      TRY(fetch_stats(c));
+      const u64 nf = c->h_stats->count2;
+      if (nf > 0) {
+        // groups crossing a tile border / larger than a tile: global radix sort
+        TRY(scan_u32(SCAN_SUM, flg, foff, m, false, scanws2, st));
+        k_flag_gather<<<g, 256, 0, st>>>(flg, foff, ugrp, k2, upos, m, ckey_a,
+                                         cval_a, fj);
+        HIP_TRY(hipGetLastError());
+        TRY(radix_sort_pairs<u32>(ckey_a, cval_a, ckey_b, cval_b, nf, cs, cw,
+                                  cnp, rws2, st, nullptr, nullptr));
+        const u64 *ck = (cnp & 1) ? ckey_b : ckey_a;
+        const u32 *cvs = (cnp & 1) ? cval_b : cval_a;
+        const u32 gf = (u32) div_up(nf, 256);
+        k_flag_heads<<<gf, 256, 0, st>>>(ck, uidx, fj, nf, foff);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_MAX, foff, foff, nf, true, scanws2, st));
+        k_flag_scatter<<<gf, 256, 0, st>>>(cvs, foff, fj, nf, cvo, hv);
+        HIP_TRY(hipGetLastError());
+      }
+      const u32 *cv = cvo;
       k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, m, sa32, rank, keep);
       HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, keep, koff, m, false, scanws2, st));

@@ -3,52 +3,15 @@
 // (u64 key, u32 value) pairs built from LDS-staged digit histograms and
 // wavefront ballot ranking.  No rocPRIM/hipCUB.
 #include "esa_prims.h"
+#include "esa_devutil.h"
 
 // ===========================================================================
 // scans
 // ===========================================================================
 namespace {
 
-constexpr int SC_THREADS = 256;
 constexpr int SC_ITEMS = 16;
 constexpr int SC_TILE = SC_THREADS * SC_ITEMS;  // 4096
-
-template <int OP> __device__ __forceinline__ u32 sc_op(u32 a, u32 b) {
-  return OP == SCAN_SUM ? a + b : (a > b ? a : b);
-}
-
-// inclusive scan across the 64 lanes of a wave
-template <int OP> __device__ __forceinline__ u32 wave_scan_incl(u32 v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u32 o = __shfl_up(v, d, 64);
-    if (lane >= d) v = sc_op<OP>(v, o);
-  }
-  return v;
-}
-
-// block-wide exclusive scan of one value per thread (256 threads);
-// returns the exclusive prefix, *total gets the block total
-template <int OP>
-__device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *total, u32 *lds4) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  u32 inc = wave_scan_incl<OP>(v);
-  if (lane == 63) lds4[w] = inc;
-  __syncthreads();
-  u32 carry = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < SC_THREADS / 64; i++) {
-    u32 s = lds4[i];
-    if (i < w) carry = sc_op<OP>(carry, s);
-    tot = sc_op<OP>(tot, s);
-  }
-  __syncthreads();
-  *total = tot;
-  u32 prev = __shfl_up(inc, 1, 64);
-  if (lane == 0) prev = 0;
-  return sc_op<OP>(carry, prev);
-}
 
 template <int OP>
 __global__ __launch_bounds__(SC_THREADS) void k_scan_reduce(

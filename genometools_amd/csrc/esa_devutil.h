@@ -22,7 +22,7 @@ template <int OP> __device__ __forceinline__ u32 wave_scan_incl(u32 v) {
 
 // block-wide exclusive scan of one value per thread (256 threads);
 // returns the exclusive prefix, *total gets the block total
-template <int OP>
+template <int OP, int THREADS = SC_THREADS>
 __device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *total, u32 *lds4) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   u32 inc = wave_scan_incl<OP>(v);
@@ -30,7 +30,7 @@ __device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *total, u32 *lds4) {
   __syncthreads();
   u32 carry = 0, tot = 0;
 #pragma unroll
-  for (int i = 0; i < SC_THREADS / 64; i++) {
+  for (int i = 0; i < THREADS / 64; i++) {
     u32 s = lds4[i];
     if (i < w) carry = sc_op<OP>(carry, s);
     tot = sc_op<OP>(tot, s);

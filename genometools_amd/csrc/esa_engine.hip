@@ -605,12 +605,14 @@ __global__ __launch_bounds__(256) void k_flag_scatter(
 // heads into the rank table; flag what is still tied
 __global__ __launch_bounds__(256) void k_round_apply(
     const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
-    const u32 *__restrict__ uidx, u64 m, u32 *__restrict__ sa32,
-    u32 *__restrict__ rank, u32 *__restrict__ keep) {
+    const u32 *__restrict__ uidx, const u32 *__restrict__ ugrp, u64 m,
+    u32 *__restrict__ sa32, u32 *__restrict__ rank, u32 *__restrict__ keep) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   const u32 p = cval[j], g = gnew[j], i = uidx[j];
-  rank[p] = g;
+  // slot j stays inside its old group's range, so ugrp[j] is the old group of
+  // whichever suffix now sits here; the leading subgroup keeps that id
+  if (g != ugrp[j]) rank[p] = g;
   const bool head = g == i;
   const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
   const bool resolved = head && nexthead;
@@ -1116,7 +1118,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         HIP_TRY(hipGetLastError());
       }
       const u32 *cv = cvo;
-      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, m, sa32, rank, keep);
+      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, ugrp, m, sa32, rank, keep);
       HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, keep, koff, m, false, scanws2, st));
       k_round_compact<<<g, 256, 0, st>>>(keep, koff, uidx, cv, hv, m, uidx2,

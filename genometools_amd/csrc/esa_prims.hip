@@ -4,6 +4,7 @@
 // wavefront ballot ranking.  No rocPRIM/hipCUB.
 #include "esa_prims.h"
 #include "esa_devutil.h"
+#include <stdlib.h>
 
 // ===========================================================================
 // scans
@@ -104,9 +105,9 @@ int scan_u32(int op, const u32 *in, u32 *out, u64 n, bool inclusive, u32 *ws,
 // ===========================================================================
 namespace {
 
-constexpr int RS_THREADS = 256;
+constexpr int RS_THREADS = 512;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ITEMS = 16;
+constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;       // 4096 pairs per block
 constexpr int RS_WAVE_CHUNK = RS_ITEMS * 64;         // 1024 consecutive pairs
 constexpr int RADIX = 256;
@@ -131,8 +132,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
     }
   }
   __syncthreads();
-  u32 c = h[0][tid] + h[1][tid] + h[2][tid] + h[3][tid];
-  hist[(u64) tid * ntiles + blockIdx.x] = c;
+  if (tid < RADIX) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) c += h[i][tid];
+    hist[(u64) tid * ntiles + blockIdx.x] = c;
+  }
 }
 
 // lanes of this wave that hold the same 8-bit digit (all 64 lanes active)
@@ -154,7 +159,16 @@ __device__ __forceinline__ u64 match_digit(u32 d) {
 // ballot match inside the wave + a per-wave running digit counter in LDS.
 // The tile is then staged in LDS in digit order and written out so that
 // neighbouring lanes write neighbouring addresses of the same digit run.
-template <typename V>
+// XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2),
+// so they take CONSECUTIVE tiles; the output runs of consecutive tiles are
+// adjacent in every digit region, and the cache line two runs share is then
+// completed inside one L2 instead of leaving two XCDs as two partial writes.
+__device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
+  const u32 per = (ntiles + 7u) >> 3;
+  return (b & 7u) * per + (b >> 3);
+}
+
+template <typename V, bool XCD>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
     u64 *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
@@ -164,10 +178,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   __shared__ u32 s_cnt[RS_WAVES][RADIX];   // running counters, then wave prefix
   __shared__ u32 s_dbase[RADIX];           // tile-local start of each digit run
   __shared__ u32 s_obase[RADIX];           // global base minus local start
-  __shared__ u32 s_scan[4];
+  __shared__ u32 s_scan[RS_WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u64 tile_base = (u64) blockIdx.x * RS_TILE;
+  const u32 tile = XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x;
+  if (tile >= ntiles) return;   // whole block leaves together
+  const u64 tile_base = (u64) tile * RS_TILE;
   const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
                                                             : (u64) RS_TILE);
   for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
@@ -207,18 +223,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     rk[j] = ((old + intra) << 8) | d;
   }
   __syncthreads();
-  // digit totals over the 4 waves, wave-exclusive prefixes, tile-local bases
+  // digit totals over the waves, wave-exclusive prefixes, tile-local bases
+  // (threads 0..255 own one digit each; the scan needs all threads)
   {
-    u32 c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid],
-        c3 = s_cnt[3][tid];
-    u32 tot = c0 + c1 + c2 + c3, blocktot;
-    s_cnt[0][tid] = 0;
-    s_cnt[1][tid] = c0;
-    s_cnt[2][tid] = c0 + c1;
-    s_cnt[3][tid] = c0 + c1 + c2;
-    u32 dbase = block_scan_excl<SCAN_SUM>(tot, &blocktot, s_scan);
-    s_dbase[tid] = dbase;
-    s_obase[tid] = hist_scanned[(u64) tid * ntiles + blockIdx.x] - dbase;
+    u32 tot = 0;
+    if (tid < RADIX) {
+#pragma unroll
+      for (int i = 0; i < RS_WAVES; i++) {
+        const u32 c = s_cnt[i][tid];
+        s_cnt[i][tid] = tot;
+        tot += c;
+      }
+    }
+    u32 blocktot;
+    u32 dbase = block_scan_excl<SCAN_SUM, RS_THREADS>(tot, &blocktot, s_scan);
+    if (tid < RADIX) {
+      s_dbase[tid] = dbase;
+      s_obase[tid] = hist_scanned[(u64) tid * ntiles + tile] - dbase;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -250,12 +272,19 @@ u64 radix_workspace_words(u64 n) {
   return hist + scan_workspace_words(hist) + 64;
 }
 
+// tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
+static bool g_xcd_remap = true;
+
 template <typename V>
 int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
                      int *n_ev) {
   if (n == 0) return 0;
+  {
+    const char *e = getenv("GTAMD_XCD_REMAP");
+    g_xcd_remap = !(e != nullptr && e[0] == '0');
+  }
   if (n >= (1ull << 32)) {
     gtamd_set_error("radix_sort_pairs: %llu pairs exceed the 32-bit index "
                     "range of one sort", (unsigned long long) n);
@@ -273,9 +302,12 @@ int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
-    k_rs_scatter<V><<<ntiles, RS_THREADS, 0, st>>>(kin, vin, kout, vout, n,
-                                                   shifts[p], mask, hist,
-                                                   ntiles);
+    if (g_xcd_remap)
+      k_rs_scatter<V, true><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+    else
+      k_rs_scatter<V, false><<<ntiles, RS_THREADS, 0, st>>>(
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {
       HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));

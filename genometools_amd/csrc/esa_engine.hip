@@ -781,6 +781,7 @@ struct gtamd_esa_ctx {
   // refinement arena (grow-only)
   void *arena;
   u64 arena_bytes;
+  u32 user_prefixlength;   // 0 = automatic
   // results
   u32 want;
   bool ran;
@@ -876,6 +877,18 @@ extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
                     numparts);
     return -1;
   }
+  return 0;
+}
+
+extern "C" int gtamd_esa_set_prefixlength(gtamd_esa_ctx *c, uint32_t k) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  const u32 maxk = c->bits == 2 ? (u32) KeyLayout<2>::KEY_SYMS : (u32) KeyLayout<5>::KEY_SYMS;
+  if (k > maxk) {
+    gtamd_set_error("prefix length %u is too large: the maximal prefix length "
+                    "for this engine is %u", k, maxk);
+    return -1;
+  }
+  c->user_prefixlength = k;
   return 0;
 }
 
@@ -980,7 +993,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   hipStream_t st = c->st;
   const bool want_suf = want & GTAMD_WANT_SUF, want_lcp = want & GTAMD_WANT_LCP,
              want_bwt = want & GTAMD_WANT_BWT;
-  const u32 prefixlength = gtamd_recommended_prefixlength(c->sigma, n);
+  const u32 prefixlength = c->user_prefixlength
+                               ? c->user_prefixlength
+                               : gtamd_recommended_prefixlength(c->sigma, n);
   if (prefixlength > (u32) K::SYMS) {
     gtamd_set_error("prefixlength %u exceeds the key width %d", prefixlength,
                     K::SYMS);

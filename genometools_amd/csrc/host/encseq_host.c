@@ -1,0 +1,217 @@
+/* encseq_host.c -- FASTA reading, symbol encoding and sequence statistics of
+   the host layer (see include/gtamd_host.h for the reference interfaces). */
+#include "gtamd_host.h"
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+enum { SYM_UNDEF = 253 };
+
+static void build_symbolmap(uint8_t map[256], int protein)
+{
+  memset(map, SYM_UNDEF, 256);
+  if (protein) {
+    static const char letters[] = "LVIFKREDAGSTNQYWPHMC", wild[] = "XUBZJO*-";
+    for (int i = 0; letters[i]; i++) map[(uint8_t) letters[i]] = (uint8_t) i;
+    for (int i = 0; wild[i]; i++) map[(uint8_t) wild[i]] = GTAMD_WILDCARD;
+  } else {
+    static const char lower[] = "acgt", upper[] = "ACGT",
+                      wild[] = "nsywrkvbdhmNSYWRKVBDHM";
+    for (int i = 0; i < 4; i++) map[(uint8_t) lower[i]] = map[(uint8_t) upper[i]] = (uint8_t) i;
+    map['u'] = map['U'] = 3;
+    for (int i = 0; wild[i]; i++) map[(uint8_t) wild[i]] = GTAMD_WILDCARD;
+  }
+}
+
+typedef struct { uint8_t *p; uint64_t len, cap; } bytebuf;
+
+static int bb_push(bytebuf *b, uint8_t c)
+{
+  if (b->len == b->cap) {
+    uint64_t ncap = b->cap ? b->cap * 2 : (1u << 20);
+    uint8_t *np = realloc(b->p, ncap);
+    if (np == NULL) return -1;
+    b->p = np; b->cap = ncap;
+  }
+  b->p[b->len++] = c;
+  return 0;
+}
+
+static int is_blank(int c)
+{
+  return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
+}
+
+int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
+                       uint8_t **enc, uint64_t *n, char *err, size_t errlen)
+{
+  uint8_t map[256];
+  bytebuf out = {NULL, 0, 0};
+  int seen_header = 0;           /* any '>' so far, over all files */
+  uint64_t seqlen = 0;           /* symbols of the sequence being read */
+  static unsigned char buf[1 << 16];
+
+  build_symbolmap(map, protein);
+  for (size_t f = 0; f < numfiles; f++) {
+    FILE *fp = fopen(paths[f], "rb");
+    uint64_t line = 1;
+    int in_header = 0;
+    size_t got;
+    if (fp == NULL) {
+      snprintf(err, errlen, "cannot open file '%s'", paths[f]);
+      free(out.p);
+      return -1;
+    }
+    while ((got = fread(buf, 1, sizeof buf, fp)) > 0) {
+      for (size_t i = 0; i < got; i++) {
+        const int c = buf[i];
+        if (in_header) {
+          if (c == '\n') { line++; in_header = 0; }
+          continue;
+        }
+        if (c == '\n') line++;
+        if (is_blank(c)) continue;
+        if (c == '>') {
+          if (seen_header) {
+            if (seqlen == 0) {
+              snprintf(err, errlen, "file '%s' contains an empty sequence", paths[f]);
+              goto fail;
+            }
+            if (bb_push(&out, GTAMD_SEPARATOR) != 0) goto nomem;
+            seqlen = 0;
+          }
+          seen_header = 1;
+          in_header = 1;
+          continue;
+        }
+        if (map[c] == SYM_UNDEF) {
+          snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu",
+                   c, paths[f], (unsigned long long) line);
+          goto fail;
+        }
+        if (bb_push(&out, map[c]) != 0) goto nomem;
+        seqlen++;
+      }
+    }
+    fclose(fp);
+    continue;
+nomem:
+    snprintf(err, errlen, "out of memory while reading '%s'", paths[f]);
+fail:
+    fclose(fp);
+    free(out.p);
+    return -1;
+  }
+  if (!seen_header) {
+    snprintf(err, errlen, "no sequences in multiple fasta file(s) %s ...",
+             numfiles ? paths[0] : "");
+    free(out.p);
+    return -1;
+  }
+  if (seqlen == 0) {
+    snprintf(err, errlen, "file '%s' contains an empty sequence", paths[numfiles - 1]);
+    free(out.p);
+    return -1;
+  }
+  *enc = out.p;
+  *n = out.len;
+  return 0;
+}
+
+/* a run of `len` specials is stored as this many table entries when the run
+   length field holds at most maxv+1 (src/core/encseq.c:5061-5074) */
+static uint64_t pieces(uint64_t len, uint64_t maxv)
+{
+  if (maxv == UINT32_MAX || len <= maxv + 1) return 1;
+  return len / (maxv + 1) + (len % (maxv + 1) != 0);
+}
+
+typedef struct { uint64_t chars, runs, tab[3], prefix, suffix, current; int at_start; } runstat;
+
+static void run_feed(runstat *r, int member, int last)
+{
+  static const uint64_t maxv[3] = {UCHAR_MAX, USHRT_MAX, UINT32_MAX};
+  if (member) {
+    r->chars++; r->current++;
+    if (r->at_start) r->prefix++;
+  } else r->at_start = 0;
+  if ((!member || last) && r->current > 0) {
+    if (member && last) r->suffix = r->current;
+    r->runs++;
+    for (int k = 0; k < 3; k++) r->tab[k] += pieces(r->current, maxv[k]);
+    r->current = 0;
+  }
+}
+
+void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
+                          gtamd_seqstats *st)
+{
+  runstat sp, wc;
+  uint64_t seqlen = 0, firstlen = 0, nsep = 0;
+  int equal = 1;
+  memset(&sp, 0, sizeof sp); memset(&wc, 0, sizeof wc);
+  sp.at_start = wc.at_start = 1;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t c = enc[i];
+    run_feed(&sp, c >= GTAMD_WILDCARD, i + 1 == n);
+    run_feed(&wc, c == GTAMD_WILDCARD, i + 1 == n);
+    if (c == GTAMD_SEPARATOR) {
+      if (nsep == 0) firstlen = seqlen; else if (seqlen != firstlen) equal = 0;
+      nsep++; seqlen = 0;
+    } else seqlen++;
+  }
+  if (nsep > 0 && seqlen != firstlen) equal = 0;
+  memset(st, 0, sizeof *st);
+  st->totallength = n; st->numofchars = numofchars; st->numofsequences = nsep + 1;
+  st->specialcharacters = sp.chars; st->realspecialranges = sp.runs;
+  st->lengthofspecialprefix = sp.prefix; st->lengthofspecialsuffix = sp.suffix;
+  st->wildcards = wc.chars; st->realwildcardranges = wc.runs;
+  st->lengthofwildcardprefix = wc.prefix; st->lengthofwildcardsuffix = wc.suffix;
+  /* which table width the reference would store the ranges with decides the
+     "ranges" numbers: smallest representation, bit access as the start value,
+     equal-length sequence sets and non-DNA alphabets use the first variant
+     (src/core/encseq_access_type.c:95-162; SW table size encseq.c:924-949) */
+  st->specialranges = sp.tab[0]; st->wildcardranges = wc.tab[0];
+  if (numofchars == 4 && !(equal && wc.chars == 0)) {
+    static const uint64_t width[3] = {1, 2, 4}, maxv[3] = {UCHAR_MAX, USHRT_MAX, UINT32_MAX};
+    uint64_t best = (wc.tab[0] > 0 || nsep > 0) ? 8 * ((n + 64 + 63) / 64) : 0;
+    for (int k = 0; k < 3; k++) {
+      const uint64_t size = wc.tab[k] == 0 ? 0
+        : 2 * width[k] * wc.tab[k] + 8 * (n / maxv[k] + 1);
+      if (size < best) {
+        best = size; st->specialranges = sp.tab[k]; st->wildcardranges = wc.tab[k];
+      }
+    }
+  }
+}
+
+int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
+                    const gtamd_esa_stats *es, int with_lcp)
+{
+  FILE *fp = fopen(path, "wb");
+  const unsigned long long n1 = es->numberofallsortedsuffixes;
+  if (fp == NULL) return -1;
+  fprintf(fp, "totallength=%llu\n", (unsigned long long) ss->totallength);
+  fprintf(fp, "specialcharacters=%llu\n", (unsigned long long) ss->specialcharacters);
+  fprintf(fp, "specialranges=%llu\n", (unsigned long long) ss->specialranges);
+  fprintf(fp, "realspecialranges=%llu\n", (unsigned long long) ss->realspecialranges);
+  fprintf(fp, "lengthofspecialprefix=%llu\n", (unsigned long long) ss->lengthofspecialprefix);
+  fprintf(fp, "lengthofspecialsuffix=%llu\n", (unsigned long long) ss->lengthofspecialsuffix);
+  fprintf(fp, "wildcards=%llu\n", (unsigned long long) ss->wildcards);
+  fprintf(fp, "wildcardranges=%llu\n", (unsigned long long) ss->wildcardranges);
+  fprintf(fp, "realwildcardranges=%llu\n", (unsigned long long) ss->realwildcardranges);
+  fprintf(fp, "lengthofwildcardprefix=%llu\n", (unsigned long long) ss->lengthofwildcardprefix);
+  fprintf(fp, "lengthofwildcardsuffix=%llu\n", (unsigned long long) ss->lengthofwildcardsuffix);
+  fprintf(fp, "numofsequences=%llu\n", (unsigned long long) ss->numofsequences);
+  fprintf(fp, "numofdbsequences=%llu\n", (unsigned long long) ss->numofsequences);
+  fprintf(fp, "numofquerysequences=0\n");
+  fprintf(fp, "numberofallsortedsuffixes=%llu\n", n1);
+  fprintf(fp, "longest=%llu\n", (unsigned long long) es->longest);
+  fprintf(fp, "prefixlength=%u\n", es->prefixlength);
+  fprintf(fp, "largelcpvalues=%llu\n", with_lcp ? (unsigned long long) es->largelcpvalues : 0ull);
+  fprintf(fp, "averagelcp=%.2f\n", with_lcp ? (double) es->lcptabsum / (double) n1 : 0.0);
+  fprintf(fp, "maxbranchdepth=%llu\n", with_lcp ? (unsigned long long) es->maxbranchdepth : 0ull);
+  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=0\nmirrored=0\n");
+  return fclose(fp) == 0 ? 0 : -1;
+}

@@ -1,0 +1,173 @@
+/* suffixerator_tool.c -- `gt suffixerator` for the option subset of this path,
+   in the shape of a GtToolfunc (src/core/toolbox.h:32): parse, encode, build
+   on the device through the C ABI, write INDEX.suf/.lcp/.llv/.bwt/.prj.
+   Option names and defaults follow src/core/encseq_options.c:181-290 and
+   src/match/index_options.c:298-515; file suffixes src/match/esa-fileend.h. */
+#include "gtamd_host.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXDB 1024
+
+static int fail(char *err, size_t errlen, const char *msg, const char *arg)
+{
+  snprintf(err, errlen, msg, arg);
+  return -1;
+}
+
+static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
+                       const char *suffix, size_t entrysize, char *err, size_t errlen)
+{
+  char path[4096];
+  const uint64_t entries = gtamd_esa_table_entries(ctx, which);
+  const uint64_t chunk = (64u << 20) / entrysize;   /* 64 MiB staging buffer */
+  void *buf = malloc(chunk * entrysize);
+  FILE *fp;
+  snprintf(path, sizeof path, "%s%s", index, suffix);
+  fp = fopen(path, "wb");
+  if (fp == NULL || buf == NULL) {
+    snprintf(err, errlen, "cannot open file '%s' for writing", path);
+    free(buf); if (fp) fclose(fp);
+    return -1;
+  }
+  for (uint64_t first = 0; first < entries; first += chunk) {
+    const uint64_t cnt = entries - first < chunk ? entries - first : chunk;
+    if (gtamd_esa_table_copy(ctx, which, buf, first, cnt) != 0) {
+      snprintf(err, errlen, "%s", gtamd_esa_last_error());
+      free(buf); fclose(fp);
+      return -1;
+    }
+    if (fwrite(buf, entrysize, cnt, fp) != cnt) {
+      snprintf(err, errlen, "cannot write to file '%s'", path);
+      free(buf); fclose(fp);
+      return -1;
+    }
+  }
+  free(buf);
+  return fclose(fp) == 0 ? 0 : fail(err, errlen, "cannot close file '%s'", path);
+}
+
+static int yesno(int argc, const char **argv, int *i)
+{
+  /* options like -tis take an optional yes|no argument */
+  if (*i + 1 < argc && (!strcmp(argv[*i + 1], "yes") || !strcmp(argv[*i + 1], "no")))
+    (*i)++;
+  return 0;
+}
+
+int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
+{
+  const char *db[MAXDB], *indexname = NULL;
+  size_t numdb = 0;
+  int protein = 0, dna = 0, verbose = 0;
+  uint32_t want = 0, userpl = 0;
+  char indexbuf[4096];
+  uint8_t *enc = NULL;
+  uint64_t n = 0;
+  gtamd_seqstats ss;
+  gtamd_esa_stats es;
+  gtamd_esa_ctx *ctx;
+  int rc = -1;
+
+  for (int i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    if (!strcmp(a, "-db")) {
+      while (i + 1 < argc && argv[i + 1][0] != '-') {
+        if (numdb == MAXDB) return fail(err, errlen, "too many arguments to option \"-%s\"", "db");
+        db[numdb++] = argv[++i];
+      }
+      if (numdb == 0) return fail(err, errlen, "missing argument to option \"-%s\"", "db");
+    } else if (!strcmp(a, "-indexname")) {
+      if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "indexname");
+      indexname = argv[++i];
+    } else if (!strcmp(a, "-dna")) dna = 1;
+    else if (!strcmp(a, "-protein")) protein = 1;
+    else if (!strcmp(a, "-suf")) want |= GTAMD_WANT_SUF;
+    else if (!strcmp(a, "-lcp")) want |= GTAMD_WANT_LCP;
+    else if (!strcmp(a, "-bwt")) want |= GTAMD_WANT_BWT;
+    else if (!strcmp(a, "-v")) verbose = 1;
+    else if (!strcmp(a, "-pl")) {
+      if (i + 1 < argc && argv[i + 1][0] != '-') userpl = (uint32_t) strtoul(argv[++i], NULL, 10);
+    } else if (!strcmp(a, "-dir")) {
+      if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "dir");
+      if (strcmp(argv[++i], "fwd") != 0)
+        return fail(err, errlen, "option -dir %s is not supported by the MI355X engine (only fwd)", argv[i]);
+    } else if (!strcmp(a, "-parts") || !strcmp(a, "-memlimit") || !strcmp(a, "-dc")) {
+      /* space/strategy knobs of the CPU algorithm: the tables do not depend on
+         them, the device build ignores them */
+      if (i + 1 < argc && argv[i + 1][0] != '-') i++;
+    } else if (!strcmp(a, "-tis") || !strcmp(a, "-des") || !strcmp(a, "-sds") ||
+               !strcmp(a, "-ssp") || !strcmp(a, "-md5") || !strcmp(a, "-showprogress")) {
+      yesno(argc, argv, &i);
+    } else
+      return fail(err, errlen, "unknown option: %s (try -help)", a);
+  }
+  if (numdb == 0) return fail(err, errlen, "option \"-%s\" is mandatory", "db");
+  if (dna && protein)
+    return fail(err, errlen, "option \"-dna\" and option \"-%s\" exclude each other", "protein");
+  if (indexname == NULL) {
+    /* default: basename of the single -db file (encseq_options.c:112-131) */
+    const char *base;
+    if (numdb > 1)
+      return fail(err, errlen, "if more than one input file is given, then option -%s is mandatory", "indexname");
+    base = strrchr(db[0], '/');
+    snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : db[0]);
+    indexname = indexbuf;
+  }
+  if (gtamd_encode_files(db, numdb, protein, &enc, &n, err, errlen) != 0) return -1;
+  gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
+  if (verbose) {
+    printf("# totallength=%llu\n# specialcharacters=%llu\n# numofsequences=%llu\n",
+           (unsigned long long) ss.totallength, (unsigned long long) ss.specialcharacters,
+           (unsigned long long) ss.numofsequences);
+  }
+  memset(&es, 0, sizeof es);
+  es.totallength = n;
+  es.numberofallsortedsuffixes = n + 1;
+  es.prefixlength = userpl ? userpl : gtamd_recommended_prefixlength(ss.numofchars, n);
+  if (want == 0) {
+    /* nothing but the sequence statistics requested: the reference still
+       writes the project file (src/match/sfx-run.c:664-694) */
+    char path[4096];
+    free(enc);
+    snprintf(path, sizeof path, "%s.prj", indexname);
+    if (gtamd_write_prj(path, &ss, &es, 0) != 0)
+      return fail(err, errlen, "cannot open file '%s' for writing", path);
+    return 0;
+  }
+  ctx = gtamd_esa_create(0, n, ss.numofchars);
+  if (ctx == NULL) {
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+    free(enc);
+    return -1;
+  }
+  if (gtamd_esa_set_prefixlength(ctx, userpl) != 0 ||
+      gtamd_esa_set_sequence_bytes(ctx, enc, n, 0) != 0 ||
+      gtamd_esa_run(ctx, want) != 0 || gtamd_esa_get_stats(ctx, &es) != 0) {
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+    goto done;
+  }
+  if (verbose)
+    printf("# prefixlength=%u\n# tied suffixes after the first sort=%llu, refinement rounds=%u\n",
+           es.prefixlength, (unsigned long long) es.tied_suffixes, es.refine_rounds);
+  if ((want & GTAMD_WANT_SUF) && write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", 8, err, errlen) != 0) goto done;
+  if (want & GTAMD_WANT_LCP) {
+    if (write_table(ctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0) goto done;
+    if (write_table(ctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0) goto done;
+  }
+  if ((want & GTAMD_WANT_BWT) && write_table(ctx, GTAMD_TAB_BWT, indexname, ".bwt", 1, err, errlen) != 0) goto done;
+  {
+    char path[4096];
+    snprintf(path, sizeof path, "%s.prj", indexname);
+    if (gtamd_write_prj(path, &ss, &es, (want & GTAMD_WANT_LCP) != 0) != 0) {
+      fail(err, errlen, "cannot open file '%s' for writing", path);
+      goto done;
+    }
+  }
+  rc = 0;
+done:
+  gtamd_esa_destroy(ctx);
+  free(enc);
+  return rc;
+}

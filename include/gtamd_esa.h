@@ -108,6 +108,11 @@ void gtamd_esa_destroy(gtamd_esa_ctx *ctx);
    Default 0 of 1. */
 int gtamd_esa_set_part(gtamd_esa_ctx *ctx, uint32_t part, uint32_t numparts);
 
+/* Prefix length to report in .prj and to mask averagelcp with (option -pl K of
+   src/match/index_options.c:363; 0 = gt_recommendedprefixlength).  The device
+   algorithm itself does not bucket by it. */
+int gtamd_esa_set_prefixlength(gtamd_esa_ctx *ctx, uint32_t prefixlength);
+
 /* ---- input: the encoded sequence (GtEncseq read side) ------------------ */
 /* One byte per symbol as the reference's encoder delivers them
    (src/core/encseq.c:249 gt_encseq_get_encoded_char): 0..sigma-1 letters,

@@ -1,0 +1,63 @@
+/*
+  gtamd_host.h -- host-side C layer around the device engine: what the
+  reference's driver (src/match/sfx-run.c:428-717) does before and after the
+  Sfxiterator loop, reduced to the `gt suffixerator` surface of this path.
+
+    gtamd_encode_files      GtEncseqEncoder read side: FASTA -> encoded symbols
+                            (src/core/sequence_buffer_fasta.c:44-170,
+                            src/core/alphabet.c:84-91,345-356,480-503)
+    gtamd_sequence_stats    GtSpecialcharinfo (src/core/chardef.h:91-116,
+                            src/core/encseq_charproc.gen, encseq.c:5061-5127)
+    gtamd_write_prj         gt_outprjfile (src/match/sfx-outprj.c:38-118)
+    gtamd_suffixerator      the tool function, GtToolfunc shape
+                            (src/core/toolbox.h:32, src/tools/gt_suffixerator.c:22)
+
+  Pure C (gcc); links against libgtamd_esa.so for the hot path.
+*/
+#ifndef GTAMD_HOST_H
+#define GTAMD_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "gtamd_esa.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  uint64_t totallength, specialcharacters, specialranges, realspecialranges,
+           lengthofspecialprefix, lengthofspecialsuffix, wildcards,
+           wildcardranges, realwildcardranges, lengthofwildcardprefix,
+           lengthofwildcardsuffix, numofsequences;
+  uint32_t numofchars;
+} gtamd_seqstats;
+
+/* Read one or more (multi-)FASTA files into one encoded sequence; consecutive
+   sequences are joined by one separator, also across files.  protein != 0
+   selects the protein alphabet.  *enc is malloc'ed.  Returns 0, or -1 with the
+   reference's error text in err ("illegal character 'X': file \"f\", line 2",
+   "file 'f' contains an empty sequence"). */
+int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
+                       uint8_t **enc, uint64_t *n, char *err, size_t errlen);
+
+void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
+                          gtamd_seqstats *st);
+
+/* INDEX.prj; with_lcp == 0 writes the zero LCP statistics the reference
+   writes when -lcp was not requested (src/match/sfx-run.c:664-670) */
+int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
+                    const gtamd_esa_stats *es, int with_lcp);
+
+/* `gt suffixerator` for the option subset of this path:
+     -db FILE...  -indexname NAME  -dna | -protein  -suf -lcp -bwt
+     -pl [K]  -v  -dir fwd   and, accepted without effect on the tables,
+     -parts N  -memlimit X  -dc V  -tis -des -sds -ssp -md5 [yes|no]
+   argv[0] is the tool name.  Returns 0, or -1 with the message in err (the
+   caller prints "gt suffixerator: error: <err>" and exits 1, src/gt.c:48-52). */
+int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

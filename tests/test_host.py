@@ -1,0 +1,125 @@
+"""Host-side C layer (libgtamd_host.so): FASTA encoder, sequence statistics
+and the .prj writer against the reference's golden data and the oracle.  No
+GPU needed; the tool function itself is exercised in test_cli_gpu.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from genometools_amd import _lib
+from genometools_amd._lib import EsaStats
+
+GOLDEN = ou.golden()
+HOST_DIR = os.path.join(_lib.HERE, "csrc", "host")
+HOST_LIB = os.path.join(_lib.HERE, "libgtamd_host.so")
+
+
+class SeqStats(ctypes.Structure):
+    _fields_ = ou.SeqStats._fields_
+
+
+@pytest.fixture(scope="module")
+def host():
+    _lib.build_library()
+    subprocess.run(["make", "-C", HOST_DIR], check=True, stdout=subprocess.DEVNULL)
+    _lib.load()   # libgtamd_esa.so first (dependency)
+    L = ctypes.CDLL(HOST_LIB)
+    P = ctypes.c_void_p
+    L.gtamd_encode_files.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t,
+                                     ctypes.c_int, ctypes.POINTER(P),
+                                     ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
+                                     ctypes.c_size_t]
+    L.gtamd_sequence_stats.argtypes = [P, ctypes.c_uint64, ctypes.c_uint32,
+                                       ctypes.POINTER(SeqStats)]
+    L.gtamd_write_prj.argtypes = [ctypes.c_char_p, ctypes.POINTER(SeqStats),
+                                  ctypes.POINTER(EsaStats), ctypes.c_int]
+    L.gtamd_suffixerator.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                     ctypes.c_char_p, ctypes.c_size_t]
+    return L
+
+
+def _encode(host, paths, protein=False):
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    err = ctypes.create_string_buffer(2048)
+    rc = host.gtamd_encode_files(arr, len(paths), int(protein), ctypes.byref(ptr),
+                                 ctypes.byref(n), err, 2048)
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    enc = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint8)
+    ctypes.CDLL(None).free(ptr)
+    return enc
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_encoder_and_prj_match_reference(host, name, tmp_path):
+    e = GOLDEN[name]
+    protein = e["alphabet"] == "protein"
+    enc = _encode(host, [ou.fixture_path(name)], protein)
+    assert np.array_equal(enc, ou.encode_fasta(ou.fixture_path(name), protein))
+    prj = dict(l.split("=") for l in e["prj"].splitlines())
+    assert enc.size == int(prj["totallength"])
+    ss = SeqStats()
+    host.gtamd_sequence_stats(enc.ctypes.data, enc.size, 20 if protein else 4,
+                              ctypes.byref(ss))
+    for key in ("specialcharacters", "specialranges", "realspecialranges",
+                "lengthofspecialprefix", "lengthofspecialsuffix", "wildcards",
+                "wildcardranges", "realwildcardranges", "lengthofwildcardprefix",
+                "lengthofwildcardsuffix", "numofsequences"):
+        assert getattr(ss, key) == int(prj[key]), key
+    # the .prj writer, fed with the table statistics the oracle derives
+    ora = ou.esa(enc, 20 if protein else 4)["stats"]
+    es = EsaStats(totallength=enc.size, numberofallsortedsuffixes=enc.size + 1,
+                  longest=ora["longest"], largelcpvalues=ora["largelcpvalues"],
+                  maxbranchdepth=ora["maxbranchdepth"], lcptabsum=int(ora["lcptabsum"]),
+                  prefixlength=ora["prefixlength"])
+    out = str(tmp_path / "x.prj")
+    assert host.gtamd_write_prj(out.encode(), ctypes.byref(ss), ctypes.byref(es), 1) == 0
+    with open(out) as f:
+        assert f.read() == e["prj"]
+
+
+def test_multiple_files_are_joined_by_separators(host):
+    # Small.fna + Verysmall.fna -> 151 + 1 + 8 = 160
+    a = _encode(host, [ou.fixture_path("Small.fna")])
+    b = _encode(host, [ou.fixture_path("Verysmall.fna")])
+    ab = _encode(host, [ou.fixture_path("Small.fna"), ou.fixture_path("Verysmall.fna")])
+    assert ab.size == a.size + 1 + b.size
+    assert np.array_equal(ab, np.concatenate([a, [255], b]))
+
+
+def test_encoder_errors_use_the_reference_wording(host, tmp_path):
+    p = tmp_path / "bad.fna"
+    p.write_text(">a\nACGT\nACXT\n")
+    with pytest.raises(ValueError, match=r"illegal character 'X': file \".*bad.fna\", line 3"):
+        _encode(host, [str(p)])
+    p.write_text(">a\n>b\nACGT\n")
+    with pytest.raises(ValueError, match="bad.fna' contains an empty sequence"):
+        _encode(host, [str(p)])
+    p.write_text(">a\nacgt\n>b\n")
+    with pytest.raises(ValueError, match="contains an empty sequence"):
+        _encode(host, [str(p)])
+    p.write_text(">p\nlvif\n")     # lower-case protein letters are illegal
+    with pytest.raises(ValueError, match="illegal character 'l'"):
+        _encode(host, [str(p)], protein=True)
+    with pytest.raises(ValueError, match="cannot open file"):
+        _encode(host, [str(tmp_path / "missing.fna")])
+
+
+def test_tool_argument_errors(host):
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"suffixerator", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        rc = host.gtamd_suffixerator(len(args) + 1, argv, err, 2048)
+        return rc, err.value.decode()
+    assert run("-suf") == (-1, 'option "-db" is mandatory')
+    rc, msg = run("-db", "a.fna", "b.fna", "-suf")
+    assert rc == -1 and "option -indexname is mandatory" in msg
+    rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-dir", "rev", "-suf")
+    assert rc == -1 and "-dir rev is not supported" in msg
+    rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-frobnicate")
+    assert rc == -1 and "unknown option" in msg

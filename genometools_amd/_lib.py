@@ -74,6 +74,7 @@ ABI = {
     "gtamd_esa_destroy": (None, [_P]),
     "gtamd_esa_set_part": (_INT, [_P, _U32, _U32]),
     "gtamd_esa_set_prefixlength": (_INT, [_P, _U32]),
+    "gtamd_esa_set_comm": (_INT, [_P, _P, _P, _P]),
     "gtamd_esa_set_sequence_bytes": (_INT, [_P, _P, _U64, _INT]),
     "gtamd_esa_set_sequence_packed": (_INT, [_P, _P, _P, _U64]),
     "gtamd_esa_run": (_INT, [_P, _U32]),

@@ -249,6 +249,124 @@ __global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
 }
 
 // ---------------------------------------------------------------------------
+// part builds: lexicographic range partition (the reference's -parts idea,
+// src/match/sfx-partssuf.c:172-347, filter src/match/sfx-suffixer.c:375-398)
+// ---------------------------------------------------------------------------
+constexpr int PART_BITS = 14;
+constexpr int PART_BINS = 1 << PART_BITS;
+
+// histogram of the leading PART_BITS key bits over all suffixes
+template <int BITS>
+__global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N,
+                                                  u32 *__restrict__ hist) {
+  __shared__ u32 h[PART_BINS];
+  for (int i = threadIdx.x; i < PART_BINS; i += 256) h[i] = 0;
+  __syncthreads();
+  for (u64 p = (u64) blockIdx.x * 256 + threadIdx.x; p < N;
+       p += (u64) gridDim.x * 256)
+    atomicAdd(&h[(u32) (make_key<BITS>(t, p) >> (64 - PART_BITS))], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < PART_BINS; i += 256)
+    if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+// suffixes of one block of 1024 text positions whose key falls in [lo, hi)
+template <int BITS>
+__global__ __launch_bounds__(256) void k_part_count(Text t, u64 N, u32 lo,
+                                                    u32 hi, u32 *__restrict__ cnt) {
+  __shared__ u32 s_scan[4];
+  const u64 p0 = (u64) blockIdx.x * 1024 + (u64) threadIdx.x * 4;
+  u32 c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u64 p = p0 + k;
+    if (p < N) {
+      const u32 b = (u32) (make_key<BITS>(t, p) >> (64 - PART_BITS));
+      c += b >= lo && b < hi;
+    }
+  }
+  u32 tot;
+  (void) block_scan_excl_sum(c, &tot, s_scan);
+  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+}
+
+// order-preserving emission of the (key, position) pairs of this range
+template <int BITS>
+__global__ __launch_bounds__(256) void k_part_emit(
+    Text t, u64 N, u32 lo, u32 hi, const u32 *__restrict__ off,
+    u64 *__restrict__ keys, u32 *__restrict__ vals) {
+  __shared__ u32 s_scan[4];
+  const u64 p0 = (u64) blockIdx.x * 1024 + (u64) threadIdx.x * 4;
+  u64 key[4];
+  u32 mask = 0, c = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u64 p = p0 + k;
+    key[k] = 0;
+    if (p < N) {
+      key[k] = make_key<BITS>(t, p);
+      const u32 b = (u32) (key[k] >> (64 - PART_BITS));
+      if (b >= lo && b < hi) { mask |= 1u << k; c++; }
+    }
+  }
+  u32 tot;
+  u32 o = off[blockIdx.x] + block_scan_excl_sum(c, &tot, s_scan);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (mask & (1u << k)) {
+      keys[o] = key[k];
+      vals[o] = (u32) (p0 + k);
+      o++;
+    }
+}
+
+// distributed rank lookup: which part owns the suffix h symbols further on
+template <int BITS>
+__global__ __launch_bounds__(256) void k_query_dest(
+    Text t, const u32 *__restrict__ upos, u64 m, u64 h,
+    const u8 *__restrict__ owner, u64 *__restrict__ dkey,
+    u32 *__restrict__ dval, u32 *__restrict__ counts) {
+  __shared__ u32 s_cnt[256];
+  s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j < m) {
+    u64 q = (u64) upos[j] + h;
+    if (q > t.n) q = t.n;
+    const u32 d = owner[(u32) (make_key<BITS>(t, q) >> (64 - PART_BITS))];
+    dkey[j] = d;
+    dval[j] = (u32) j;
+    atomicAdd(&s_cnt[d], 1u);
+  }
+  __syncthreads();
+  if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_query_fill(
+    const u32 *__restrict__ upos, const u32 *__restrict__ order, u64 m, u64 h,
+    u64 n, u32 *__restrict__ sendq) {
+  const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  u64 q = (u64) upos[order[s]] + h;
+  sendq[s] = (u32) (q > n ? n : q);
+}
+
+__global__ __launch_bounds__(256) void k_answer(const u32 *__restrict__ q,
+                                                u64 cnt,
+                                                const u32 *__restrict__ rank,
+                                                u32 *__restrict__ ans) {
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt) ans[i] = rank[q[i]];
+}
+
+__global__ __launch_bounds__(256) void k_k2_scatter(
+    const u32 *__restrict__ ans, const u32 *__restrict__ order, u64 m,
+    u32 *__restrict__ k2) {
+  const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (s < m) k2[order[s]] = ans[s];
+}
+
+// ---------------------------------------------------------------------------
 // finalize
 // ---------------------------------------------------------------------------
 struct Stats {          // device-side accumulators
@@ -272,7 +390,10 @@ template <int BITS>
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
     const u64 *__restrict__ keys, const u32 *__restrict__ pos, u64 N,
     u32 prefixlength, u64 *__restrict__ suf, u8 *__restrict__ lcp,
-    u8 *__restrict__ bwt, u64 *__restrict__ tiebits, Stats *stats) {
+    u8 *__restrict__ bwt, u64 *__restrict__ tiebits, Stats *stats,
+    u64 prev_key, int has_prev, u64 index_offset) {
+  // prev_key: key of the entry in front of this slice (part builds): the last
+  // key of the preceding lexicographic range, needed for the LCP of entry 0
   using K = Key<BITS>;
   __shared__ unsigned long long s_sum[FIN_THREADS / 64];
   __shared__ unsigned long long s_ties[FIN_THREADS / 64];
@@ -302,7 +423,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
     // predecessor key: previous lane's last key, or a global load at the
     // wave's left edge
     u64 prevk = __shfl_up(k[3], 1, 64);
-    if (lane == 0) prevk = (i0 > 0 && i0 < N + 4) ? keys[i0 - 1] : ~0ull;
+    if (lane == 0) prevk = i0 == 0 ? prev_key : (i0 < N + 4 ? keys[i0 - 1] : ~0ull);
     u32 lcpv[4], tiemask = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -315,13 +436,14 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
       u32 l = m < da ? m : da;
       l = l < db ? l : db;
       bool tie = (m == (u32) K::SYMS) && (K::dcode(a) == 0) && (K::dcode(b) == 0);
-      if (i == 0 || i >= N) { l = 0; tie = false; }
+      if ((i == 0 && !has_prev) || i >= N) l = 0;
+      if (i == 0 || i >= N) tie = false;   // equal keys never straddle a range border
       lcpv[c] = l;
       if (tie) { tiemask |= 1u << c; ties++; }
       else if (i < N) {
         mx = l > mx ? l : mx;
         if (db >= prefixlength) sum += l;
-        if (p[c] == 0) stats->longest = i;
+        if (p[c] == 0) stats->longest = index_offset + i;
       }
     }
     if (i0 + 4 <= N) {
@@ -436,12 +558,13 @@ __global__ __launch_bounds__(256) void k_unres_emit(
 // sort; refined in place by the doubling rounds)
 __global__ __launch_bounds__(256) void k_rank_init(
     const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
-    const u32 *__restrict__ sa32, u64 N, u32 *__restrict__ rank) {
+    const u32 *__restrict__ sa32, u64 N, u32 rank_offset,
+    u32 *__restrict__ rank) {
   const u64 base = (u64) blockIdx.x * 1024;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const u64 i = base + (u64) j * 256 + threadIdx.x;
-    if (i < N) rank[sa32[i]] = group_head(tiebits, carry, i);
+    if (i < N) rank[sa32[i]] = rank_offset + group_head(tiebits, carry, i);
   }
 }
 
@@ -606,13 +729,14 @@ __global__ __launch_bounds__(256) void k_flag_scatter(
 __global__ __launch_bounds__(256) void k_round_apply(
     const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
     const u32 *__restrict__ uidx, const u32 *__restrict__ ugrp, u64 m,
-    u32 *__restrict__ sa32, u32 *__restrict__ rank, u32 *__restrict__ keep) {
+    u32 rank_offset, u32 *__restrict__ sa32, u32 *__restrict__ rank,
+    u32 *__restrict__ keep) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m) return;
   const u32 p = cval[j], g = gnew[j], i = uidx[j];
   // slot j stays inside its old group's range, so ugrp[j] is the old group of
   // whichever suffix now sits here; the leading subgroup keeps that id
-  if (g != ugrp[j]) rank[p] = g;
+  if (g != ugrp[j]) rank[p] = rank_offset + g;
   const bool head = g == i;
   const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
   const bool resolved = head && nexthead;
@@ -652,14 +776,14 @@ __global__ __launch_bounds__(256) void k_fix_basic(
     Text t, const u32 *__restrict__ uidx0, u64 m0,
     const u64 *__restrict__ tiebits, const u32 *__restrict__ sa32,
     u64 *__restrict__ suf, u8 *__restrict__ bwt, u32 *__restrict__ tied,
-    u32 *__restrict__ lcpu, Stats *stats) {
+    u32 *__restrict__ lcpu, Stats *stats, u64 index_offset) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m0) return;
   const u64 i = uidx0[j];
   const u64 p = sa32[i];
   if (suf != nullptr) suf[i] = p;
   if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
-  if (p == 0) stats->longest = i;
+  if (p == 0) stats->longest = index_offset + i;
   tied[j] = (u32) ((tiebits[i >> 6] >> (i & 63)) & 1ull);
   lcpu[j] = 0;
 }
@@ -782,6 +906,16 @@ struct gtamd_esa_ctx {
   void *arena;
   u64 arena_bytes;
   u32 user_prefixlength;   // 0 = automatic
+  // part build (lexicographic range `part` of `numparts`)
+  u32 part, numparts;
+  gtamd_allgather_fn comm_allgather;
+  gtamd_alltoallv_fn comm_alltoallv;
+  void *comm_user;
+  u64 NL, index_offset;    // entries and offset of this part's slice
+  u32 *d_parthist;         // PART_BINS counters
+  u8 *d_owner;             // bin -> owning part
+  u32 *xbuf;               // exchange buffers (grow-only)
+  u64 xbuf_words;
   // results
   u32 want;
   bool ran;
@@ -802,7 +936,8 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
   free_dev(c->rws); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
   free_dev(c->llv); free_dev(c->tiebits); free_dev(c->d_stats);
-  free_dev(c->arena);
+  free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
+  free_dev(c->xbuf);
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
   for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
@@ -864,6 +999,9 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   CTX_TRY(hipMalloc(&c->tiebits, (div_up(N, 64) + 2) * 8));
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
+  CTX_TRY(hipMalloc(&c->d_parthist, PART_BINS * 4));
+  CTX_TRY(hipMalloc(&c->d_owner, PART_BINS));
+  c->numparts = 1;
   for (auto &e : c->ev) CTX_TRY(hipEventCreate(&e));
   for (auto &e : c->ev_scatter) CTX_TRY(hipEventCreate(&e));
   return c;
@@ -872,11 +1010,22 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
 extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
                                   uint32_t numparts) {
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
-  if (numparts != 1 || part != 0) {
-    gtamd_set_error("part builds (%u of %u) are not implemented yet", part,
-                    numparts);
+  if (numparts == 0 || numparts > 255 || part >= numparts) {
+    gtamd_set_error("invalid part %u of %u (1..255 parts)", part, numparts);
     return -1;
   }
+  c->part = part;
+  c->numparts = numparts;
+  c->ran = false;
+  return 0;
+}
+
+extern "C" int gtamd_esa_set_comm(gtamd_esa_ctx *c, gtamd_allgather_fn ag,
+                                  gtamd_alltoallv_fn a2a, void *user) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  c->comm_allgather = ag;
+  c->comm_alltoallv = a2a;
+  c->comm_user = user;
   return 0;
 }
 
@@ -959,7 +1108,8 @@ extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
 static int ensure_arena(gtamd_esa_ctx *c, u64 bytes) {
   if (bytes <= c->arena_bytes) return 0;
   HIP_TRY(hipStreamSynchronize(c->st));
-  free_dev(c->arena);
+  free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
+  free_dev(c->xbuf);
   c->arena = nullptr;
   c->arena_bytes = 0;
   bytes += bytes / 8 + (1 << 20);
@@ -987,9 +1137,94 @@ static int bits_for(u64 maxvalue) {
   return b;
 }
 
+static int ensure_xbuf(gtamd_esa_ctx *c, u64 words) {
+  if (words <= c->xbuf_words) return 0;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  free_dev(c->xbuf);
+  c->xbuf = nullptr;
+  c->xbuf_words = 0;
+  words += words / 4 + 4096;
+  HIP_TRY(hipMalloc(&c->xbuf, words * 4));
+  c->xbuf_words = words;
+  return 0;
+}
+
+// host-side collectives of a part build go through the caller's callbacks
+static int comm_allgather(gtamd_esa_ctx *c, const void *send, void *recv,
+                          u32 bytes) {
+  if (c->comm_allgather(c->comm_user, send, recv, bytes) != 0) {
+    gtamd_set_error("allgather callback failed");
+    return -1;
+  }
+  return 0;
+}
+
+// k2[j] = rank of suffix upos[j] + h, looked up at the part that owns that
+// suffix: queries are bucketed by owner (one radix pass), exchanged with
+// alltoallv, answered from the owner's rank table, and sent back.
+template <int BITS>
+static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
+                          const u32 *rank, u32 *k2, u64 *dkey_a, u32 *dval_a,
+                          u64 *dkey_b, u32 *dval_b, u32 *sendq, u32 *rws2) {
+  hipStream_t st = c->st;
+  const u32 R = c->numparts;
+  u32 *d_counts = c->d_parthist;   // idle after the split: reuse 256 counters
+  HIP_TRY(hipMemsetAsync(d_counts, 0, 256 * 4, st));
+  if (m > 0) {
+    k_query_dest<BITS><<<(u32) div_up(m, 256), 256, 0, st>>>(
+        c->text, upos, m, h, c->d_owner, dkey_a, dval_a, d_counts);
+    HIP_TRY(hipGetLastError());
+  }
+  u32 h_counts[256];
+  HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 256 * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::vector<u64> sendcounts(R), matrix((size_t) R * R), recvcounts(R);
+  for (u32 r = 0; r < R; r++) sendcounts[r] = h_counts[r];
+  TRY(comm_allgather(c, sendcounts.data(), matrix.data(), R * 8));
+  u64 nrecv = 0;
+  for (u32 r = 0; r < R; r++) {
+    recvcounts[r] = matrix[(size_t) r * R + c->part];
+    nrecv += recvcounts[r];
+  }
+  const u32 *order = dval_a;
+  if (m > 0) {
+    const int shift0 = 0, width8 = 8;
+    TRY(radix_sort_pairs<u32>(dkey_a, dval_a, dkey_b, dval_b, m, &shift0,
+                              &width8, 1, rws2, st, nullptr, nullptr));
+    order = dval_b;
+    k_query_fill<<<(u32) div_up(m, 256), 256, 0, st>>>(upos, order, m, h, c->n, sendq);
+    HIP_TRY(hipGetLastError());
+  }
+  TRY(ensure_xbuf(c, 2 * nrecv + m + 64));
+  u32 *recvq = c->xbuf, *ans = c->xbuf + nrecv + 16, *recvans = ans + nrecv + 16;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (c->comm_alltoallv(c->comm_user, sendq, sendcounts.data(), recvq,
+                        recvcounts.data(), 4) != 0) {
+    gtamd_set_error("alltoallv callback failed (queries)");
+    return -1;
+  }
+  if (nrecv > 0) {
+    k_answer<<<(u32) div_up(nrecv, 256), 256, 0, st>>>(recvq, nrecv, rank, ans);
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (c->comm_alltoallv(c->comm_user, ans, recvcounts.data(), recvans,
+                        sendcounts.data(), 4) != 0) {
+    gtamd_set_error("alltoallv callback failed (answers)");
+    return -1;
+  }
+  if (m > 0) {
+    k_k2_scatter<<<(u32) div_up(m, 256), 256, 0, st>>>(recvans, order, m, k2);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
 template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   using K = Key<BITS>;
   const u64 N = c->N, n = c->n;
+  const u32 R = c->numparts;
+  const bool parts = R > 1;
   hipStream_t st = c->st;
   const bool want_suf = want & GTAMD_WANT_SUF, want_lcp = want & GTAMD_WANT_LCP,
              want_bwt = want & GTAMD_WANT_BWT;
@@ -1001,18 +1236,71 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
                     K::SYMS);
     return -1;
   }
+  if (parts && (c->comm_allgather == nullptr || c->comm_alltoallv == nullptr)) {
+    gtamd_set_error("a part build needs the collective callbacks "
+                    "(gtamd_esa_set_comm)");
+    return -1;
+  }
   memset(&c->timing, 0, sizeof c->timing);
   memset(&c->stats, 0, sizeof c->stats);
   c->llv_pairs = 0;
   HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
   HIP_TRY(hipEventRecord(c->ev[0], st));
 
-  // keygen
-  k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
-  HIP_TRY(hipGetLastError());
+  // ---- keygen (whole table, or the pairs of this part's key range)
+  u64 NL = N, index_offset = 0;
+  if (!parts) {
+    k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+    HIP_TRY(hipGetLastError());
+  } else {
+    // split points from the histogram of the leading key bits; every part
+    // computes the same histogram from the replicated text
+    HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
+    k_key_hist<BITS><<<2048, 256, 0, st>>>(c->text, N, c->d_parthist);
+    HIP_TRY(hipGetLastError());
+    std::vector<u32> hist(PART_BINS);
+    HIP_TRY(hipMemcpyAsync(hist.data(), c->d_parthist, PART_BINS * 4,
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<u64> start(PART_BINS + 1);
+    start[0] = 0;
+    for (int b = 0; b < PART_BINS; b++) start[b + 1] = start[b] + hist[b];
+    if (start[PART_BINS] != N) {
+      gtamd_set_error("key histogram counts %llu suffixes, expected %llu",
+                      (unsigned long long) start[PART_BINS], (unsigned long long) N);
+      return -1;
+    }
+    std::vector<u32> cut(R + 1);
+    std::vector<u8> owner(PART_BINS);
+    cut[0] = 0;
+    cut[R] = PART_BINS;
+    for (u32 r = 1; r < R; r++) {
+      const u64 target = (u64) (((unsigned __int128) N * r) / R);
+      u32 b = cut[r - 1];
+      while (b < (u32) PART_BINS && start[b] < target) b++;
+      cut[r] = b;
+    }
+    for (u32 r = 0; r < R; r++)
+      for (u32 b = cut[r]; b < cut[r + 1]; b++) owner[b] = (u8) r;
+    HIP_TRY(hipMemcpyAsync(c->d_owner, owner.data(), PART_BINS,
+                           hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const u32 lo = cut[c->part], hi = cut[c->part + 1];
+    index_offset = start[lo];
+    NL = start[hi] - start[lo];
+    const u64 nblk = div_up(N, 1024);
+    u32 *cnt = c->rws, *off = cnt + nblk + 16, *sws = off + nblk + 16;
+    k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, cnt);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, cnt, off, nblk, false, sws, st));
+    k_part_emit<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, off, c->k0, c->v0);
+    HIP_TRY(hipGetLastError());
+  }
+  c->NL = NL;
+  c->index_offset = index_offset;
   HIP_TRY(hipEventRecord(c->ev[1], st));
 
-  // first sort: all key bits above the payload
+  // ---- first sort: all key bits above the payload
   int shifts[16], widths[16], np = 0;
   for (int b = KeyLayout<BITS>::PAYLOAD_BITS; b < 64; b += 8) {
     shifts[np] = b;
@@ -1020,47 +1308,69 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     np++;
   }
   int nev = 0;
-  TRY(radix_sort_pairs<u32>(c->k0, c->v0, c->k1, c->v1, N, shifts, widths, np,
+  TRY(radix_sort_pairs<u32>(c->k0, c->v0, c->k1, c->v1, NL, shifts, widths, np,
                             c->rws, st, c->ev_scatter, &nev));
   u64 *skey = (np & 1) ? c->k1 : c->k0;   // sorted keys
   u32 *sa32 = (np & 1) ? c->v1 : c->v0;   // positions in suffix order
-  u64 *fkey = (np & 1) ? c->k0 : c->k1;   // free key-sized buffer
   u32 *rank = (np & 1) ? c->v0 : c->v1;   // free value-sized buffer
   HIP_TRY(hipEventRecord(c->ev[2], st));
 
-  // finalize
-  k_finalize<BITS><<<(u32) div_up(N, FIN_TILE), FIN_THREADS, 0, st>>>(
-      skey, sa32, N, prefixlength, want_suf ? c->suf : nullptr,
-      want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, c->tiebits,
-      c->d_stats);
-  HIP_TRY(hipGetLastError());
+  // ---- finalize; a part needs the last key of the preceding range
+  u64 prev_key = 0;
+  int has_prev = 0;
+  if (parts) {
+    u64 mine[2] = {NL, 0};
+    if (NL > 0)
+      HIP_TRY(hipMemcpyAsync(&mine[1], skey + (NL - 1), 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<u64> all(2 * (size_t) R);
+    TRY(comm_allgather(c, mine, all.data(), 16));
+    for (u32 r = 0; r < c->part; r++)
+      if (all[2 * r] > 0) { prev_key = all[2 * r + 1]; has_prev = 1; }
+  }
+  if (NL > 0) {
+    k_finalize<BITS><<<(u32) div_up(NL, FIN_TILE), FIN_THREADS, 0, st>>>(
+        skey, sa32, NL, prefixlength, want_suf ? c->suf : nullptr,
+        want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, c->tiebits,
+        c->d_stats, prev_key, has_prev, index_offset);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(c->ev[3], st));
   TRY(fetch_stats(c));
   const u64 numties = c->h_stats->numties;
+  u64 anyties = numties;
+  if (parts) {
+    std::vector<u64> all(R);
+    TRY(comm_allgather(c, &numties, all.data(), 8));
+    anyties = 0;
+    for (u32 r = 0; r < R; r++) anyties += all[r];
+  }
   u32 rounds = 0;
   u64 m0 = 0;
   HIP_TRY(hipEventRecord(c->ev[4], st));
   HIP_TRY(hipEventRecord(c->ev[5], st));
-  if (numties > 0) {
+  if (anyties > 0) {
     // ---- unresolved list and group heads
-    const u64 nwords = div_up(N, 64);
+    const u64 nwords = div_up(NL, 64);
     u32 *cntw = c->rws;                    // radix workspace is idle now
     u32 *headw = cntw + nwords + 16;
     u32 *offw = headw + nwords + 16;
     u32 *carry = offw + nwords + 16;
     u32 *scanws = carry + nwords + 16;
-    k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(c->tiebits, nwords,
-                                                          cntw, headw);
-    HIP_TRY(hipGetLastError());
-    TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
-    TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
+    if (NL > 0) {
+      k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(c->tiebits, nwords,
+                                                            cntw, headw);
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
+      TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
+    }
     k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
     HIP_TRY(hipGetLastError());
     TRY(fetch_stats(c));
     m0 = c->h_stats->count;
     // arena layout (u32 units unless noted)
     const u64 mp = m0 + 64;
-    const u64 need = mp * 4 * 17 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
+    const u64 need = mp * 4 * 18 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
                      scan_workspace_words(m0) * 4 + 4096;
     TRY(ensure_arena(c, need));
     u32 *a32 = reinterpret_cast<u32 *>(c->arena);
@@ -1083,14 +1393,21 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     u32 *flg = a32; a32 += mp;     // deferred to the global path
     u32 *foff = a32; a32 += mp;
     u32 *fj = a32; a32 += mp;
+    u32 *sendq = a32; a32 += mp;   // part builds: rank queries
     u32 *rws2 = a32;               // radix + scan workspace for the rounds
     u32 *scanws2 = rws2 + radix_workspace_words(m0);
-    k_unres_emit<<<(u32) div_up(nwords, 256), 256, 0, st>>>(
-        c->tiebits, nwords, offw, carry, sa32, uidx0, uidx, upos, ugrp);
-    HIP_TRY(hipGetLastError());
-    k_rank_init<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->tiebits, carry, sa32,
-                                                      N, rank);
-    HIP_TRY(hipGetLastError());
+    if (m0 > 0) {
+      k_unres_emit<<<(u32) div_up(nwords, 256), 256, 0, st>>>(
+          c->tiebits, nwords, offw, carry, sa32, uidx0, uidx, upos, ugrp);
+      HIP_TRY(hipGetLastError());
+    }
+    // rank table: global ranks of this part's suffixes (all of them when
+    // there is one part); other parts' entries are never read here
+    if (NL > 0) {
+      k_rank_init<<<(u32) div_up(NL, 1024), 256, 0, st>>>(
+          c->tiebits, carry, sa32, NL, (u32) index_offset, rank);
+      HIP_TRY(hipGetLastError());
+    }
     // ---- doubling rounds
     const int nb = bits_for(N - 1);
     int cs[16], cw[16], cnp = 0;
@@ -1101,14 +1418,28 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         cnp++;
       }
     u64 m = m0, h = (u64) K::SYMS;
-    while (m > 0) {
+    for (;;) {
+      u64 active = m;
+      if (parts) {
+        std::vector<u64> all(R);
+        TRY(comm_allgather(c, &m, all.data(), 8));
+        active = 0;
+        for (u32 r = 0; r < R; r++) active += all[r];
+      }
+      if (active == 0) break;
       if (++rounds > 64) {
         gtamd_set_error("prefix doubling did not converge after 64 rounds");
         return -1;
       }
       const u32 g = (u32) div_up(m, 256);
-      k_round_gather<<<g, 256, 0, st>>>(upos, m, h, n, rank, k2);
-      HIP_TRY(hipGetLastError());
+      if (parts) {
+        TRY(exchange_ranks<BITS>(c, upos, m, h, rank, k2, ckey_a, cval_a, ckey_b,
+                                 cval_b, sendq, rws2));
+      } else {
+        k_round_gather<<<g, 256, 0, st>>>(upos, m, h, n, rank, k2);
+        HIP_TRY(hipGetLastError());
+      }
+      if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
       HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
       k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(
           uidx, upos, ugrp, k2, m, cvo, hv, flg, c->d_stats);
@@ -1133,7 +1464,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         HIP_TRY(hipGetLastError());
       }
       const u32 *cv = cvo;
-      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, ugrp, m, sa32, rank, keep);
+      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, ugrp, m, (u32) index_offset,
+                                       sa32, rank, keep);
       HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, keep, koff, m, false, scanws2, st));
       k_round_compact<<<g, 256, 0, st>>>(keep, koff, uidx, cv, hv, m, uidx2,
@@ -1151,11 +1483,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     // ---- final entries of the tied suffixes
     u32 *lcpu = hv, *large = keep, *loff = koff, *tied = cval_b;
     const u32 g0 = (u32) div_up(m0, 256);
-    k_fix_basic<BITS><<<g0, 256, 0, st>>>(
-        c->text, uidx0, m0, c->tiebits, sa32, want_suf ? c->suf : nullptr,
-        want_bwt ? c->bwt : nullptr, tied, lcpu, c->d_stats);
-    HIP_TRY(hipGetLastError());
-    if (want_lcp) {
+    if (m0 > 0) {
+      k_fix_basic<BITS><<<g0, 256, 0, st>>>(
+          c->text, uidx0, m0, c->tiebits, sa32, want_suf ? c->suf : nullptr,
+          want_bwt ? c->bwt : nullptr, tied, lcpu, c->d_stats, index_offset);
+      HIP_TRY(hipGetLastError());
+    }
+    if (want_lcp && m0 > 0) {
       // entries tied with their predecessor, sorted by text position
       TRY(scan_u32(SCAN_SUM, tied, loff, m0, false, scanws2, st));
       k_total<<<1, 1, 0, st>>>(loff, tied, m0, c->d_stats);
@@ -1193,7 +1527,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         c->llv_cap = pairs + pairs / 4 + 1024;
       }
       if (pairs > 0) {
-        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, lcpu, large, loff, m0, 0, c->llv);
+        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, lcpu, large, loff, m0,
+                                       index_offset, c->llv);
         HIP_TRY(hipGetLastError());
       }
       c->llv_pairs = pairs;
@@ -1201,9 +1536,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   }
   HIP_TRY(hipEventRecord(c->ev[6], st));
   TRY(fetch_stats(c));
-  (void) fkey;
 
-  // results
+  // results (of this part; the caller combines parts: sums, max, and the one
+  // part that holds suffix 0 reports `longest`)
   c->stats.totallength = n;
   c->stats.numberofallsortedsuffixes = N;
   c->stats.longest = c->h_stats->longest;
@@ -1227,7 +1562,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   }
   c->timing.scatter_ms = sc;
   c->timing.scatter_launches = (u32) nev;
-  c->timing.scatter_items = N;
+  c->timing.scatter_items = NL;
   c->want = want;
   c->ran = true;
   return 0;
@@ -1247,11 +1582,10 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
 extern "C" uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *c,
                                             gtamd_table which) {
   if (c == nullptr || !c->ran) return 0;
-  return which == GTAMD_TAB_LLV ? c->llv_pairs : c->N;
+  return which == GTAMD_TAB_LLV ? c->llv_pairs : c->NL;
 }
 extern "C" uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *c) {
-  (void) c;
-  return 0;
+  return (c == nullptr || !c->ran) ? 0 : c->index_offset;
 }
 extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
                                               gtamd_table which) {

@@ -1,0 +1,131 @@
+"""Sharding the ESA build over the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
+in the CPU tests).  The suffix array is cut into `world` lexicographic ranges
+of (almost) equal size -- the reference's `-parts` mechanism
+(src/match/sfx-partssuf.c:172-347) -- and rank r builds slice r of every table
+from the replicated packed sequence.  The only data-path exchange is the rank
+lookup of the prefix-doubling rounds: "what is the rank of suffix p+h" is asked
+of the part that owns that suffix (alltoallv of 4-byte queries, alltoallv of
+4-byte answers), plus a few 8/16-byte allgathers (slice border keys, round
+termination).  The engine calls back into `TorchComm` for these collectives;
+it never sees a torch type.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_uint32)
+ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+
+
+class _DevMem:
+    """expose raw device memory to torch without copying"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1",
+                                         "data": (ptr, False), "version": 2}
+
+
+def _device_bytes(ptr, nbytes, device):
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+
+
+def _host_bytes(ptr, nbytes):
+    buf = (ctypes.c_uint8 * nbytes).from_address(ptr)
+    return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+
+
+class TorchComm:
+    """the two collectives of include/gtamd_esa.h on a torch process group.
+
+    `device` is the torch device the engine's buffers live on ("cuda:k"), or
+    "cpu" when the buffers are host memory (gloo tests)."""
+
+    def __init__(self, device, group=None):
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bytes_exchanged = 0
+        self.calls = 0
+        # keep the ctypes thunks alive as long as the object lives
+        self.allgather_cb = ALLGATHER_FN(self._allgather)
+        self.alltoallv_cb = ALLTOALLV_FN(self._alltoallv)
+
+    # host memory in, host memory out
+    def _allgather(self, user, send, recv, nbytes):
+        try:
+            mine = _host_bytes(send, nbytes)
+            out = _host_bytes(recv, nbytes * self.world)
+            if self.device.type == "cpu":
+                self._gloo_allgather(out, mine)
+            else:
+                d_in = mine.to(self.device)
+                d_out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device)
+                dist.all_gather_into_tensor(d_out, d_in, group=self.group)
+                out.copy_(d_out.cpu())
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("allgather callback failed:", repr(e), flush=True)
+            return -1
+
+    def _gloo_allgather(self, out, mine):
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine.clone(), group=self.group)
+        out.copy_(torch.cat(parts))
+
+    # device memory in, device memory out
+    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem):
+        try:
+            sc = [int(sendcounts[r]) * elem for r in range(self.world)]
+            rc = [int(recvcounts[r]) * elem for r in range(self.world)]
+            if self.device.type == "cpu":
+                t_in = _host_bytes(send, sum(sc)) if sum(sc) else torch.empty(0, dtype=torch.uint8)
+                t_out = _host_bytes(recv, sum(rc)) if sum(rc) else torch.empty(0, dtype=torch.uint8)
+                outs = list(t_out.split(rc)) if sum(rc) else [torch.empty(0, dtype=torch.uint8) for _ in rc]
+                ins = [x.clone() for x in t_in.split(sc)] if sum(sc) else [torch.empty(0, dtype=torch.uint8) for _ in sc]
+                tmp = [torch.empty(n, dtype=torch.uint8) for n in rc]
+                dist.all_to_all(tmp, ins, group=self.group)
+                for o, t in zip(outs, tmp):
+                    o.copy_(t)
+            else:
+                t_in = _device_bytes(send, sum(sc), self.device)
+                t_out = _device_bytes(recv, sum(rc), self.device)
+                dist.all_to_all_single(t_out, t_in, output_split_sizes=rc,
+                                       input_split_sizes=sc, group=self.group)
+                torch.cuda.synchronize(self.device)
+            self.bytes_exchanged += sum(sc)
+            self.calls += 1
+            return 0
+        except Exception as e:
+            print("alltoallv callback failed:", repr(e), flush=True)
+            return -1
+
+    def attach(self, engine):
+        """make `engine` (genometools_amd.esa.EsaEngine) build part `rank` of
+        `world` with this object as the transport"""
+        engine.set_part(self.rank, self.world, self)
+
+
+def combine_stats(stats, device, group=None):
+    """whole-table statistics from the per-part ones (see gtamd_esa_set_part)"""
+    dev = torch.device(device)
+    s = torch.tensor([stats["lcptabsum"], stats["largelcpvalues"], stats["longest"],
+                      stats["tied_suffixes"]], dtype=torch.int64, device=dev)
+    m = torch.tensor([stats["maxbranchdepth"], stats["refine_rounds"]],
+                     dtype=torch.int64, device=dev)
+    dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    out = dict(stats)
+    out["lcptabsum"], out["largelcpvalues"], out["longest"], out["tied_suffixes"] = \
+        [int(x) for x in s.tolist()]
+    out["maxbranchdepth"], out["refine_rounds"] = [int(x) for x in m.tolist()]
+    return out

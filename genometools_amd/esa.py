@@ -83,6 +83,20 @@ class EsaEngine:
         check(self._lib.gtamd_esa_set_sequence_bytes(self._ctx, ptr, n, 1))
         self.n = int(n)
 
+    # -- sharding -----------------------------------------------------------
+    def set_part(self, part, numparts, comm=None):
+        """build slice `part` of `numparts` lexicographic ranges; `comm` is a
+        genometools_amd.dist.TorchComm (kept alive by the engine)"""
+        check(self._lib.gtamd_esa_set_part(self._ctx, part, numparts))
+        self._comm = comm
+        if comm is not None:
+            check(self._lib.gtamd_esa_set_comm(
+                self._ctx, ctypes.cast(comm.allgather_cb, ctypes.c_void_p),
+                ctypes.cast(comm.alltoallv_cb, ctypes.c_void_p), None))
+
+    def table_offset(self):
+        return int(self._lib.gtamd_esa_table_offset(self._ctx))
+
     # -- hot path ---------------------------------------------------------
     def run(self, want=WANT_SUF | WANT_LCP | WANT_BWT):
         check(self._lib.gtamd_esa_run(self._ctx, want))

@@ -105,8 +105,30 @@ void gtamd_esa_destroy(gtamd_esa_ctx *ctx);
 /* Restrict the build to the part `part` of `numparts` equal-width (by suffix
    count) lexicographic ranges, the reference's -parts mechanism
    (src/match/sfx-partssuf.c:172-347) used here to shard over GPUs.
-   Default 0 of 1. */
+   Default 0 of 1.  Every part holds the whole sequence, builds the slice
+   [table_offset, table_offset + table_entries) of each table, and looks up
+   the ranks of other parts' suffixes through the callbacks of
+   gtamd_esa_set_comm during prefix doubling.  The statistics of a part cover
+   its slice: the caller adds lcptabsum / largelcpvalues, takes the max of
+   maxbranchdepth, and `longest` from the part whose slice holds suffix 0
+   (the others report 0). */
 int gtamd_esa_set_part(gtamd_esa_ctx *ctx, uint32_t part, uint32_t numparts);
+
+/* Collectives a part build needs; the caller supplies the transport (RCCL
+   through torch.distributed in bench.py).  Both return 0 on success.
+   allgather: every part contributes `bytes` bytes of HOST memory, `recv`
+   (host) receives numparts x bytes in part order.
+   alltoallv: DEVICE buffers of `elem_bytes`-sized elements; the block for part
+   r has sendcounts[r] elements, blocks are laid out in part order on both
+   sides; recvcounts is known to the engine (it allgathers the count matrix). */
+typedef int (*gtamd_allgather_fn)(void *user, const void *send, void *recv,
+                                  uint32_t bytes);
+typedef int (*gtamd_alltoallv_fn)(void *user, const void *send,
+                                  const uint64_t *sendcounts, void *recv,
+                                  const uint64_t *recvcounts,
+                                  uint32_t elem_bytes);
+int gtamd_esa_set_comm(gtamd_esa_ctx *ctx, gtamd_allgather_fn allgather,
+                       gtamd_alltoallv_fn alltoallv, void *user);
 
 /* Prefix length to report in .prj and to mask averagelcp with (option -pl K of
    src/match/index_options.c:363; 0 = gt_recommendedprefixlength).  The device

@@ -1,0 +1,115 @@
+"""In-process stand-in for the collectives of a part build: R engine contexts
+on ONE device, one Python thread each (ctypes releases the GIL while the engine
+runs), exchanging through shared state, barriers and device-to-device copies.
+Lets the sharded path be checked on a single-GPU box.  Test infrastructure."""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+
+from genometools_amd.dist import ALLGATHER_FN, ALLTOALLV_FN, _DevMem
+
+
+class _View:
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+        self.allgather_cb = ALLGATHER_FN(self._allgather)
+        self.alltoallv_cb = ALLTOALLV_FN(self._alltoallv)
+        self.bytes_exchanged = 0
+
+    def _allgather(self, user, send, recv, nbytes):
+        try:
+            sh = self.shared
+            sh.slots[self.rank] = bytes((ctypes.c_uint8 * nbytes).from_address(send))
+            sh.barrier.wait()
+            ctypes.memmove(recv, b"".join(sh.slots), nbytes * self.world)
+            sh.barrier.wait()
+            return 0
+        except Exception as e:
+            print("thread allgather failed", repr(e), flush=True)
+            return -1
+
+    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem):
+        try:
+            sh = self.shared
+            sc = [int(sendcounts[r]) * elem for r in range(self.world)]
+            rc = [int(recvcounts[r]) * elem for r in range(self.world)]
+            sh.slots[self.rank] = (send, sc)
+            sh.barrier.wait()
+            dev = torch.device("cuda", sh.device)
+            out_off = 0
+            for src in range(self.world):
+                sptr, ssc = sh.slots[src]
+                nb = ssc[self.rank]
+                assert nb == rc[src], "count matrix mismatch"
+                if nb:
+                    s_off = sum(ssc[:self.rank])
+                    s_t = torch.as_tensor(_DevMem(sptr + s_off, nb), device=dev)
+                    d_t = torch.as_tensor(_DevMem(recv + out_off, nb), device=dev)
+                    d_t.copy_(s_t)
+                out_off += nb
+            torch.cuda.synchronize(dev)
+            self.bytes_exchanged += sum(sc)
+            sh.barrier.wait()
+            return 0
+        except Exception as e:
+            print("thread alltoallv failed", repr(e), flush=True)
+            sh.barrier.abort()
+            return -1
+
+
+class ThreadComm:
+    def __init__(self, world, device=0):
+        self.world, self.device = world, device
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def view(self, rank):
+        return _View(self, rank)
+
+
+def build_in_parts(enc, sigma, parts, want=7, device=0):
+    """run `parts` engines concurrently; return the assembled tables and the
+    combined statistics"""
+    from genometools_amd import esa
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    shared = ThreadComm(parts, device)
+    results, errors = [None] * parts, []
+
+    def worker(r):
+        try:
+            with esa.EsaEngine(max(enc.size, 1), sigma, device) as eng:
+                eng.set_sequence(enc)
+                eng.set_part(r, parts, shared.view(r))
+                eng.run(want)
+                results[r] = (eng.table_offset(), eng.result())
+        except Exception as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(parts)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    out = {"suf": [], "lcp": [], "bwt": [], "llv": []}
+    stats = {"lcptabsum": 0, "largelcpvalues": 0, "longest": 0, "maxbranchdepth": 0,
+             "tied_suffixes": 0, "refine_rounds": 0}
+    expect = 0
+    for off, res in results:
+        assert off == expect, "slices must tile the table"
+        expect += len(res.suf) if res.suf is not None else len(res.bwt)
+        for k in out:
+            v = getattr(res, k)
+            if v is not None:
+                out[k].append(v)
+        for k in ("lcptabsum", "largelcpvalues", "longest", "tied_suffixes"):
+            stats[k] += res.stats[k]
+        for k in ("maxbranchdepth", "refine_rounds"):
+            stats[k] = max(stats[k], res.stats[k])
+        stats["prefixlength"] = res.stats["prefixlength"]
+    assert expect == enc.size + 1
+    tabs = {k: (np.concatenate(v) if v else None) for k, v in out.items()}
+    return tabs, stats, [r[1].stats for r in results]

@@ -1108,8 +1108,7 @@ extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
 static int ensure_arena(gtamd_esa_ctx *c, u64 bytes) {
   if (bytes <= c->arena_bytes) return 0;
   HIP_TRY(hipStreamSynchronize(c->st));
-  free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
-  free_dev(c->xbuf);
+  free_dev(c->arena);
   c->arena = nullptr;
   c->arena_bytes = 0;
   bytes += bytes / 8 + (1 << 20);

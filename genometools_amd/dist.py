@@ -92,8 +92,19 @@ class TorchComm:
                 t_out = _host_bytes(recv, sum(rc)) if sum(rc) else torch.empty(0, dtype=torch.uint8)
                 outs = list(t_out.split(rc)) if sum(rc) else [torch.empty(0, dtype=torch.uint8) for _ in rc]
                 ins = [x.clone() for x in t_in.split(sc)] if sum(sc) else [torch.empty(0, dtype=torch.uint8) for _ in sc]
+                # gloo has no alltoall: pairwise non-blocking send/recv
                 tmp = [torch.empty(n, dtype=torch.uint8) for n in rc]
-                dist.all_to_all(tmp, ins, group=self.group)
+                reqs = []
+                for r in range(self.world):
+                    if r == self.rank:
+                        tmp[r].copy_(ins[r])
+                        continue
+                    if rc[r]:
+                        reqs.append(dist.irecv(tmp[r], src=r, group=self.group))
+                    if sc[r]:
+                        reqs.append(dist.isend(ins[r], dst=r, group=self.group))
+                for q in reqs:
+                    q.wait()
                 for o, t in zip(outs, tmp):
                     o.copy_(t)
             else:

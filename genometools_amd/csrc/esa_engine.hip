@@ -143,9 +143,11 @@ template <int BITS> struct Key {
 // packed text word by word, stop at the first special on either side
 // (specials never match: src/core/encseq.c:6449-6530, sfx-linlcp.c:93,162)
 template <int BITS>
-__device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l) {
+__device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l,
+                          u64 cap = ~0ull) {
   constexpr int S = Sym<BITS>::WIN;
   for (;;) {
+    if (l >= cap) return l;
     u64 x = Sym<BITS>::window(t, p + l) ^ Sym<BITS>::window(t, q + l);
     if (BITS * S < 64) x &= ~0ull << (64 - BITS * S);
     int m = x ? __clzll((long long) x) / BITS : S;
@@ -377,6 +379,9 @@ struct Stats {          // device-side accumulators
   u32 maxlcp;
   u32 count;                      // generic counter (compaction totals)
   u32 count2;                     // second counter (deferred elements)
+  u32 dmax;                       // direct tie path: max lcp
+  unsigned long long dsum;        // direct tie path: lcp sum
+  u32 dfallback;                  // direct tie path gave up on some group
   u32 pad;
 };
 
@@ -764,6 +769,63 @@ __global__ __launch_bounds__(256) void k_round_compact(
 __global__ void k_total(const u32 *__restrict__ off, const u32 *__restrict__ cnt,
                         u64 n, Stats *stats) {
   stats->count = n ? off[n - 1] + cnt[n - 1] : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// few, shallow ties (random coincidences on non-repetitive input): resolve
+// each tie group by comparing the suffixes on the packed text directly, no
+// rank table needed.  Gives up (dfallback) on big groups or deep matches.
+// ---------------------------------------------------------------------------
+constexpr int DIRECT_MAX_GROUP = 16;
+constexpr u64 DIRECT_MAX_LCP = 250;   // below LCPOVERFLOW: never an .llv entry
+
+template <int BITS>
+__device__ bool suffix_less(const Text &t, u64 p, u64 q, bool *deep) {
+  const u64 l = lcp_extend<BITS>(t, p, q, (u64) Key<BITS>::SYMS, DIRECT_MAX_LCP);
+  if (l >= DIRECT_MAX_LCP) { *deep = true; return p < q; }
+  const bool sp = is_special(t, p + l), sq = is_special(t, q + l);
+  if (sp || sq) return (sp && sq) ? p < q : sq;   // a special is the larger one
+  return Sym<BITS>::at(t, p + l) < Sym<BITS>::at(t, q + l);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void k_direct_ties(
+    Text t, const u32 *__restrict__ uidx0, const u32 *__restrict__ ugrp, u64 m0,
+    u32 *__restrict__ sa32, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    u8 *__restrict__ bwt, bool want_lcp, u64 index_offset, Stats *stats) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m0) return;
+  const u32 i0 = uidx0[j];
+  if (ugrp[j] != i0) return;          // one thread per group, at its head
+  int g = 1;
+  while (j + g < m0 && ugrp[j + g] == i0 && g <= DIRECT_MAX_GROUP) g++;
+  if (g > DIRECT_MAX_GROUP) { stats->dfallback = 1; return; }
+  u32 pos[DIRECT_MAX_GROUP];
+  bool deep = false;
+  for (int k = 0; k < g; k++) {       // insertion sort
+    const u32 p = sa32[i0 + k];
+    int a = k;
+    while (a > 0 && suffix_less<BITS>(t, p, pos[a - 1], &deep)) {
+      pos[a] = pos[a - 1];
+      a--;
+    }
+    pos[a] = p;
+  }
+  if (deep) { stats->dfallback = 1; return; }
+  for (int k = 0; k < g; k++) {
+    const u64 i = (u64) i0 + k;
+    const u64 p = pos[k];
+    sa32[i] = (u32) p;
+    if (suf != nullptr) suf[i] = p;
+    if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
+    if (p == 0) stats->longest = index_offset + i;
+    if (k > 0 && want_lcp) {
+      const u32 l = (u32) lcp_extend<BITS>(t, pos[k - 1], p, (u64) Key<BITS>::SYMS);
+      if (lcp != nullptr) lcp[i] = (u8) l;
+      atomicAdd(&stats->dsum, (unsigned long long) l);
+      atomicMax(&stats->dmax, l);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1301,10 +1363,19 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
 
   // ---- first sort: all key bits above the payload
   int shifts[16], widths[16], np = 0;
-  for (int b = KeyLayout<BITS>::PAYLOAD_BITS; b < 64; b += 8) {
-    shifts[np] = b;
-    widths[np] = 64 - b < 8 ? 64 - b : 8;
-    np++;
+  {
+    const int lo0 = KeyLayout<BITS>::PAYLOAD_BITS,
+              hi0 = lo0 + KeyLayout<BITS>::DCODE_BITS;   // dcode
+    for (int b = lo0; b < hi0; b += 8) {
+      shifts[np] = b;
+      widths[np] = hi0 - b < 8 ? hi0 - b : 8;
+      np++;
+    }
+    for (int b = K::LOW_BITS; b < 64; b += 8) {          // symbol prefix
+      shifts[np] = b;
+      widths[np] = 64 - b < 8 ? 64 - b : 8;
+      np++;
+    }
   }
   int nev = 0;
   TRY(radix_sort_pairs<u32>(c->k0, c->v0, c->k1, c->v1, NL, shifts, widths, np,
@@ -1400,6 +1471,41 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
           c->tiebits, nwords, offw, carry, sa32, uidx0, uidx, upos, ugrp);
       HIP_TRY(hipGetLastError());
     }
+    // few shallow ties: settle them by direct comparison, no rank table
+    bool settled = false;
+    {
+      const u64 thresh = NL / 512 > 4096 ? NL / 512 : 4096;
+      u64 small = m0 <= thresh;
+      if (parts) {
+        std::vector<u64> all(R);
+        TRY(comm_allgather(c, &small, all.data(), 8));
+        for (u32 r = 0; r < R; r++) small &= all[r];
+      }
+      if (small) {
+        if (m0 > 0) {
+          k_direct_ties<BITS><<<(u32) div_up(m0, 256), 256, 0, st>>>(
+              c->text, uidx0, ugrp, m0, sa32, want_suf ? c->suf : nullptr,
+              want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, want_lcp,
+              index_offset, c->d_stats);
+          HIP_TRY(hipGetLastError());
+        }
+        TRY(fetch_stats(c));
+        u64 gaveup = c->h_stats->dfallback;
+        if (parts) {
+          std::vector<u64> all(R);
+          TRY(comm_allgather(c, &gaveup, all.data(), 8));
+          gaveup = 0;
+          for (u32 r = 0; r < R; r++) gaveup |= all[r];
+        }
+        settled = gaveup == 0;
+        if (!settled) {
+          // discard the partial statistics of the direct attempt
+          HIP_TRY(hipMemsetAsync(&c->d_stats->dsum, 0, 8, st));
+          HIP_TRY(hipMemsetAsync(&c->d_stats->dmax, 0, 4, st));
+        }
+      }
+    }
+    if (!settled) {
     // rank table: global ranks of this part's suffixes (all of them when
     // there is one part); other parts' entries are never read here
     if (NL > 0) {
@@ -1532,6 +1638,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       }
       c->llv_pairs = pairs;
     }
+    }  // !settled
   }
   HIP_TRY(hipEventRecord(c->ev[6], st));
   TRY(fetch_stats(c));
@@ -1542,8 +1649,10 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   c->stats.numberofallsortedsuffixes = N;
   c->stats.longest = c->h_stats->longest;
   c->stats.largelcpvalues = want_lcp ? c->h_stats->numlarge : 0;
-  c->stats.maxbranchdepth = want_lcp ? c->h_stats->maxlcp : 0;
-  c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum : 0;
+  c->stats.maxbranchdepth =
+      want_lcp ? (c->h_stats->maxlcp > c->h_stats->dmax ? c->h_stats->maxlcp
+                                                         : c->h_stats->dmax) : 0;
+  c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum + c->h_stats->dsum : 0;
   c->stats.prefixlength = prefixlength;
   c->stats.refine_rounds = rounds;
   c->stats.tied_suffixes = m0;

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--n", type=float, default=3e9, help="symbols per sequence")
     ap.add_argument("--model", type=int, default=synth.MODEL_HUMANLIKE_DNA)
     ap.add_argument("--seed", type=int, default=43)
-    ap.add_argument("--cpu-sample", type=float, default=16e6)
+    ap.add_argument("--cpu-sample", type=float, default=32e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 

@@ -26,9 +26,9 @@ void gtamd_set_error(const char *fmt, ...);
     }                                                                         \
   } while (0)
 
-#define TRY(expr)                                                             \
+#define TRY(...)                                                              \
   do {                                                                        \
-    if ((expr) != 0) return -1;                                               \
+    if ((__VA_ARGS__) != 0) return -1;                                        \
   } while (0)
 
 static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }

@@ -12,14 +12,14 @@ int scan_u32(int op, const u32 *in, u32 *out, u64 n, bool inclusive, u32 *ws,
 
 // workspace (u32 words) for sorting n pairs
 u64 radix_workspace_words(u64 n);
-// Stable LSD radix sort of (key, value) pairs on the digits
+// Stable LSD radix sort of (key, value) pairs (K = u64 or u32 keys) on the digits
 // (key >> shifts[p]) & ((1 << widths[p]) - 1), p = 0..npasses-1 (least
 // significant digit first, widths <= 8).  Ping-pongs between (a) and (b); the
 // result is in (a) if npasses is even, else in (b).  If ev_pairs != NULL, a
 // start/stop event pair is recorded around every scatter launch
 // (ev_pairs[2*i], ev_pairs[2*i+1]) and *n_ev is advanced.
-template <typename V>
-int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
+template <typename K, typename V>
+int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
                      int *n_ev);

@@ -115,8 +115,9 @@ constexpr int RADIX = 256;
 // Per-tile digit histogram.  hist is digit-major: hist[d * ntiles + tile], so
 // that one exclusive scan over the whole array yields every tile's global
 // write base for every digit.
+template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
-    const u64 *__restrict__ keys, u64 n, int shift, u32 mask,
+    const K *__restrict__ keys, u64 n, int shift, u32 mask,
     u32 *__restrict__ hist, u32 ntiles) {
   __shared__ u32 h[RS_WAVES][RADIX];
   const int tid = threadIdx.x, w = tid >> 6;
@@ -168,12 +169,12 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-template <typename V, bool XCD>
+template <typename K, typename V, bool XCD>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
-    const u64 *__restrict__ keys_in, const V *__restrict__ vals_in,
-    u64 *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
+    const K *__restrict__ keys_in, const V *__restrict__ vals_in,
+    K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
     u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles) {
-  __shared__ u64 s_key[RS_TILE];
+  __shared__ K s_key[RS_TILE];
   __shared__ V s_val[RS_TILE];
   __shared__ u32 s_cnt[RS_WAVES][RADIX];   // running counters, then wave prefix
   __shared__ u32 s_dbase[RADIX];           // tile-local start of each digit run
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
     (&s_cnt[0][0])[i] = 0;
 
-  u64 key[RS_ITEMS];
+  K key[RS_ITEMS];
   V val[RS_ITEMS];
   u32 rk[RS_ITEMS];   // rank inside the wave's stream << 8 | digit
 #pragma unroll
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
       key[j] = keys_in[tile_base + e];
       val[j] = vals_in[tile_base + e];
     } else {
-      key[j] = ~0ull;
+      key[j] = (K) ~(K) 0;
       val[j] = 0;
     }
   }
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) j * RS_THREADS + tid;
     if (e < valid) {
-      const u64 k = s_key[e];
+      const K k = s_key[e];
       const u32 d = (u32) (k >> shift) & mask;
       const u32 g = s_obase[d] + e;
       keys_out[g] = k;
@@ -275,8 +276,8 @@ u64 radix_workspace_words(u64 n) {
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
 static bool g_xcd_remap = true;
 
-template <typename V>
-int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
+template <typename K, typename V>
+int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
                      int *n_ev) {
@@ -293,32 +294,35 @@ int radix_sort_pairs(u64 *keys_a, V *vals_a, u64 *keys_b, V *vals_b, u64 n,
   const u32 ntiles = (u32) div_up(n, RS_TILE);
   u32 *hist = ws;
   u32 *scanws = ws + (u64) ntiles * RADIX;
-  u64 *kin = keys_a, *kout = keys_b;
+  K *kin = keys_a, *kout = keys_b;
   V *vin = vals_a, *vout = vals_b;
   for (int p = 0; p < npasses; p++) {
     const u32 mask = (1u << widths[p]) - 1u;
-    k_rs_hist<<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
+    k_rs_hist<K><<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
                                              ntiles);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
     if (g_xcd_remap)
-      k_rs_scatter<V, true><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, true><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     else
-      k_rs_scatter<V, false><<<ntiles, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, false><<<ntiles, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {
       HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));
       (*n_ev)++;
     }
-    u64 *tk = kin; kin = kout; kout = tk;
+    K *tk = kin; kin = kout; kout = tk;
     V *tv = vin; vin = vout; vout = tv;
   }
   return 0;
 }
 
-template int radix_sort_pairs<u32>(u64 *, u32 *, u64 *, u32 *, u64, const int *,
-                                   const int *, int, u32 *, hipStream_t,
-                                   hipEvent_t *, int *);
+template int radix_sort_pairs<u64, u32>(u64 *, u32 *, u64 *, u32 *, u64,
+                                        const int *, const int *, int, u32 *,
+                                        hipStream_t, hipEvent_t *, int *);
+template int radix_sort_pairs<u32, u32>(u32 *, u32 *, u32 *, u32 *, u64,
+                                        const int *, const int *, int, u32 *,
+                                        hipStream_t, hipEvent_t *, int *);

@@ -623,6 +623,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   __shared__ u64 s_key[RT_TILE];
   __shared__ u32 s_grp[RT_TILE + 1];
   __shared__ u32 s_pos[RT_TILE];
+  __shared__ u16 s_start[RT_TILE + 2];   // first slot of each local group
   __shared__ u32 s_scan[4];
   const int tid = threadIdx.x;
   const u64 base = (u64) blockIdx.x * RT_TILE;
@@ -656,32 +657,99 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   u32 tot;
   u32 lg = block_scan_excl_sum(nstart, &tot, s_scan);
   u32 nflag = 0;
+  // does any group of this tile split in this round?  (inside a long repeat
+  // most rounds leave a group as it is: every member's k2 is the same)
+  int splits = 0;
+  u32 kprev = (tid > 0 && (u32) tid * RT_PER - 1 < cnt) ? k2[base + (u32) tid * RT_PER - 1] : 0u;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) tid * RT_PER + c;
-    lg += (startflags >> c) & 1u;
+    const bool start = (startflags >> c) & 1u;
+    lg += start;
     const u32 g = s_grp[e];
     const bool open = e < cnt && ((first_open && g == g_first) ||
                                   (last_open && g == g_last));
-    const u32 kk = (open || e >= cnt) ? 0u : k2[base + e];
+    const u32 kraw = e < cnt ? k2[base + e] : 0u;
+    const u32 kk = open ? 0u : kraw;
+    splits |= (e < cnt && !open && !start && kraw != kprev);
+    kprev = kraw;
     s_key[e] = ((u64) lg << 43) | ((u64) kk << 11) | (u64) e;
     if (e < cnt) flg[base + e] = open;
     nflag += open;
   }
-  __syncthreads();
-  // bitonic sort, ascending
-  for (u32 k = 2; k <= (u32) RT_TILE; k <<= 1) {
-    for (u32 j = k >> 1; j > 0; j >>= 1) {
+  // (the barrier also orders the s_key writes before the network's reads)
+  const int any_split = __syncthreads_or(splits);
+  if (any_split) {
+    // largest group that has to be sorted here (open and padding groups are
+    // already in order)
+    {
+      u32 lgw = lg;   // local group number of this thread's last slot
 #pragma unroll
-      for (int c = 0; c < RT_PER / 2; c++) {
-        const u32 idx = (u32) c * RT_THREADS + tid;
-        const u32 lo = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
-        const u32 hi = lo + j;
-        const bool up = (lo & k) == 0;
-        const u64 a = s_key[lo], b = s_key[hi];
-        if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+      for (int c = RT_PER - 1; c >= 0; c--) {
+        const u32 e = (u32) tid * RT_PER + c;
+        if ((startflags >> c) & 1u) { s_start[lgw] = (u16) e; lgw--; }
       }
-      __syncthreads();
+      if (tid == 0) s_start[tot + 1] = (u16) RT_TILE;
+    }
+    __syncthreads();
+    u32 gmax = 0;
+    {
+      u32 lgw = lg;
+#pragma unroll
+      for (int c = RT_PER - 1; c >= 0; c--) {
+        const u32 e = (u32) tid * RT_PER + c;
+        if ((startflags >> c) & 1u) {
+          const u32 g = s_grp[e];
+          const bool open = (first_open && g == g_first) || (last_open && g == g_last);
+          if (e < cnt && !open) {
+            const u32 size = (u32) s_start[lgw + 1] - e;
+            gmax = size > gmax ? size : gmax;
+          }
+          lgw--;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const u32 o = __shfl_xor(gmax, d, 64);
+      gmax = o > gmax ? o : gmax;
+    }
+    if ((tid & 63) == 0) s_scan[tid >> 6] = gmax;
+    __syncthreads();
+    gmax = s_scan[0];
+    for (int i = 1; i < RT_THREADS / 64; i++) gmax = s_scan[i] > gmax ? s_scan[i] : gmax;
+    __syncthreads();
+    if (gmax <= 32u) {
+      // small groups: odd-even transposition, gmax + 1 phases; the group
+      // number in the top key bits keeps every exchange inside its group
+      for (u32 ph = 0; ph <= gmax; ph++) {
+        const u32 odd = ph & 1u;
+#pragma unroll
+        for (int c = 0; c < RT_PER / 2; c++) {
+          const u32 lo = 2u * ((u32) c * RT_THREADS + tid) + odd;
+          if (lo + 1 < (u32) RT_TILE) {
+            const u64 a = s_key[lo], b = s_key[lo + 1];
+            if (a > b) { s_key[lo] = b; s_key[lo + 1] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    } else {
+      // bitonic network, ascending
+      for (u32 k = 2; k <= (u32) RT_TILE; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+          for (int c = 0; c < RT_PER / 2; c++) {
+            const u32 idx = (u32) c * RT_THREADS + tid;
+            const u32 lo = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+            const u32 hi = lo + j;
+            const bool up = (lo & k) == 0;
+            const u64 a = s_key[lo], b = s_key[hi];
+            if ((a > b) == up) { s_key[lo] = b; s_key[hi] = a; }
+          }
+          __syncthreads();
+        }
+      }
     }
   }
   // outputs; new group head = first slot of every (group, k2) class

@@ -169,7 +169,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-template <typename K, typename V, bool XCD>
+template <typename K, typename V, bool XCD, int RANKMODE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
     K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
@@ -189,6 +189,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
                                                             : (u64) RS_TILE);
   for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
     (&s_cnt[0][0])[i] = 0;
+  // this tile's global write base per digit: strided, latency-bound load,
+  // issued first so that it is back long before it is needed
+  u32 gbase = 0;
+  if (tid < RADIX) gbase = hist_scanned[(u64) tid * ntiles + tile];
 
   K key[RS_ITEMS];
   V val[RS_ITEMS];
@@ -206,22 +210,45 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   }
   __syncthreads();
   const u64 lt = (1ull << lane) - 1ull;
+  if (RANKMODE == 1) {
+    // ballots first (register only) ...
+    u32 npeer[RS_ITEMS];   // lanes of this wave with the same digit (leader only)
 #pragma unroll
-  for (int j = 0; j < RS_ITEMS; j++) {
-    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
-    // out-of-range pairs go to the last digit; being the last pairs of the
-    // tile they end up behind all valid ones and are never written
-    const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
-    const u64 m = match_digit(d);
-    const u32 intra = (u32) __popcll(m & lt);
-    const int leader = __ffsll((unsigned long long) m) - 1;
-    u32 old = 0;
-    if (lane == leader) {
-      old = s_cnt[w][d];
-      s_cnt[w][d] = old + (u32) __popcll(m);
+    for (int j = 0; j < RS_ITEMS; j++) {
+      const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+      const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
+      const u64 m = match_digit(d);
+      const u32 intra = (u32) __popcll(m & lt);
+      rk[j] = (intra << 8) | d;
+      npeer[j] = intra == 0 ? (u32) __popcll(m) : 0u;   // lowest lane leads
     }
-    old = __shfl(old, leader, 64);
-    rk[j] = ((old + intra) << 8) | d;
+    // ... then the running per-wave digit counters: every lane reads the
+    // counter of its digit, the group's leader adds the group size.
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; j++) {
+      const u32 d = rk[j] & 255u;
+      const u32 old = s_cnt[w][d];
+      if (npeer[j]) atomicAdd(&s_cnt[w][d], npeer[j]);
+      rk[j] += old << 8;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; j++) {
+      const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+      // out-of-range pairs go to the last digit; being the last pairs of the
+      // tile they end up behind all valid ones and are never written
+      const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
+      const u64 m = match_digit(d);
+      const u32 intra = (u32) __popcll(m & lt);
+      const int leader = __ffsll((unsigned long long) m) - 1;
+      u32 old = 0;
+      if (lane == leader) {
+        old = s_cnt[w][d];
+        s_cnt[w][d] = old + (u32) __popcll(m);
+      }
+      old = __shfl(old, leader, 64);
+      rk[j] = ((old + intra) << 8) | d;
+    }
   }
   __syncthreads();
   // digit totals over the waves, wave-exclusive prefixes, tile-local bases
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     u32 dbase = block_scan_excl<SCAN_SUM, RS_THREADS>(tot, &blocktot, s_scan);
     if (tid < RADIX) {
       s_dbase[tid] = dbase;
-      s_obase[tid] = hist_scanned[(u64) tid * ntiles + tile] - dbase;
+      s_obase[tid] = gbase - dbase;
     }
   }
   __syncthreads();
@@ -275,6 +302,7 @@ u64 radix_workspace_words(u64 n) {
 
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
 static bool g_xcd_remap = true;
+static int g_rank_mode = 0;   // GTAMD_RANK_MODE
 
 template <typename K, typename V>
 int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
@@ -285,6 +313,8 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
   {
     const char *e = getenv("GTAMD_XCD_REMAP");
     g_xcd_remap = !(e != nullptr && e[0] == '0');
+    const char *r = getenv("GTAMD_RANK_MODE");
+    g_rank_mode = (r != nullptr && r[0] == '1') ? 1 : 0;
   }
   if (n >= (1ull << 32)) {
     gtamd_set_error("radix_sort_pairs: %llu pairs exceed the 32-bit index "
@@ -303,11 +333,14 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
-    if (g_xcd_remap)
-      k_rs_scatter<K, V, true><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+    if (!g_xcd_remap)
+      k_rs_scatter<K, V, false, 0><<<ntiles, RS_THREADS, 0, st>>>(
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+    else if (g_rank_mode == 1)
+      k_rs_scatter<K, V, true, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     else
-      k_rs_scatter<K, V, false><<<ntiles, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, true, 0><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {

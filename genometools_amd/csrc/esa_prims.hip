@@ -5,6 +5,7 @@
 #include "esa_prims.h"
 #include "esa_devutil.h"
 #include <stdlib.h>
+#include <vector>
 
 // ===========================================================================
 // scans
@@ -111,6 +112,8 @@ constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;       // 4096 pairs per block
 constexpr int RS_WAVE_CHUNK = RS_ITEMS * 64;         // 1024 consecutive pairs
 constexpr int RADIX = 256;
+constexpr int OS_MAXPASS = 8;
+constexpr u64 OS_AUX_WORDS = 2 * OS_MAXPASS * RADIX + 64;  // totals, bases, flag
 
 // Per-tile digit histogram.  hist is digit-major: hist[d * ntiles + tile], so
 // that one exclusive scan over the whole array yields every tile's global
@@ -160,6 +163,16 @@ __device__ __forceinline__ u64 match_digit(u32 d) {
 // ballot match inside the wave + a per-wave running digit counter in LDS.
 // The tile is then staged in LDS in digit order and written out so that
 // neighbouring lanes write neighbouring addresses of the same digit run.
+constexpr u32 OS_CHUNK = 8;
+constexpr u32 OS_AGG = 1u << 30, OS_INCL = 2u << 30, OS_VAL = (1u << 30) - 1u;
+constexpr u32 OS_SPIN_LIMIT = 1u << 21;
+constexpr int OS_WIN = 8;
+
+__device__ __forceinline__ u32 os_tile(u32 b) {
+  const u32 x = b & 7u, q = b >> 3;
+  return (q / OS_CHUNK) * (8u * OS_CHUNK) + x * OS_CHUNK + (q % OS_CHUNK);
+}
+
 // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its L2),
 // so they take CONSECUTIVE tiles; the output runs of consecutive tiles are
 // adjacent in every digit region, and the cache line two runs share is then
@@ -169,7 +182,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-template <typename K, typename V, bool XCD, int RANKMODE>
+template <typename K, typename V, int XCD, int RANKMODE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
     K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
@@ -182,7 +195,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   __shared__ u32 s_scan[RS_WAVES];
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 tile = XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x;
+  const u32 tile = XCD == 2 ? os_tile(blockIdx.x)
+                            : (XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x);
   if (tile >= ntiles) return;   // whole block leaves together
   const u64 tile_base = (u64) tile * RS_TILE;
   const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
@@ -292,17 +306,224 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   }
 }
 
+// ---------------------------------------------------------------------------
+// chained-scan scatter ("onesweep"): no per-tile histogram pass and no scan.
+// Every tile publishes its digit counts in a status word per digit
+// (flag | value in ONE 32-bit word, so no fence is needed), looks back over the
+// status words of the preceding tiles until it meets an inclusive prefix, and
+// publishes its own inclusive prefix.  Tiles are dealt to workgroups in a
+// chunk-permuted order (workgroups b, b+8, ... share an XCD and take
+// OS_CHUNK consecutive tiles at a time) so that neighbouring output runs are
+// still completed inside one L2.  Every spin is bounded; a pass that times out
+// (*errflag) is redone by the caller with the histogram/scan/scatter path.
+// ---------------------------------------------------------------------------
+// digit totals of all passes in one read of the keys
+template <typename K>
+__global__ __launch_bounds__(256) void k_os_totals(
+    const K *__restrict__ keys, u64 n, const int *__restrict__ shifts,
+    const int *__restrict__ widths, int npasses, u32 *__restrict__ totals) {
+  __shared__ u32 h[OS_MAXPASS][RADIX];
+  for (int i = threadIdx.x; i < OS_MAXPASS * RADIX; i += 256) (&h[0][0])[i] = 0;
+  __syncthreads();
+  int sh[OS_MAXPASS];
+  u32 mk[OS_MAXPASS];
+#pragma unroll
+  for (int p = 0; p < OS_MAXPASS; p++) {
+    sh[p] = p < npasses ? shifts[p] : 0;
+    mk[p] = p < npasses ? (1u << widths[p]) - 1u : 0u;
+  }
+  for (u64 i = (u64) blockIdx.x * 256 + threadIdx.x; i < n; i += (u64) gridDim.x * 256) {
+    const K k = keys[i];
+#pragma unroll
+    for (int p = 0; p < OS_MAXPASS; p++)
+      if (p < npasses) atomicAdd(&h[p][(u32) (k >> sh[p]) & mk[p]], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < npasses * RADIX; i += 256)
+    if ((&h[0][0])[i]) atomicAdd(&totals[i], (&h[0][0])[i]);
+}
+
+// per pass: exclusive scan of the 256 digit totals (one block of 256 threads)
+__global__ __launch_bounds__(256) void k_os_bases(const u32 *__restrict__ totals,
+                                                  u32 *__restrict__ bases) {
+  __shared__ u32 s_scan[4];
+  const u32 v = totals[blockIdx.x * RADIX + threadIdx.x];
+  u32 tot;
+  bases[blockIdx.x * RADIX + threadIdx.x] = block_scan_excl<SCAN_SUM>(v, &tot, s_scan);
+}
+
+template <typename K, typename V>
+__global__ __launch_bounds__(RS_THREADS) void k_os_scatter(
+    const K *__restrict__ keys_in, const V *__restrict__ vals_in,
+    K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
+    u32 mask, const u32 *__restrict__ digit_base, u32 *__restrict__ status,
+    u32 ntiles, u32 *__restrict__ errflag) {
+  __shared__ K s_key[RS_TILE];
+  __shared__ V s_val[RS_TILE];
+  __shared__ u32 s_cnt[RS_WAVES][RADIX];
+  __shared__ u32 s_dbase[RADIX];
+  __shared__ u32 s_obase[RADIX];
+  __shared__ u32 s_tot[RADIX];
+  __shared__ u32 s_scan[RS_WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile = os_tile(blockIdx.x);
+  if (tile >= ntiles) return;   // whole block leaves together
+  const u64 tile_base = (u64) tile * RS_TILE;
+  const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
+                                                            : (u64) RS_TILE);
+  for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
+    (&s_cnt[0][0])[i] = 0;
+  u32 gbase = 0;
+  if (tid < RADIX) gbase = digit_base[tid];
+
+  K key[RS_ITEMS];
+  V val[RS_ITEMS];
+  u32 rk[RS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    if (e < valid) {
+      key[j] = keys_in[tile_base + e];
+      val[j] = vals_in[tile_base + e];
+    } else {
+      key[j] = (K) ~(K) 0;
+      val[j] = 0;
+    }
+  }
+  __syncthreads();
+  const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
+    const u64 m = match_digit(d);
+    const u32 intra = (u32) __popcll(m & lt);
+    const int leader = __ffsll((unsigned long long) m) - 1;
+    u32 old = 0;
+    if (lane == leader) {
+      old = s_cnt[w][d];
+      s_cnt[w][d] = old + (u32) __popcll(m);
+    }
+    old = __shfl(old, leader, 64);
+    rk[j] = ((old + intra) << 8) | d;
+  }
+  __syncthreads();
+  {
+    u32 tot = 0;
+    if (tid < RADIX) {
+#pragma unroll
+      for (int i = 0; i < RS_WAVES; i++) {
+        const u32 c = s_cnt[i][tid];
+        s_cnt[i][tid] = tot;
+        tot += c;
+      }
+      // the padding of a short last tile was counted under the last digit
+      if (tid == RADIX - 1) tot -= (u32) RS_TILE - valid;
+    }
+    u32 blocktot;
+    u32 padded = tot + ((tid == RADIX - 1) ? (u32) RS_TILE - valid : 0u);
+    u32 dbase = block_scan_excl<SCAN_SUM, RS_THREADS>(tid < RADIX ? padded : 0u,
+                                                      &blocktot, s_scan);
+    if (tid < RADIX) {
+      s_tot[tid] = tot;
+      s_dbase[tid] = dbase;
+      s_obase[tid] = gbase;
+    }
+  }
+  __syncthreads();
+  // publish this tile's digit counts as early as possible: two digits per
+  // 8-byte store (each 32-bit half is a complete flag|value word)
+  u64 *status64 = reinterpret_cast<u64 *>(status);
+  if (tid < RADIX / 2) {
+    const u32 fl = tile == 0 ? OS_INCL : OS_AGG;
+    const u64 pack = (u64) (fl | s_tot[2 * tid]) | ((u64) (fl | s_tot[2 * tid + 1]) << 32);
+    __hip_atomic_store(status64 + (u64) tile * (RADIX / 2) + tid, pack,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // stage the tile in LDS in digit order: needs tile-local offsets only, and
+  // gives the preceding tiles time to publish theirs
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 d = rk[j] & 255u;
+    const u32 pos = s_dbase[d] + s_cnt[w][d] + (rk[j] >> 8);
+    s_key[pos] = key[j];
+    s_val[pos] = val[j];
+  }
+  if (tid < RADIX / 2) {
+    // ---- chained scan over the tiles, one thread per digit pair
+    u32 excl0 = 0, excl1 = 0;
+    if (tile > 0) {
+      // walk back OS_WIN tiles at a time: the loads of one window are
+      // independent and in flight together, so a hop costs a fraction of a
+      // memory round trip
+      u32 t = tile, spins = 0, hops = 0;
+      bool done = false;
+      while (!done) {
+        u64 v[OS_WIN];
+#pragma unroll
+        for (int k = 0; k < OS_WIN; k++) {
+          const u32 tt = t > (u32) k ? t - 1 - k : 0u;
+          v[k] = __hip_atomic_load(status64 + (u64) tt * (RADIX / 2) + tid,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < OS_WIN; k++) {
+          if (done) break;
+          const u32 lo = (u32) v[k], hi = (u32) (v[k] >> 32);
+          const u32 f = lo >> 30;   // both halves always carry the same flag
+          if (f == 0) {             // not published yet: re-read from here
+            if (++spins > OS_SPIN_LIMIT) { *errflag = 1; done = true; }
+            __builtin_amdgcn_s_sleep(1);
+            break;
+          }
+          excl0 += lo & OS_VAL;
+          excl1 += hi & OS_VAL;
+          t--;
+          hops++;
+          if (f == 2) done = true;  // tile 0 always publishes an inclusive prefix
+        }
+      }
+      if (tid == 0 && errflag[1] != 0) atomicAdd(&errflag[2], hops);
+      const u64 pack = (u64) (OS_INCL | (excl0 + s_tot[2 * tid])) |
+                       ((u64) (OS_INCL | (excl1 + s_tot[2 * tid + 1])) << 32);
+      __hip_atomic_store(status64 + (u64) tile * (RADIX / 2) + tid, pack,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_obase[2 * tid] += excl0 - s_dbase[2 * tid];
+    s_obase[2 * tid + 1] += excl1 - s_dbase[2 * tid + 1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) j * RS_THREADS + tid;
+    if (e < valid) {
+      const K k = s_key[e];
+      const u32 d = (u32) (k >> shift) & mask;
+      const u32 g = s_obase[d] + e;
+      keys_out[g] = k;
+      vals_out[g] = s_val[e];
+    }
+  }
+}
+
 }  // namespace
 
 u64 radix_workspace_words(u64 n) {
   u64 ntiles = div_up(n, RS_TILE);
   u64 hist = ntiles * RADIX;
-  return hist + scan_workspace_words(hist) + 64;
+  return hist + scan_workspace_words(hist) + 64 + OS_AUX_WORDS;
 }
 
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
 static bool g_xcd_remap = true;
+static int g_xcd_mode = 1;
 static int g_rank_mode = 0;   // GTAMD_RANK_MODE
+// chained-scan scatter: opt-in (GTAMD_ONESWEEP=1).  Measured at 3 Gbp: the
+// look-back walks 39 tiles on average (status hop latency across XCDs x tile
+// rate), which eats most of what the saved histogram pass gives back: sort
+// 151.7 ms vs 158.7 ms.  Correct, but not worth a spin loop by default.
+static bool g_onesweep = false;
 
 template <typename K, typename V>
 int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
@@ -313,8 +534,11 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
   {
     const char *e = getenv("GTAMD_XCD_REMAP");
     g_xcd_remap = !(e != nullptr && e[0] == '0');
+    g_xcd_mode = (e != nullptr && e[0] == '2') ? 2 : 1;
     const char *r = getenv("GTAMD_RANK_MODE");
     g_rank_mode = (r != nullptr && r[0] == '1') ? 1 : 0;
+    const char *o = getenv("GTAMD_ONESWEEP");
+    g_onesweep = o != nullptr && o[0] == '1';
   }
   if (n >= (1ull << 32)) {
     gtamd_set_error("radix_sort_pairs: %llu pairs exceed the 32-bit index "
@@ -326,21 +550,78 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
   u32 *scanws = ws + (u64) ntiles * RADIX;
   K *kin = keys_a, *kout = keys_b;
   V *vin = vals_a, *vout = vals_b;
+  // ---- chained-scan path for big sorts
+  bool chained[OS_MAXPASS] = {false};
+  u32 *aux = scanws + scan_workspace_words((u64) ntiles * RADIX) + 32;
+  u32 *d_totals = aux, *d_bases = aux + OS_MAXPASS * RADIX,
+      *d_flag = aux + 2 * OS_MAXPASS * RADIX;
+  int *d_shifts = reinterpret_cast<int *>(d_flag + 8), *d_widths = d_shifts + OS_MAXPASS;
+  if (g_onesweep && n >= (1u << 20) && npasses <= OS_MAXPASS) {
+    HIP_TRY(hipMemsetAsync(d_totals, 0, OS_MAXPASS * RADIX * 4, st));
+    HIP_TRY(hipMemcpyAsync(d_shifts, shifts, npasses * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_widths, widths, npasses * sizeof(int), hipMemcpyHostToDevice, st));
+    k_os_totals<K><<<2048, 256, 0, st>>>(kin, n, d_shifts, d_widths, npasses, d_totals);
+    HIP_TRY(hipGetLastError());
+    k_os_bases<<<npasses, 256, 0, st>>>(d_totals, d_bases);
+    HIP_TRY(hipGetLastError());
+    std::vector<u32> h_tot((size_t) npasses * RADIX);
+    HIP_TRY(hipMemcpyAsync(h_tot.data(), d_totals, h_tot.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int p = 0; p < npasses; p++) {
+      u32 mx = 0;
+      for (int d = 0; d < RADIX; d++) mx = h_tot[(size_t) p * RADIX + d] > mx ? h_tot[(size_t) p * RADIX + d] : mx;
+      chained[p] = mx < (1u << 30);   // status words carry 30-bit prefixes
+    }
+  }
   for (int p = 0; p < npasses; p++) {
     const u32 mask = (1u << widths[p]) - 1u;
+    if (chained[p]) {
+      HIP_TRY(hipMemsetAsync(hist, 0, (u64) ntiles * RADIX * 4, st));
+      HIP_TRY(hipMemsetAsync(d_flag, 0, 12, st));
+      if (getenv("GTAMD_OS_STATS") != nullptr) {
+        const u32 one = 1;
+        HIP_TRY(hipMemcpyAsync(d_flag + 1, &one, 4, hipMemcpyHostToDevice, st));
+      }
+      if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
+      const u32 groups = (ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK);
+      k_os_scatter<K, V><<<groups * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
+          kin, vin, kout, vout, n, shifts[p], mask, d_bases + p * RADIX, hist,
+          ntiles, d_flag);
+      HIP_TRY(hipGetLastError());
+      if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));
+      u32 h_flags[3] = {0, 0, 0};
+      HIP_TRY(hipMemcpyAsync(h_flags, d_flag, 12, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      const u32 h_flag = h_flags[0];
+      if (h_flags[1])
+        fprintf(stderr, "gtamd: chained scan pass %d: %.2f look-back hops per tile\n", p,
+                (double) h_flags[2] / ntiles);
+      if (h_flag == 0) {
+        if (ev_pairs != nullptr) (*n_ev)++;
+        K *tk = kin; kin = kout; kout = tk;
+        V *tv = vin; vin = vout; vout = tv;
+        continue;
+      }
+      // a look-back timed out (the dispatch order assumption did not hold):
+      // the input of this pass is untouched, redo it the classic way
+      fprintf(stderr, "gtamd: chained scan timed out in pass %d, falling back\n", p);
+    }
     k_rs_hist<K><<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
                                              ntiles);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
-    if (!g_xcd_remap)
-      k_rs_scatter<K, V, false, 0><<<ntiles, RS_THREADS, 0, st>>>(
+    if (g_xcd_mode == 2)
+      k_rs_scatter<K, V, 2, 0><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+    else if (!g_xcd_remap)
+      k_rs_scatter<K, V, 0, 0><<<ntiles, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     else if (g_rank_mode == 1)
-      k_rs_scatter<K, V, true, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, 1, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     else
-      k_rs_scatter<K, V, true, 0><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, 1, 0><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {

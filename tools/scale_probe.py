@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--runs", type=int, default=2)
     ap.add_argument("--want", type=int, default=7)
     ap.add_argument("--ab", default="", help="env var to toggle 0/1 between runs")
+    ap.add_argument("--abvals", default="0,1")
     ap.add_argument("--check", type=int, default=0, help="sampled pairs to verify on the CPU")
     a = ap.parse_args()
     n = int(a.n)
@@ -36,12 +37,12 @@ def main():
     eng.set_sequence_device(buf.data_ptr(), n)
     for r in range(a.runs):
         if a.ab:
-            os.environ[a.ab] = str(r & 1)
+            os.environ[a.ab] = a.abvals.split(',')[r % len(a.abvals.split(','))]
         t0 = time.time()
         eng.run(a.want)
         dt = time.time() - t0
         tm, st = eng.timing(), eng.stats()
-        print(("[%s=%d] " % (a.ab, r & 1) if a.ab else "") + "run%d wall %.3fs dev %.1f ms -> %.3f Gbp/s | keygen %.1f sort %.1f (scatter %.1f/%d) fin %.1f refine %.1f fix %.1f | tied %d rounds %d large %d maxlcp %d" % (
+        print(("[%s=%s] " % (a.ab, os.environ.get(a.ab)) if a.ab else "") + "run%d wall %.3fs dev %.1f ms -> %.3f Gbp/s | keygen %.1f sort %.1f (scatter %.1f/%d) fin %.1f refine %.1f fix %.1f | tied %d rounds %d large %d maxlcp %d" % (
             r, dt, tm["total_ms"], n / tm["total_ms"] / 1e6, tm["keygen_ms"], tm["sort_ms"],
             tm["scatter_ms"], tm["scatter_launches"], tm["finalize_ms"], tm["refine_ms"],
             tm["tie_fix_ms"], st["tied_suffixes"], st["refine_rounds"], st["largelcpvalues"],

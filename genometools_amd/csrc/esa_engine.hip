@@ -257,69 +257,109 @@ __global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
 constexpr int PART_BITS = 14;
 constexpr int PART_BINS = 1 << PART_BITS;
 
-// histogram of the leading PART_BITS key bits over all suffixes
+// leading PART_BITS bits of the key of suffix p (the bits the range partition
+// looks at): the padded symbol prefix only, without dcode and payload
 template <int BITS>
-__global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N,
+__device__ __forceinline__ u32 key_bin(const Text &t, u64 p) {
+  using K = Key<BITS>;
+  constexpr int SYMS = K::SYMS;
+  u64 s = sp_window(t, p) & ((1ull << SYMS) - 1ull);
+  const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+  if (d == 0) return (u32) PART_BINS - 1u;
+  u64 pre = Sym<BITS>::window(t, p) >> K::LOW_BITS;
+  if (d < SYMS) pre |= (1ull << (BITS * (SYMS - d))) - 1ull;
+  return (u32) (pre >> (K::PFX_BITS - PART_BITS));
+}
+
+// histogram of the key bins over every `stride`-th suffix: enough to place
+// the range cuts; exact slice sizes come from the count pass
+template <int BITS>
+__global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N, u64 stride,
                                                   u32 *__restrict__ hist) {
   __shared__ u32 h[PART_BINS];
   for (int i = threadIdx.x; i < PART_BINS; i += 256) h[i] = 0;
   __syncthreads();
-  for (u64 p = (u64) blockIdx.x * 256 + threadIdx.x; p < N;
-       p += (u64) gridDim.x * 256)
-    atomicAdd(&h[(u32) (make_key<BITS>(t, p) >> (64 - PART_BITS))], 1u);
+  const u64 nsamp = (N + stride - 1) / stride;
+  for (u64 i = (u64) blockIdx.x * 256 + threadIdx.x; i < nsamp;
+       i += (u64) gridDim.x * 256)
+    atomicAdd(&h[key_bin<BITS>(t, i * stride)], 1u);
   __syncthreads();
   for (int i = threadIdx.x; i < PART_BINS; i += 256)
     if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// suffixes of one block of 1024 text positions whose key falls in [lo, hi)
+// One block per 1024 text positions, one lane per position: which suffixes
+// fall into the bins [lo, hi)?  Writes the answer as a bitmask (one 64-bit
+// word per wave and slab), the number of in-range suffixes of the block, and
+// adds the block's counts per part to partcnt (for the exact slice offsets).
 template <int BITS>
-__global__ __launch_bounds__(256) void k_part_count(Text t, u64 N, u32 lo,
-                                                    u32 hi, u32 *__restrict__ cnt) {
-  __shared__ u32 s_scan[4];
-  const u64 p0 = (u64) blockIdx.x * 1024 + (u64) threadIdx.x * 4;
+__global__ __launch_bounds__(256) void k_part_count(
+    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner,
+    u64 *__restrict__ inrange, u32 *__restrict__ cnt,
+    unsigned long long *__restrict__ partcnt) {
+  __shared__ u32 s_cnt[4];
+  __shared__ u32 s_part[256];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  s_part[threadIdx.x] = 0;
+  __syncthreads();
   u32 c = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const u64 p = p0 + k;
+  for (int j = 0; j < 4; j++) {
+    const u64 p = (u64) blockIdx.x * 1024 + (u64) j * 256 + threadIdx.x;
+    bool in = false;
     if (p < N) {
-      const u32 b = (u32) (make_key<BITS>(t, p) >> (64 - PART_BITS));
-      c += b >= lo && b < hi;
+      const u32 b = key_bin<BITS>(t, p);
+      in = b >= lo && b < hi;
+      atomicAdd(&s_part[owner[b]], 1u);
+    }
+    const u64 m = __ballot(in);
+    if (lane == 0) {
+      inrange[(u64) blockIdx.x * 16 + j * 4 + w] = m;
+      c += (u32) __popcll(m);
     }
   }
-  u32 tot;
-  (void) block_scan_excl_sum(c, &tot, s_scan);
-  if (threadIdx.x == 0) cnt[blockIdx.x] = tot;
+  if (lane == 0) s_cnt[w] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (s_part[threadIdx.x])
+    atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
 }
 
-// order-preserving emission of the (key, position) pairs of this range
+// order-preserving emission of the (key, position) pairs of this part: the
+// threads of a block share out the SET bits of its 16 mask words, so full
+// keys are built for this part's suffixes only
 template <int BITS>
 __global__ __launch_bounds__(256) void k_part_emit(
-    Text t, u64 N, u32 lo, u32 hi, const u32 *__restrict__ off,
-    u64 *__restrict__ keys, u32 *__restrict__ vals) {
-  __shared__ u32 s_scan[4];
-  const u64 p0 = (u64) blockIdx.x * 1024 + (u64) threadIdx.x * 4;
-  u64 key[4];
-  u32 mask = 0, c = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const u64 p = p0 + k;
-    key[k] = 0;
-    if (p < N) {
-      key[k] = make_key<BITS>(t, p);
-      const u32 b = (u32) (key[k] >> (64 - PART_BITS));
-      if (b >= lo && b < hi) { mask |= 1u << k; c++; }
-    }
+    Text t, u64 N, const u64 *__restrict__ inrange, const u32 *__restrict__ off,
+    const u32 *__restrict__ cnt, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+  __shared__ u64 s_mask[16];
+  __shared__ u32 s_pre[17];
+  if (threadIdx.x < 16) s_mask[threadIdx.x] = inrange[(u64) blockIdx.x * 16 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 a = 0;
+    for (int i = 0; i < 16; i++) { s_pre[i] = a; a += (u32) __popcll(s_mask[i]); }
+    s_pre[16] = a;
   }
-  u32 tot;
-  u32 o = off[blockIdx.x] + block_scan_excl_sum(c, &tot, s_scan);
+  __syncthreads();
+  const u32 total = s_pre[16];
+  const u64 out0 = off[blockIdx.x];
+  (void) cnt;
+  for (u32 k = threadIdx.x; k < total; k += 256) {
+    // word that holds the k-th set bit, then the bit inside it
+    int wi = 0;
 #pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (mask & (1u << k)) {
-      keys[o] = key[k];
-      vals[o] = (u32) (p0 + k);
-      o++;
-    }
+    for (int i = 1; i < 16; i++) wi += (s_pre[i] <= k);
+    u64 m = s_mask[wi];
+    u32 r = k - s_pre[wi];
+    while (r--) m &= m - 1;            // drop the r lowest set bits
+    const int bit = __ffsll((unsigned long long) m) - 1;
+    // word wi = slab j (wi / 4), wave w (wi % 4): position j*256 + w*64 + bit
+    const u64 p = (u64) blockIdx.x * 1024 + (u64) (wi >> 2) * 256 + (u64) (wi & 3) * 64 + bit;
+    keys[out0 + k] = make_key<BITS>(t, p);
+    vals[out0 + k] = (u32) p;
+  }
+  (void) N;
 }
 
 // distributed rank lookup: which part owns the suffix h symbols further on
@@ -335,7 +375,7 @@ __global__ __launch_bounds__(256) void k_query_dest(
   if (j < m) {
     u64 q = (u64) upos[j] + h;
     if (q > t.n) q = t.n;
-    const u32 d = owner[(u32) (make_key<BITS>(t, q) >> (64 - PART_BITS))];
+    const u32 d = owner[key_bin<BITS>(t, q)];
     dkey[j] = d;
     dval[j] = (u32) j;
     atomicAdd(&s_cnt[d], 1u);
@@ -1404,10 +1444,11 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
     HIP_TRY(hipGetLastError());
   } else {
-    // split points from the histogram of the leading key bits; every part
-    // computes the same histogram from the replicated text
+    // range cuts from a histogram of the key bins over every 16th suffix;
+    // every part computes the same cuts from the replicated text
+    const u64 stride = N > (1u << 24) ? 16 : 1;
     HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
-    k_key_hist<BITS><<<2048, 256, 0, st>>>(c->text, N, c->d_parthist);
+    k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, N, stride, c->d_parthist);
     HIP_TRY(hipGetLastError());
     std::vector<u32> hist(PART_BINS);
     HIP_TRY(hipMemcpyAsync(hist.data(), c->d_parthist, PART_BINS * 4,
@@ -1416,17 +1457,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     std::vector<u64> start(PART_BINS + 1);
     start[0] = 0;
     for (int b = 0; b < PART_BINS; b++) start[b + 1] = start[b] + hist[b];
-    if (start[PART_BINS] != N) {
-      gtamd_set_error("key histogram counts %llu suffixes, expected %llu",
-                      (unsigned long long) start[PART_BINS], (unsigned long long) N);
-      return -1;
-    }
+    const u64 nsamp = start[PART_BINS];
     std::vector<u32> cut(R + 1);
     std::vector<u8> owner(PART_BINS);
     cut[0] = 0;
     cut[R] = PART_BINS;
     for (u32 r = 1; r < R; r++) {
-      const u64 target = (u64) (((unsigned __int128) N * r) / R);
+      const u64 target = (u64) (((unsigned __int128) nsamp * r) / R);
       u32 b = cut[r - 1];
       while (b < (u32) PART_BINS && start[b] < target) b++;
       cut[r] = b;
@@ -1435,17 +1472,38 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       for (u32 b = cut[r]; b < cut[r + 1]; b++) owner[b] = (u8) r;
     HIP_TRY(hipMemcpyAsync(c->d_owner, owner.data(), PART_BINS,
                            hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
     const u32 lo = cut[c->part], hi = cut[c->part + 1];
-    index_offset = start[lo];
-    NL = start[hi] - start[lo];
+    // exact membership (bitmask), block counts and the sizes of all parts
     const u64 nblk = div_up(N, 1024);
     u32 *cnt = c->rws, *off = cnt + nblk + 16, *sws = off + nblk + 16;
-    k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, cnt);
+    u64 *inrange = c->k1;            // nblk * 16 words <= N / 64 + 16
+    unsigned long long *d_partcnt =
+        reinterpret_cast<unsigned long long *>(c->d_parthist);  // 256 x u64 fit
+    HIP_TRY(hipMemsetAsync(d_partcnt, 0, 256 * 8, st));
+    k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, c->d_owner,
+                                                   inrange, cnt, d_partcnt);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, cnt, off, nblk, false, sws, st));
-    k_part_emit<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, off, c->k0, c->v0);
-    HIP_TRY(hipGetLastError());
+    unsigned long long h_partcnt[256];
+    HIP_TRY(hipMemcpyAsync(h_partcnt, d_partcnt, 256 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    index_offset = 0;
+    u64 allparts = 0;
+    for (u32 r = 0; r < R; r++) {
+      if (r < c->part) index_offset += h_partcnt[r];
+      allparts += h_partcnt[r];
+    }
+    NL = h_partcnt[c->part];
+    if (allparts != N) {
+      gtamd_set_error("range partition counts %llu suffixes, expected %llu",
+                      (unsigned long long) allparts, (unsigned long long) N);
+      return -1;
+    }
+    if (NL > 0) {
+      k_part_emit<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, inrange, off, cnt,
+                                                    c->k0, c->v0);
+      HIP_TRY(hipGetLastError());
+    }
   }
   c->NL = NL;
   c->index_offset = index_offset;

@@ -69,7 +69,7 @@ class ThreadComm:
         return _View(self, rank)
 
 
-def build_in_parts(enc, sigma, parts, want=7, device=0):
+def build_in_parts(enc, sigma, parts, want=7, device=0, timing=False):
     """run `parts` engines concurrently; return the assembled tables and the
     combined statistics"""
     from genometools_amd import esa
@@ -112,4 +112,6 @@ def build_in_parts(enc, sigma, parts, want=7, device=0):
         stats["prefixlength"] = res.stats["prefixlength"]
     assert expect == enc.size + 1
     tabs = {k: (np.concatenate(v) if v else None) for k, v in out.items()}
+    if timing:
+        return tabs, stats, [(r[1].stats, r[1].timing) for r in results]
     return tabs, stats, [r[1].stats for r in results]

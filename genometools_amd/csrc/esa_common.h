@@ -35,9 +35,10 @@ static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
 
 // ---- key layout ------------------------------------------------------------
 // One 64-bit sort key per suffix:
-//   [ prefix: KEY_SYMS symbols x BITS ][ unused ][ dcode ][ payload: symbol
-//   before the suffix ]          (prefix in the top bits, dcode | payload in
-//   the lowest; only prefix and dcode are sorted)
+//   [ prefix: KEY_SYMS symbols x BITS ][ dcode ][ unused ][ payload: symbol
+//   before the suffix ]          (prefix in the top bits, dcode right below,
+//   payload in the lowest bits; only prefix and dcode are sorted, as one
+//   contiguous bit range)
 // dcode = 0: no special among the first KEY_SYMS symbols;
 // dcode = KEY_SYMS - d (1..KEY_SYMS-1): first special after d letters (the
 //   prefix is padded with 1-bits behind the d letters, so the suffix sorts
@@ -58,7 +59,8 @@ template <> struct KeyLayout<2> {
   static constexpr int SYMS_PER_WORD = 32;
 };
 template <> struct KeyLayout<5> {
-  static constexpr int KEY_SYMS = 8;        // 40 bits
+  // 20^10 >> 10^9: random ties stay rare enough for the direct tie path
+  static constexpr int KEY_SYMS = 10;       // 50 bits
   static constexpr int DCODE_BITS = 4;
   static constexpr int PAYLOAD_BITS = 5;
   static constexpr int SYMS_PER_WORD = 12;  // 60 bits used, 4 low bits idle

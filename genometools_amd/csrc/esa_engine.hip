@@ -126,11 +126,14 @@ template <int BITS> struct Key {
   using L = KeyLayout<BITS>;
   static constexpr int SYMS = L::KEY_SYMS;
   static constexpr int PFX_BITS = SYMS * BITS;
-  static constexpr int LOW_BITS = 64 - PFX_BITS;          // dcode + payload
+  static constexpr int LOW_BITS = 64 - PFX_BITS;          // below the prefix
+  static constexpr int DSHIFT = LOW_BITS - L::DCODE_BITS; // dcode sits right
+                                                          // below the prefix
   static constexpr u32 DMAX = (1u << L::DCODE_BITS) - 1u;  // suffix starts special
   static constexpr u64 PAY_MASK = (1ull << L::PAYLOAD_BITS) - 1ull;
+  static_assert(DSHIFT >= L::PAYLOAD_BITS, "key layout does not fit 64 bits");
   static __device__ __forceinline__ u32 dcode(u64 key) {
-    return (u32) (key >> L::PAYLOAD_BITS) & DMAX;
+    return (u32) (key >> DSHIFT) & DMAX;
   }
   // number of letters in front of the first special, capped at SYMS
   static __device__ __forceinline__ u32 letters(u64 key) {
@@ -225,14 +228,14 @@ __device__ __forceinline__ u64 make_key(const Text &t, u64 p) {
   u64 s = sp_window(t, p) & ((1ull << SYMS) - 1ull);
   const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
   if (d == 0)  // suffix starts with a special (or is the virtual end)
-    return (~0ull << KeyLayout<BITS>::PAYLOAD_BITS) | pay;
+    return (~0ull << K::DSHIFT) | pay;
   u64 pre = Sym<BITS>::window(t, p) >> K::LOW_BITS;  // SYMS symbols
   u32 dc = 0;
   if (d < SYMS) {
     pre |= (1ull << (BITS * (SYMS - d))) - 1ull;  // pad behind the d letters
     dc = (u32) (SYMS - d);
   }
-  return (pre << K::LOW_BITS) | ((u64) dc << KeyLayout<BITS>::PAYLOAD_BITS) | pay;
+  return (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
 }
 
 template <int BITS>
@@ -1511,19 +1514,10 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
 
   // ---- first sort: all key bits above the payload
   int shifts[16], widths[16], np = 0;
-  {
-    const int lo0 = KeyLayout<BITS>::PAYLOAD_BITS,
-              hi0 = lo0 + KeyLayout<BITS>::DCODE_BITS;   // dcode
-    for (int b = lo0; b < hi0; b += 8) {
-      shifts[np] = b;
-      widths[np] = hi0 - b < 8 ? hi0 - b : 8;
-      np++;
-    }
-    for (int b = K::LOW_BITS; b < 64; b += 8) {          // symbol prefix
-      shifts[np] = b;
-      widths[np] = 64 - b < 8 ? 64 - b : 8;
-      np++;
-    }
+  for (int b = K::DSHIFT; b < 64; b += 8) {   // dcode and prefix, contiguous
+    shifts[np] = b;
+    widths[np] = 64 - b < 8 ? 64 - b : 8;
+    np++;
   }
   int nev = 0;
   TRY(radix_sort_pairs<u64, u32>(c->k0, c->v0, c->k1, c->v1, NL, shifts, widths, np,

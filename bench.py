@@ -90,14 +90,21 @@ def main():
     ap.add_argument("--seed", type=int, default=43)
     ap.add_argument("--cpu-sample", type=float, default=32e6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="gloo + --same-device rehearses N>1 on one GPU")
+    ap.add_argument("--same-device", action="store_true")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.same_device:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
     dev = local_rank
     n = int(a.n)
     sigma = synth.numofchars(a.model)
@@ -138,7 +145,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        cdev = "cuda:%d" % dev if a.backend == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = eng.stats()
@@ -147,7 +155,7 @@ def main():
         st = gdist.combine_stats(st, "cuda:%d" % dev)
         t = torch.tensor([sc_ms, float(sc_launches), float(slice_entries),
                           float(comm.bytes_exchanged)], dtype=torch.float64,
-                         device="cuda:%d" % dev)
+                         device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         sc_ms, sc_launches = float(t[0].item()) / world, int(t[1].item()) // world
         pairs_per_launch = float(t[2].item()) / world

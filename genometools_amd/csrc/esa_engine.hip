@@ -1089,6 +1089,7 @@ struct gtamd_esa_ctx {
   u64 *k0, *k1;
   u32 *v0, *v1;
   u32 *rws;                // radix / scan workspace
+  u8 *dig0, *dig1;         // digit side arrays of the first sort
   u64 rws_words;
   // outputs
   u64 *suf;
@@ -1129,7 +1130,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
   free_dev(c->tb_own); free_dev(c->sp_own);
   free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
-  free_dev(c->rws); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
+  free_dev(c->rws); free_dev(c->dig0); free_dev(c->dig1); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
   free_dev(c->llv); free_dev(c->tiebits); free_dev(c->d_stats);
   free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
   free_dev(c->xbuf);
@@ -1188,6 +1189,8 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   c->rws_words = radix_workspace_words(N) + 4 * (div_up(N, 64) + 64) +
                  scan_workspace_words(div_up(N, 64)) + 64;
   CTX_TRY(hipMalloc(&c->rws, c->rws_words * 4));
+  CTX_TRY(hipMalloc(&c->dig0, Npad));
+  CTX_TRY(hipMalloc(&c->dig1, Npad));
   CTX_TRY(hipMalloc(&c->suf, Npad * 8));
   CTX_TRY(hipMalloc(&c->lcp, Npad));
   CTX_TRY(hipMalloc(&c->bwt, Npad));
@@ -1359,7 +1362,8 @@ static int comm_allgather(gtamd_esa_ctx *c, const void *send, void *recv,
 template <int BITS>
 static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
                           const u32 *rank, u32 *k2, u64 *dkey_a, u32 *dval_a,
-                          u64 *dkey_b, u32 *dval_b, u32 *sendq, u32 *rws2) {
+                          u64 *dkey_b, u32 *dval_b, u32 *sendq, u32 *rws2,
+                          u64 *all_queries) {
   hipStream_t st = c->st;
   const u32 R = c->numparts;
   u32 *d_counts = c->d_parthist;   // idle after the split: reuse 256 counters
@@ -1375,11 +1379,14 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   std::vector<u64> sendcounts(R), matrix((size_t) R * R), recvcounts(R);
   for (u32 r = 0; r < R; r++) sendcounts[r] = h_counts[r];
   TRY(comm_allgather(c, sendcounts.data(), matrix.data(), R * 8));
-  u64 nrecv = 0;
+  u64 nrecv = 0, total = 0;
   for (u32 r = 0; r < R; r++) {
     recvcounts[r] = matrix[(size_t) r * R + c->part];
     nrecv += recvcounts[r];
   }
+  for (size_t i = 0; i < matrix.size(); i++) total += matrix[i];
+  *all_queries = total;   // zero: no part has tied suffixes left
+  if (total == 0) return 0;
   const u32 *order = dval_a;
   if (m > 0) {
     const int shift0 = 0, width8 = 8;
@@ -1521,7 +1528,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   }
   int nev = 0;
   TRY(radix_sort_pairs<u64, u32>(c->k0, c->v0, c->k1, c->v1, NL, shifts, widths, np,
-                            c->rws, st, c->ev_scatter, &nev));
+                            c->rws, st, c->ev_scatter, &nev, c->dig0, c->dig1));
   u64 *skey = (np & 1) ? c->k1 : c->k0;   // sorted keys
   u32 *sa32 = (np & 1) ? c->v1 : c->v0;   // positions in suffix order
   u64 *fkey = (np & 1) ? c->k0 : c->k1;   // free key-sized buffer
@@ -1681,26 +1688,24 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       }
     u64 m = m0, h = (u64) K::SYMS;
     for (;;) {
-      u64 active = m;
-      if (parts) {
-        std::vector<u64> all(R);
-        TRY(comm_allgather(c, &m, all.data(), 8));
-        active = 0;
-        for (u32 r = 0; r < R; r++) active += all[r];
-      }
-      if (active == 0) break;
-      if (++rounds > 64) {
+      if (!parts && m == 0) break;
+      if (rounds >= 64) {
         gtamd_set_error("prefix doubling did not converge after 64 rounds");
         return -1;
       }
       const u32 g = (u32) div_up(m, 256);
       if (parts) {
+        // the query exchange doubles as the termination test: the gathered
+        // count matrix is all zero when no part has tied suffixes left
+        u64 all_queries = 0;
         TRY(exchange_ranks<BITS>(c, upos, m, h, rank, k2, ckey_a, cval_a, ckey_b,
-                                 cval_b, sendq, rws2));
+                                 cval_b, sendq, rws2, &all_queries));
+        if (all_queries == 0) break;
       } else {
         k_round_gather<<<g, 256, 0, st>>>(upos, m, h, n, rank, k2);
         HIP_TRY(hipGetLastError());
       }
+      rounds++;
       if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
       HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
       k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(

@@ -17,9 +17,12 @@ u64 radix_workspace_words(u64 n);
 // significant digit first, widths <= 8).  Ping-pongs between (a) and (b); the
 // result is in (a) if npasses is even, else in (b).  If ev_pairs != NULL, a
 // start/stop event pair is recorded around every scatter launch
-// (ev_pairs[2*i], ev_pairs[2*i+1]) and *n_ev is advanced.
+// (ev_pairs[2*i], ev_pairs[2*i+1]) and *n_ev is advanced.  dig_a/dig_b: optional
+// n-byte scratch arrays; when given, every scatter pass also writes the next
+// pass's digit of each pair as one byte and the next histogram reads those
+// bytes instead of the keys.
 template <typename K, typename V>
 int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
-                     int *n_ev);
+                     int *n_ev, u8 *dig_a = nullptr, u8 *dig_b = nullptr);

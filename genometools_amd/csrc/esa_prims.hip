@@ -144,6 +144,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
   }
 }
 
+// the same histogram from the digit bytes the previous scatter pass left
+// behind (1 B per pair instead of the 8-byte key)
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_bytes(
+    const u8 *__restrict__ dig, u64 n, u32 *__restrict__ hist, u32 ntiles) {
+  __shared__ u32 h[RS_WAVES][RADIX];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 base = (u64) blockIdx.x * RS_TILE + (u64) tid * RS_ITEMS;
+  if (base + RS_ITEMS <= n) {
+    static_assert(RS_ITEMS == 8, "one 8-byte load per thread");
+    const u64 v = *reinterpret_cast<const u64 *>(dig + base);
+#pragma unroll
+    for (int j = 0; j < 8; j++) atomicAdd(&h[w][(u32) (v >> (8 * j)) & 255u], 1u);
+  } else {
+    for (int j = 0; j < RS_ITEMS; j++)
+      if (base + j < n) atomicAdd(&h[w][dig[base + j]], 1u);
+  }
+  __syncthreads();
+  if (tid < RADIX) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; i++) c += h[i][tid];
+    hist[(u64) tid * ntiles + blockIdx.x] = c;
+  }
+}
+
 // lanes of this wave that hold the same 8-bit digit (all 64 lanes active)
 __device__ __forceinline__ u64 match_digit(u32 d) {
   u64 m = ~0ull;
@@ -186,7 +213,8 @@ template <typename K, typename V, int XCD, int RANKMODE>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
     K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
-    u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles) {
+    u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles,
+    u8 *__restrict__ dig_out, int next_shift, u32 next_mask) {
   __shared__ K s_key[RS_TILE];
   __shared__ V s_val[RS_TILE];
   __shared__ u32 s_cnt[RS_WAVES][RADIX];   // running counters, then wave prefix
@@ -302,6 +330,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
       const u32 g = s_obase[d] + e;
       keys_out[g] = k;
       vals_out[g] = s_val[e];
+      if (dig_out != nullptr) dig_out[g] = (u8) ((u32) (k >> next_shift) & next_mask);
     }
   }
 }
@@ -518,6 +547,7 @@ u64 radix_workspace_words(u64 n) {
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
 static bool g_xcd_remap = true;
 static int g_xcd_mode = 1;
+static bool g_no_digbytes = false;   // GTAMD_DIGBYTES=0
 static int g_rank_mode = 0;   // GTAMD_RANK_MODE
 // chained-scan scatter: opt-in (GTAMD_ONESWEEP=1).  Measured at 3 Gbp: the
 // look-back walks 39 tiles on average (status hop latency across XCDs x tile
@@ -529,7 +559,7 @@ template <typename K, typename V>
 int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
-                     int *n_ev) {
+                     int *n_ev, u8 *dig_a, u8 *dig_b) {
   if (n == 0) return 0;
   {
     const char *e = getenv("GTAMD_XCD_REMAP");
@@ -537,8 +567,11 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     g_xcd_mode = (e != nullptr && e[0] == '2') ? 2 : 1;
     const char *r = getenv("GTAMD_RANK_MODE");
     g_rank_mode = (r != nullptr && r[0] == '1') ? 1 : 0;
+    const char *db = getenv("GTAMD_DIGBYTES");
+    g_no_digbytes = db != nullptr && db[0] == '0';
     const char *o = getenv("GTAMD_ONESWEEP");
     g_onesweep = o != nullptr && o[0] == '1';
+    if (g_onesweep) g_no_digbytes = true;   // the chained kernel writes no digit bytes
   }
   if (n >= (1ull << 32)) {
     gtamd_set_error("radix_sort_pairs: %llu pairs exceed the 32-bit index "
@@ -606,23 +639,33 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
       // the input of this pass is untouched, redo it the classic way
       fprintf(stderr, "gtamd: chained scan timed out in pass %d, falling back\n", p);
     }
-    k_rs_hist<K><<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
-                                             ntiles);
+    // digit bytes: written by the previous pass into din, this pass leaves the
+    // next pass's digits in dout
+    const bool have_dig = dig_a != nullptr && p > 0 && !g_no_digbytes;
+    u8 *din = (p & 1) ? dig_a : dig_b, *dout = (p & 1) ? dig_b : dig_a;
+    if (dig_a == nullptr || p + 1 >= npasses || g_no_digbytes) dout = nullptr;
+    const int nsh = p + 1 < npasses ? shifts[p + 1] : 0;
+    const u32 nmk = p + 1 < npasses ? (1u << widths[p + 1]) - 1u : 0u;
+    if (have_dig)
+      k_rs_hist_bytes<<<ntiles, RS_THREADS, 0, st>>>(din, n, hist, ntiles);
+    else
+      k_rs_hist<K><<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
+                                               ntiles);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
     if (g_xcd_mode == 2)
       k_rs_scatter<K, V, 2, 0><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else if (!g_xcd_remap)
       k_rs_scatter<K, V, 0, 0><<<ntiles, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else if (g_rank_mode == 1)
       k_rs_scatter<K, V, 1, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else
       k_rs_scatter<K, V, 1, 0><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles);
+          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {
       HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));
@@ -636,7 +679,9 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
 
 template int radix_sort_pairs<u64, u32>(u64 *, u32 *, u64 *, u32 *, u64,
                                         const int *, const int *, int, u32 *,
-                                        hipStream_t, hipEvent_t *, int *);
+                                        hipStream_t, hipEvent_t *, int *, u8 *,
+                                        u8 *);
 template int radix_sort_pairs<u32, u32>(u32 *, u32 *, u32 *, u32 *, u64,
                                         const int *, const int *, int, u32 *,
-                                        hipStream_t, hipEvent_t *, int *);
+                                        hipStream_t, hipEvent_t *, int *, u8 *,
+                                        u8 *);

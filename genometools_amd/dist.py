@@ -54,6 +54,8 @@ class TorchComm:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # host transport for device buffers when the backend cannot move them
+        self.staged = self.device.type != "cpu" and dist.get_backend(group) == "gloo"
         self.bytes_exchanged = 0
         self.calls = 0
         # keep the ctypes thunks alive as long as the object lives
@@ -65,7 +67,7 @@ class TorchComm:
         try:
             mine = _host_bytes(send, nbytes)
             out = _host_bytes(recv, nbytes * self.world)
-            if self.device.type == "cpu":
+            if self.device.type == "cpu" or self.staged:
                 self._gloo_allgather(out, mine)
             else:
                 d_in = mine.to(self.device)
@@ -76,6 +78,20 @@ class TorchComm:
         except Exception as e:  # never let an exception cross the C boundary
             print("allgather callback failed:", repr(e), flush=True)
             return -1
+
+    def _p2p(self, tmp, ins, rc, sc):
+        # gloo has no alltoall: pairwise non-blocking send/recv
+        reqs = []
+        for r in range(self.world):
+            if r == self.rank:
+                tmp[r].copy_(ins[r])
+                continue
+            if rc[r]:
+                reqs.append(dist.irecv(tmp[r], src=r, group=self.group))
+            if sc[r]:
+                reqs.append(dist.isend(ins[r].contiguous(), dst=r, group=self.group))
+        for q in reqs:
+            q.wait()
 
     def _gloo_allgather(self, out, mine):
         parts = [torch.empty_like(mine) for _ in range(self.world)]
@@ -92,21 +108,20 @@ class TorchComm:
                 t_out = _host_bytes(recv, sum(rc)) if sum(rc) else torch.empty(0, dtype=torch.uint8)
                 outs = list(t_out.split(rc)) if sum(rc) else [torch.empty(0, dtype=torch.uint8) for _ in rc]
                 ins = [x.clone() for x in t_in.split(sc)] if sum(sc) else [torch.empty(0, dtype=torch.uint8) for _ in sc]
-                # gloo has no alltoall: pairwise non-blocking send/recv
                 tmp = [torch.empty(n, dtype=torch.uint8) for n in rc]
-                reqs = []
-                for r in range(self.world):
-                    if r == self.rank:
-                        tmp[r].copy_(ins[r])
-                        continue
-                    if rc[r]:
-                        reqs.append(dist.irecv(tmp[r], src=r, group=self.group))
-                    if sc[r]:
-                        reqs.append(dist.isend(ins[r], dst=r, group=self.group))
-                for q in reqs:
-                    q.wait()
+                self._p2p(tmp, ins, rc, sc)
                 for o, t in zip(outs, tmp):
                     o.copy_(t)
+            elif self.staged:
+                # device buffers, host transport (gloo): used to rehearse the
+                # multi-process path on a box with a single GPU
+                t_in = _device_bytes(send, sum(sc), self.device).cpu()
+                ins = list(t_in.split(sc)) if sum(sc) else [torch.empty(0, dtype=torch.uint8) for _ in sc]
+                tmp = [torch.empty(n, dtype=torch.uint8) for n in rc]
+                self._p2p(tmp, ins, rc, sc)
+                if sum(rc):
+                    _device_bytes(recv, sum(rc), self.device).copy_(torch.cat(tmp))
+                torch.cuda.synchronize(self.device)
             else:
                 t_in = _device_bytes(send, sum(sc), self.device)
                 t_out = _device_bytes(recv, sum(rc), self.device)
@@ -129,6 +144,8 @@ class TorchComm:
 def combine_stats(stats, device, group=None):
     """whole-table statistics from the per-part ones (see gtamd_esa_set_part)"""
     dev = torch.device(device)
+    if dev.type != "cpu" and dist.get_backend(group) == "gloo":
+        dev = torch.device("cpu")
     s = torch.tensor([stats["lcptabsum"], stats["largelcpvalues"], stats["longest"],
                       stats["tied_suffixes"]], dtype=torch.int64, device=dev)
     m = torch.tensor([stats["maxbranchdepth"], stats["refine_rounds"]],

@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=float, default=3e9, help="symbols per sequence")
+    ap.add_argument("--symbols", dest="n", type=float, default=3e9, help="sequence length")
     ap.add_argument("--model", type=int, default=synth.MODEL_HUMANLIKE_DNA)
     ap.add_argument("--seed", type=int, default=43)
     ap.add_argument("--cpu-sample", type=float, default=32e6)

@@ -432,6 +432,36 @@ constexpr int FIN_THREADS = 256;
 constexpr int FIN_PER_THREAD = 4;
 constexpr int FIN_TILE = FIN_THREADS * FIN_PER_THREAD * 4;  // 4096 entries
 
+// "entry i has the same sorted key bits as entry i-1" for every entry, and the
+// number of such entries: all the refinement needs from the sorted keys, so the
+// table emission (k_finalize) can run beside it on a second stream
+template <int BITS>
+__global__ __launch_bounds__(256) void k_tiebits(const u64 *__restrict__ keys,
+                                                 u64 N, u64 *__restrict__ tiebits,
+                                                 Stats *stats) {
+  using K = Key<BITS>;
+  __shared__ u32 s_cnt[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 cnt = 0;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const u64 i = (u64) blockIdx.x * 4096 + (u64) r * 256 + threadIdx.x;
+    const u64 k = i < N ? keys[i] : ~0ull;
+    u64 prev = __shfl_up(k, 1, 64);
+    if (lane == 0) prev = (i > 0 && i < N) ? keys[i - 1] : ~k;
+    const bool tie = i > 0 && i < N && (k >> K::DSHIFT) == (prev >> K::DSHIFT) &&
+                     K::dcode(k) == 0;
+    const u64 m = __ballot(tie);
+    if (lane == 0 && i < N) { tiebits[i >> 6] = m; cnt += (u32) __popcll(m); }
+  }
+  if (lane == 0) s_cnt[w] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 t = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (t) atomicAdd(&stats->numties, (unsigned long long) t);
+  }
+}
+
 // Each thread owns 4 consecutive entries so that .lcp/.bwt leave as one
 // 32-bit store and .suf as two 16-byte stores per lane.
 template <int BITS>
@@ -528,7 +558,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
     tw |= __shfl_xor(tw, 2, 64);
     tw |= __shfl_xor(tw, 4, 64);
     tw |= __shfl_xor(tw, 8, 64);
-    if ((lane & 15) == 0 && i0 < N) tiebits[i0 >> 6] = tw;
+    if (tiebits != nullptr && (lane & 15) == 0 && i0 < N) tiebits[i0 >> 6] = tw;
   }
   // block reduction of the statistics, one atomic each per block
 #pragma unroll
@@ -547,7 +577,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
       S += s_sum[i]; T += s_ties[i]; M = s_max[i] > M ? s_max[i] : M;
     }
     if (S) atomicAdd(&stats->lcpsum, S);
-    if (T) atomicAdd(&stats->numties, T);
+    if (T && tiebits != nullptr) atomicAdd(&stats->numties, T);
     if (M) atomicMax(&stats->maxlcp, M);
   }
 }
@@ -987,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_fix_basic(
 __global__ __launch_bounds__(256) void k_lcp_pairs(
     const u32 *__restrict__ tied, const u32 *__restrict__ off,
     const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32, u64 m0,
-    u64 *__restrict__ pkey, u32 *__restrict__ pval) {
+    u32 *__restrict__ pkey, u32 *__restrict__ pval) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m0 || !tied[j]) return;
   const u32 o = off[j];
@@ -1003,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_lcp_pairs(
 constexpr int LCP_CHUNK = 32;
 template <int BITS>
 __global__ __launch_bounds__(256) void k_lcp_chunks(
-    Text t, const u64 *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
+    Text t, const u32 *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
     const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32,
     u8 *__restrict__ lcp, u32 *__restrict__ lcpu, Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
@@ -1080,7 +1110,9 @@ struct gtamd_esa_ctx {
   u32 sigma;
   int bits;                // 2 or 5
   u64 max_n, n, N;         // N = n + 1 entries
-  hipStream_t st;
+  hipStream_t st, st2;     // st2: table emission beside the refinement
+  hipEvent_t ev_sorted, ev_emitted;
+  u32 *isa_tmp;            // partitioned (position, head) pairs of the rank build
   // resident sequence
   u64 *tb_own, *sp_own;
   Text text;
@@ -1128,8 +1160,10 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c == nullptr) return;
   (void) hipSetDevice(c->device);
   if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
+  if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
   free_dev(c->tb_own); free_dev(c->sp_own);
   free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
+  free_dev(c->isa_tmp);
   free_dev(c->rws); free_dev(c->dig0); free_dev(c->dig1); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
   free_dev(c->llv); free_dev(c->tiebits); free_dev(c->d_stats);
   free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
@@ -1137,6 +1171,9 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
   for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
+  if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
+  if (c->ev_emitted != nullptr) (void) hipEventDestroy(c->ev_emitted);
+  if (c->st2 != nullptr) (void) hipStreamDestroy(c->st2);
   if (c->st != nullptr) (void) hipStreamDestroy(c->st);
   delete c;
 }
@@ -1178,6 +1215,9 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   const u64 N = max_n + 1;
   CTX_TRY(hipSetDevice(device));
   CTX_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+  CTX_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
   const u64 spw = c->bits == 2 ? 32 : 12;
   CTX_TRY(hipMalloc(&c->tb_own, (div_up(N, spw) + 2) * 8));
   CTX_TRY(hipMalloc(&c->sp_own, (div_up(N, 64) + 2) * 8));
@@ -1189,6 +1229,7 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   c->rws_words = radix_workspace_words(N) + 4 * (div_up(N, 64) + 64) +
                  scan_workspace_words(div_up(N, 64)) + 64;
   CTX_TRY(hipMalloc(&c->rws, c->rws_words * 4));
+  CTX_TRY(hipMalloc(&c->isa_tmp, Npad * 8));
   CTX_TRY(hipMalloc(&c->dig0, Npad));
   CTX_TRY(hipMalloc(&c->dig1, Npad));
   CTX_TRY(hipMalloc(&c->suf, Npad * 8));
@@ -1548,11 +1589,29 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     for (u32 r = 0; r < c->part; r++)
       if (all[2 * r] > 0) { prev_key = all[2 * r + 1]; has_prev = 1; }
   }
+  // Table emission (k_finalize, bandwidth-bound) runs on the second stream.
+  // It is started where the first stream turns latency-bound (the scatter of
+  // the rank table), so that the two actually overlap; whatever it writes for
+  // tied entries is provisional and overwritten after the join.
+  bool emitted = false;
+  auto launch_emission = [&]() -> int {
+    if (emitted) return 0;
+    emitted = true;
+    HIP_TRY(hipEventRecord(c->ev_sorted, st));
+    HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
+    if (NL > 0) {
+      k_finalize<BITS><<<(u32) div_up(NL, FIN_TILE), FIN_THREADS, 0, c->st2>>>(
+          skey, sa32, NL, prefixlength, want_suf ? c->suf : nullptr,
+          want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, nullptr,
+          c->d_stats, prev_key, has_prev, index_offset);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev_emitted, c->st2));
+    return 0;
+  };
   if (NL > 0) {
-    k_finalize<BITS><<<(u32) div_up(NL, FIN_TILE), FIN_THREADS, 0, st>>>(
-        skey, sa32, NL, prefixlength, want_suf ? c->suf : nullptr,
-        want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, c->tiebits,
-        c->d_stats, prev_key, has_prev, index_offset);
+    k_tiebits<BITS><<<(u32) div_up(NL, 4096), 256, 0, st>>>(skey, NL, c->tiebits,
+                                                           c->d_stats);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -1632,6 +1691,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         for (u32 r = 0; r < R; r++) small &= all[r];
       }
       if (small) {
+        TRY(launch_emission());
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));   // join the emission
         if (m0 > 0) {
           k_direct_ties<BITS><<<(u32) div_up(m0, 256), 256, 0, st>>>(
               c->text, uidx0, ugrp, m0, sa32, want_suf ? c->suf : nullptr,
@@ -1660,8 +1721,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     // there is one part); other parts' entries are never read here
     if (NL > 0) {
       u32 *heads = reinterpret_cast<u32 *>(fkey);          // free key buffer
-      u32 *ppos = reinterpret_cast<u32 *>(skey);           // sorted keys are
-      u32 *phead = ppos + NL;                              // no longer needed
+      u32 *ppos = c->isa_tmp, *phead = ppos + NL;          // (skey is still being
+                                                           // read by the emission)
       u32 *pws = scanws + scan_workspace_words(nwords) + 64;
       k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(c->tiebits, carry, NL,
                                                      (u32) index_offset, heads);
@@ -1674,6 +1735,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
       TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,
                                      &pwidth, 1, pws, st, nullptr, nullptr));
+      TRY(launch_emission());   // overlaps with the latency-bound scatter
       k_rank_scatter<<<(u32) div_up(NL, 1024), 256, 0, st>>>(ppos, phead, NL, rank);
       HIP_TRY(hipGetLastError());
     }
@@ -1747,7 +1809,10 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       h *= 2;
     }
     HIP_TRY(hipEventRecord(c->ev[5], st));
-    // ---- final entries of the tied suffixes
+    // ---- final entries of the tied suffixes (after the emission has
+    // written its provisional values)
+    TRY(launch_emission());
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
     u32 *lcpu = hv, *large = keep, *loff = koff, *tied = cval_b;
     const u32 g0 = (u32) div_up(m0, 256);
     if (m0 > 0) {
@@ -1763,7 +1828,10 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 m1 = c->h_stats->count;
-      k_lcp_pairs<<<g0, 256, 0, st>>>(tied, loff, uidx0, sa32, m0, ckey_a, cval_a);
+      // (text position, slot) pairs, 32-bit keys
+      u32 *pkey_a = reinterpret_cast<u32 *>(ckey_a), *pkey_b = reinterpret_cast<u32 *>(ckey_b);
+      u32 *pval_b = uidx2;   // the round buffers are free now
+      k_lcp_pairs<<<g0, 256, 0, st>>>(tied, loff, uidx0, sa32, m0, pkey_a, cval_a);
       HIP_TRY(hipGetLastError());
       int ps[8], pw[8], pn = 0;
       for (int b = 0; b < nb; b += 8) {
@@ -1771,10 +1839,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         pw[pn] = nb - b < 8 ? nb - b : 8;
         pn++;
       }
-      u32 *pval_b = uidx2;   // the round buffers are free now
-      TRY(radix_sort_pairs<u64, u32>(ckey_a, cval_a, ckey_b, pval_b, m1, ps, pw, pn,
-                                rws2, st, nullptr, nullptr));
-      const u64 *pk = (pn & 1) ? ckey_b : ckey_a;
+      TRY(radix_sort_pairs<u32, u32>(pkey_a, cval_a, pkey_b, pval_b, m1, ps, pw, pn,
+                                     rws2, st, nullptr, nullptr));
+      const u32 *pk = (pn & 1) ? pkey_b : pkey_a;
       const u32 *pv = (pn & 1) ? pval_b : cval_a;
       k_lcp_chunks<BITS><<<(u32) div_up(div_up(m1, LCP_CHUNK), 256), 256, 0, st>>>(
           c->text, pk, pv, m1, uidx0, sa32, c->lcp, lcpu, c->d_stats);
@@ -1802,6 +1869,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     }
     }  // !settled
   }
+  TRY(launch_emission());
+  HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
   HIP_TRY(hipEventRecord(c->ev[6], st));
   TRY(fetch_stats(c));
 

@@ -999,9 +999,8 @@ __global__ __launch_bounds__(256) void k_direct_ties(
 template <int BITS>
 __global__ __launch_bounds__(256) void k_fix_basic(
     Text t, const u32 *__restrict__ uidx0, u64 m0,
-    const u64 *__restrict__ tiebits, const u32 *__restrict__ sa32,
-    u64 *__restrict__ suf, u8 *__restrict__ bwt, u32 *__restrict__ tied,
-    u32 *__restrict__ lcpu, Stats *stats, u64 index_offset) {
+    const u32 *__restrict__ sa32, u64 *__restrict__ suf, u8 *__restrict__ bwt,
+    Stats *stats, u64 index_offset) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m0) return;
   const u64 i = uidx0[j];
@@ -1009,6 +1008,16 @@ __global__ __launch_bounds__(256) void k_fix_basic(
   if (suf != nullptr) suf[i] = p;
   if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
   if (p == 0) stats->longest = index_offset + i;
+}
+
+// which entries of the unresolved list are tied with their predecessor (need
+// a real LCP)
+__global__ __launch_bounds__(256) void k_tied_flags(
+    const u32 *__restrict__ uidx0, u64 m0, const u64 *__restrict__ tiebits,
+    u32 *__restrict__ tied, u32 *__restrict__ lcpu) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m0) return;
+  const u64 i = uidx0[j];
   tied[j] = (u32) ((tiebits[i >> 6] >> (i & 63)) & 1ull);
   lcpu[j] = 0;
 }
@@ -1816,9 +1825,16 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     u32 *lcpu = hv, *large = keep, *loff = koff, *tied = cval_b;
     const u32 g0 = (u32) div_up(m0, 256);
     if (m0 > 0) {
-      k_fix_basic<BITS><<<g0, 256, 0, st>>>(
-          c->text, uidx0, m0, c->tiebits, sa32, want_suf ? c->suf : nullptr,
-          want_bwt ? c->bwt : nullptr, tied, lcpu, c->d_stats, index_offset);
+      // .suf/.bwt of the tied entries: random accesses, on the second stream
+      // (behind the emission there) while this stream sorts the LCP pairs
+      HIP_TRY(hipEventRecord(c->ev_sorted, st));          // rounds are done
+      HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
+      k_fix_basic<BITS><<<g0, 256, 0, c->st2>>>(
+          c->text, uidx0, m0, sa32, want_suf ? c->suf : nullptr,
+          want_bwt ? c->bwt : nullptr, c->d_stats, index_offset);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->ev_emitted, c->st2));
+      k_tied_flags<<<g0, 256, 0, st>>>(uidx0, m0, c->tiebits, tied, lcpu);
       HIP_TRY(hipGetLastError());
     }
     if (want_lcp && m0 > 0) {

@@ -547,7 +547,10 @@ u64 radix_workspace_words(u64 n) {
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
 static bool g_xcd_remap = true;
 static int g_xcd_mode = 1;
-static bool g_no_digbytes = false;   // GTAMD_DIGBYTES=0
+// digit side arrays: opt-in (GTAMD_DIGBYTES=1).  Measured at 3 Gbp: the
+// histogram passes get 17 ms cheaper, but the byte stores cost the scatter
+// kernel 2 ms per pass, net -4.6 ms (1 %): not worth 2 B/pair of memory.
+static bool g_no_digbytes = true;
 static int g_rank_mode = 0;   // GTAMD_RANK_MODE
 // chained-scan scatter: opt-in (GTAMD_ONESWEEP=1).  Measured at 3 Gbp: the
 // look-back walks 39 tiles on average (status hop latency across XCDs x tile
@@ -568,7 +571,7 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     const char *r = getenv("GTAMD_RANK_MODE");
     g_rank_mode = (r != nullptr && r[0] == '1') ? 1 : 0;
     const char *db = getenv("GTAMD_DIGBYTES");
-    g_no_digbytes = db != nullptr && db[0] == '0';
+    g_no_digbytes = !(db != nullptr && db[0] == '1');
     const char *o = getenv("GTAMD_ONESWEEP");
     g_onesweep = o != nullptr && o[0] == '1';
     if (g_onesweep) g_no_digbytes = true;   // the chained kernel writes no digit bytes

@@ -142,6 +142,53 @@ class EsaEngine:
         return r
 
 
+class Sfxiterator:
+    """The reference's iterator seam on top of the one-shot engine
+    (src/match/sfx-suffixer.h:32-72): `next()` hands out the suffix array in
+    slices -- first all suffixes that start with a letter (what the reference
+    delivers part by part), then the suffixes that start with a special in
+    pages, `None` at the end (src/match/sfx-suffixer.c:2162-2198) -- and
+    `longest()` is the index of suffix 0.  Arguments keep the reference's
+    names; `readmode` must be 0 (forward), `numofparts`/`maximumspace` only
+    set the page size of the special tail: the whole table is resident."""
+
+    def __init__(self, encseq, readmode=0, prefixlength=0, numofparts=1,
+                 maximumspace=0, numofchars=4, device=0):
+        if readmode != 0:
+            raise EsaError("readmode %d is not supported by the MI355X engine "
+                           "(only forward)" % readmode)
+        enc = np.ascontiguousarray(encseq, dtype=np.uint8)
+        self._eng = EsaEngine(max(int(enc.size), 1), numofchars, device)
+        check(self._eng._lib.gtamd_esa_set_prefixlength(self._eng._ctx, prefixlength))
+        self._eng.set_sequence(enc)
+        self._eng.run(WANT_SUF)
+        n1 = int(enc.size) + 1
+        specials = int(np.count_nonzero(enc >= 254))
+        self._nonspecial = n1 - specials - 1
+        page = max(1, -(-self._nonspecial // max(1, numofparts)))
+        self._slices = [(0, self._nonspecial, False)] if self._nonspecial else []
+        first = self._nonspecial
+        while first < n1:
+            cnt = min(page, n1 - first)
+            self._slices.append((first, cnt, True))
+            first += cnt
+        self._next = 0
+
+    def next(self):
+        """(suffixsortspace slice, numberofsuffixes, specialsuffixes) or None"""
+        if self._next >= len(self._slices):
+            return None
+        first, cnt, special = self._slices[self._next]
+        self._next += 1
+        return self._eng.table(TAB_SUF, first, cnt), cnt, special
+
+    def longest(self):
+        return self._eng.stats()["longest"]
+
+    def delete(self):
+        self._eng.close()
+
+
 def suffixerator_tables(enc, numofchars=4, want=WANT_SUF | WANT_LCP | WANT_BWT,
                         device=0):
     """one-shot: encoded symbols in, EsaResult out"""

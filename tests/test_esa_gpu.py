@@ -169,3 +169,27 @@ def test_errors(gpu):
             eng.run()
     with pytest.raises(esa.EsaError, match="32-bit position"):
         esa.EsaEngine(1 << 32, 4)
+
+
+def test_sfxiterator_adapter(gpu):
+    """the reference's iterator call shape: slices concatenate to .suf, the
+    special tail comes in pages flagged `specialsuffixes`"""
+    e = GOLDEN["Atinsert.fna"]
+    enc = ou.encode_fasta(ou.fixture_path("Atinsert.fna"))
+    sfi = esa.Sfxiterator(enc, readmode=0, prefixlength=0, numofparts=3)
+    parts, flags = [], []
+    while True:
+        r = sfi.next()
+        if r is None:
+            break
+        tab, cnt, special = r
+        assert len(tab) == cnt
+        parts.append(tab)
+        flags.append(special)
+    assert flags[0] is False and all(flags[1:])
+    assert len(parts[0]) == 11817 + 1 - 2950 - 1       # non-special suffixes
+    assert _md5(np.concatenate(parts)) == e["tables"]["suf"]["md5"]
+    assert sfi.longest() == 2529
+    sfi.delete()
+    with pytest.raises(esa.EsaError, match="only forward"):
+        esa.Sfxiterator(enc, readmode=1)

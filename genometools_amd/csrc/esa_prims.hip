@@ -190,6 +190,10 @@ __device__ __forceinline__ u64 match_digit(u32 d) {
 // ballot match inside the wave + a per-wave running digit counter in LDS.
 // The tile is then staged in LDS in digit order and written out so that
 // neighbouring lanes write neighbouring addresses of the same digit run.
+// (Two other ranking schemes were measured in-process against this one at
+// 3 Gbp -- register ballots + pipelined LDS counter adds: 122 ms per 6 passes;
+// lane masks through LDS atomic-or: 110 ms; this one: 106.5 ms -- so ranking
+// is not what limits the kernel.)
 constexpr u32 OS_CHUNK = 8;
 constexpr u32 OS_AGG = 1u << 30, OS_INCL = 2u << 30, OS_VAL = (1u << 30) - 1u;
 constexpr u32 OS_SPIN_LIMIT = 1u << 21;
@@ -209,7 +213,7 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-template <typename K, typename V, int XCD, int RANKMODE>
+template <typename K, typename V, int XCD>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
     K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
@@ -252,28 +256,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   }
   __syncthreads();
   const u64 lt = (1ull << lane) - 1ull;
-  if (RANKMODE == 1) {
-    // ballots first (register only) ...
-    u32 npeer[RS_ITEMS];   // lanes of this wave with the same digit (leader only)
-#pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
-      const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
-      const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
-      const u64 m = match_digit(d);
-      const u32 intra = (u32) __popcll(m & lt);
-      rk[j] = (intra << 8) | d;
-      npeer[j] = intra == 0 ? (u32) __popcll(m) : 0u;   // lowest lane leads
-    }
-    // ... then the running per-wave digit counters: every lane reads the
-    // counter of its digit, the group's leader adds the group size.
-#pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
-      const u32 d = rk[j] & 255u;
-      const u32 old = s_cnt[w][d];
-      if (npeer[j]) atomicAdd(&s_cnt[w][d], npeer[j]);
-      rk[j] += old << 8;
-    }
-  } else {
+  {
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; j++) {
       const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
@@ -551,7 +534,6 @@ static int g_xcd_mode = 1;
 // histogram passes get 17 ms cheaper, but the byte stores cost the scatter
 // kernel 2 ms per pass, net -4.6 ms (1 %): not worth 2 B/pair of memory.
 static bool g_no_digbytes = true;
-static int g_rank_mode = 0;   // GTAMD_RANK_MODE
 // chained-scan scatter: opt-in (GTAMD_ONESWEEP=1).  Measured at 3 Gbp: the
 // look-back walks 39 tiles on average (status hop latency across XCDs x tile
 // rate), which eats most of what the saved histogram pass gives back: sort
@@ -568,8 +550,6 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     const char *e = getenv("GTAMD_XCD_REMAP");
     g_xcd_remap = !(e != nullptr && e[0] == '0');
     g_xcd_mode = (e != nullptr && e[0] == '2') ? 2 : 1;
-    const char *r = getenv("GTAMD_RANK_MODE");
-    g_rank_mode = (r != nullptr && r[0] == '1') ? 1 : 0;
     const char *db = getenv("GTAMD_DIGBYTES");
     g_no_digbytes = !(db != nullptr && db[0] == '1');
     const char *o = getenv("GTAMD_ONESWEEP");
@@ -658,16 +638,13 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
     if (g_xcd_mode == 2)
-      k_rs_scatter<K, V, 2, 0><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, 2><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else if (!g_xcd_remap)
-      k_rs_scatter<K, V, 0, 0><<<ntiles, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
-    else if (g_rank_mode == 1)
-      k_rs_scatter<K, V, 1, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, 0><<<ntiles, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else
-      k_rs_scatter<K, V, 1, 0><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      k_rs_scatter<K, V, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
           kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {

@@ -186,8 +186,51 @@ void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
   }
 }
 
+void gtamd_apply_readmode(uint8_t *enc, uint64_t n, int readmode)
+{
+  const int reverse = readmode == 1 || readmode == 3,
+            complement = readmode == 2 || readmode == 3;
+  if (reverse)
+    for (uint64_t a = 0, b = n; a + 1 < b; a++) {
+      const uint8_t t = enc[a];
+      b--;
+      enc[a] = enc[b];
+      enc[b] = t;
+    }
+  if (complement)
+    for (uint64_t i = 0; i < n; i++)
+      if (enc[i] < 4) enc[i] ^= 3;      /* a<->t, c<->g */
+}
+
+uint8_t *gtamd_mirror(const uint8_t *enc, uint64_t n)
+{
+  uint8_t *m = malloc(2 * n + 1);
+  if (m == NULL) return NULL;
+  memcpy(m, enc, n);
+  m[n] = GTAMD_SEPARATOR;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint8_t c = enc[n - 1 - i];
+    m[n + 1 + i] = c < 4 ? (uint8_t) (c ^ 3) : c;
+  }
+  return m;
+}
+
+void gtamd_seqstats_mirror(gtamd_seqstats *st, int last_symbol_is_wildcard)
+{
+  const uint64_t central = last_symbol_is_wildcard ? 0 : 2;   /* 2r-1 or 2r+1 */
+  st->totallength = 2 * st->totallength + 1;
+  st->specialcharacters = 2 * st->specialcharacters + 1;
+  st->specialranges = 2 * st->specialranges - 1 + central;
+  st->realspecialranges = 2 * st->realspecialranges - 1 + central;
+  st->wildcards *= 2;
+  st->wildcardranges *= 2;
+  st->realwildcardranges *= 2;
+  st->numofsequences *= 2;
+}
+
 int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
-                    const gtamd_esa_stats *es, int with_lcp)
+                    const gtamd_esa_stats *es, int with_lcp, int readmode,
+                    int mirrored)
 {
   FILE *fp = fopen(path, "wb");
   const unsigned long long n1 = es->numberofallsortedsuffixes;
@@ -212,6 +255,7 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
   fprintf(fp, "largelcpvalues=%llu\n", with_lcp ? (unsigned long long) es->largelcpvalues : 0ull);
   fprintf(fp, "averagelcp=%.2f\n", with_lcp ? (double) es->lcptabsum / (double) n1 : 0.0);
   fprintf(fp, "maxbranchdepth=%llu\n", with_lcp ? (unsigned long long) es->maxbranchdepth : 0ull);
-  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=0\nmirrored=0\n");
+  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=%d\nmirrored=%d\n",
+          readmode, mirrored ? 1 : 0);
   return fclose(fp) == 0 ? 0 : -1;
 }

@@ -60,7 +60,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
 {
   const char *db[MAXDB], *indexname = NULL;
   size_t numdb = 0;
-  int protein = 0, dna = 0, verbose = 0;
+  int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0;
   uint32_t want = 0, userpl = 0;
   char indexbuf[4096];
   uint8_t *enc = NULL;
@@ -91,8 +91,15 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       if (i + 1 < argc && argv[i + 1][0] != '-') userpl = (uint32_t) strtoul(argv[++i], NULL, 10);
     } else if (!strcmp(a, "-dir")) {
       if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "dir");
-      if (strcmp(argv[++i], "fwd") != 0)
-        return fail(err, errlen, "option -dir %s is not supported by the MI355X engine (only fwd)", argv[i]);
+      i++;
+      if (!strcmp(argv[i], "fwd")) readmode = 0;
+      else if (!strcmp(argv[i], "rev")) readmode = 1;
+      else if (!strcmp(argv[i], "cpl")) readmode = 2;
+      else if (!strcmp(argv[i], "rcl")) readmode = 3;
+      else
+        return fail(err, errlen, "argument to option -dir must be fwd or rev or cpl or rcl, not %s", argv[i]);
+    } else if (!strcmp(a, "-mirrored")) {
+      mirrored = 1;
     } else if (!strcmp(a, "-parts") || !strcmp(a, "-memlimit") || !strcmp(a, "-dc")) {
       /* space/strategy knobs of the CPU algorithm: the tables do not depend on
          them, the device build ignores them */
@@ -115,8 +122,22 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : db[0]);
     indexname = indexbuf;
   }
+  if (protein && (readmode >= 2 || mirrored))
+    /* wording of src/match/sfx-run.c:566-570 */
+    return fail(err, errlen, "option -%s only can be used for DNA alphabets",
+                mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
   if (gtamd_encode_files(db, numdb, protein, &enc, &n, err, errlen) != 0) return -1;
+  /* .prj describes the sequence as stored, the tables the sequence as read */
   gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
+  if (mirrored) {
+    uint8_t *m = gtamd_mirror(enc, n);
+    if (m == NULL) { free(enc); return fail(err, errlen, "out of memory (%s)", "-mirrored"); }
+    gtamd_seqstats_mirror(&ss, n > 0 && enc[n - 1] == GTAMD_WILDCARD);
+    free(enc);
+    enc = m;
+    n = 2 * n + 1;
+  }
+  gtamd_apply_readmode(enc, n, readmode);
   if (verbose) {
     printf("# totallength=%llu\n# specialcharacters=%llu\n# numofsequences=%llu\n",
            (unsigned long long) ss.totallength, (unsigned long long) ss.specialcharacters,
@@ -132,7 +153,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     char path[4096];
     free(enc);
     snprintf(path, sizeof path, "%s.prj", indexname);
-    if (gtamd_write_prj(path, &ss, &es, 0) != 0)
+    if (gtamd_write_prj(path, &ss, &es, 0, readmode, mirrored) != 0)
       return fail(err, errlen, "cannot open file '%s' for writing", path);
     return 0;
   }
@@ -160,7 +181,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   {
     char path[4096];
     snprintf(path, sizeof path, "%s.prj", indexname);
-    if (gtamd_write_prj(path, &ss, &es, (want & GTAMD_WANT_LCP) != 0) != 0) {
+    if (gtamd_write_prj(path, &ss, &es, (want & GTAMD_WANT_LCP) != 0, readmode, mirrored) != 0) {
       fail(err, errlen, "cannot open file '%s' for writing", path);
       goto done;
     }

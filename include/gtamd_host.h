@@ -44,14 +44,28 @@ int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                           gtamd_seqstats *st);
 
+/* The sequence as the reference reads it with -dir fwd|rev|cpl|rcl (readmode
+   0..3, src/core/readmode_api.h:24-27), in place; complement (3 - code) is
+   defined for DNA only, specials are their own complement. */
+void gtamd_apply_readmode(uint8_t *enc, uint64_t n, int readmode);
+
+/* -mirrored (src/core/encseq_api.h:190-198, encseq_options.c): sequence +
+   separator + its reverse complement, 2n+1 symbols, malloc'ed; and the
+   statistics a mirrored GtEncseq reports, from those of the original
+   (src/core/encseq.c:4960-5054). */
+uint8_t *gtamd_mirror(const uint8_t *enc, uint64_t n);
+void gtamd_seqstats_mirror(gtamd_seqstats *st, int last_symbol_is_wildcard);
+
 /* INDEX.prj; with_lcp == 0 writes the zero LCP statistics the reference
    writes when -lcp was not requested (src/match/sfx-run.c:664-670) */
 int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
-                    const gtamd_esa_stats *es, int with_lcp);
+                    const gtamd_esa_stats *es, int with_lcp, int readmode,
+                    int mirrored);
 
 /* `gt suffixerator` for the option subset of this path:
      -db FILE...  -indexname NAME  -dna | -protein  -suf -lcp -bwt
-     -pl [K]  -v  -dir fwd   and, accepted without effect on the tables,
+     -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored   and, accepted without
+     effect on the tables,
      -parts N  -memlimit X  -dc V  -tis -des -sds -ssp -md5 [yes|no]
    argv[0] is the tool name.  Returns 0, or -1 with the message in err (the
    caller prints "gt suffixerator: error: <err>" and exits 1, src/gt.c:48-52). */

@@ -103,6 +103,32 @@ emptyseq:
   return 0;
 }
 
+/* readmodes: src/core/readmode_api.h:24-27; complement of a DNA code is
+   3 - code (a<->t, c<->g), specials are their own complement */
+void ora_apply_readmode(uint8_t *enc, uint64_t n, int readmode)
+{
+  uint64_t i;
+  if (readmode == 1 || readmode == 3)
+    for (i = 0; i < n / 2; i++) {
+      uint8_t t = enc[i]; enc[i] = enc[n - 1 - i]; enc[n - 1 - i] = t;
+    }
+  if (readmode == 2 || readmode == 3)
+    for (i = 0; i < n; i++) if (enc[i] < 4) enc[i] = (uint8_t) (3 - enc[i]);
+}
+
+uint8_t *ora_mirror(const uint8_t *enc, uint64_t n)
+{
+  uint8_t *m = malloc(2 * n + 1);
+  uint64_t i;
+  memcpy(m, enc, n);
+  m[n] = ORA_SEPARATOR;
+  for (i = 0; i < n; i++) {
+    uint8_t c = enc[n - 1 - i];
+    m[n + 1 + i] = c < 4 ? (uint8_t) (3 - c) : c;
+  }
+  return m;
+}
+
 /* ------------------------------------------------------------------ */
 /* range bookkeeping: src/core/encseq.c:5061-5074 */
 static uint64_t stored_ranges(uint64_t len, uint64_t maxrangevalue)
@@ -188,6 +214,23 @@ void ora_seqstats_compute(const uint8_t *enc, uint64_t n, uint32_t numofchars,
       }
     }
   }
+}
+
+void ora_seqstats_mirror(ora_seqstats *st, int last_symbol_is_wildcard)
+{
+  st->totallength = 2 * st->totallength + 1;
+  st->specialcharacters = 2 * st->specialcharacters + 1;
+  if (last_symbol_is_wildcard) {
+    st->specialranges = 2 * st->specialranges - 1;
+    st->realspecialranges = 2 * st->realspecialranges - 1;
+  } else {
+    st->specialranges = 2 * st->specialranges + 1;
+    st->realspecialranges = 2 * st->realspecialranges + 1;
+  }
+  st->wildcards *= 2;
+  st->wildcardranges *= 2;
+  st->realwildcardranges *= 2;
+  st->numofsequences *= 2;
 }
 
 /* ------------------------------------------------------------------ */
@@ -387,7 +430,8 @@ int ora_check_suffix_array(const uint8_t *enc, uint64_t n, const uint64_t *sa,
 
 /* src/match/sfx-outprj.c:38-83 */
 int ora_write_prj(const char *path, const ora_seqstats *ss,
-                  const ora_esastats *es, int with_lcp)
+                  const ora_esastats *es, int with_lcp, int readmode,
+                  int mirrored)
 {
   FILE *fp = fopen(path, "wb");
   if (fp == NULL) return -1;
@@ -412,7 +456,8 @@ int ora_write_prj(const char *path, const ora_seqstats *ss,
                    : 0.0);
   fprintf(fp, "maxbranchdepth=%llu\n",
           (unsigned long long) (with_lcp ? es->maxbranchdepth : 0));
-  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=0\nmirrored=0\n");
+  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=%d\nmirrored=%d\n",
+          readmode, mirrored);
   fclose(fp);
   return 0;
 }

@@ -45,10 +45,25 @@ typedef struct {
 int ora_encode_fasta(const char *path, int protein, uint8_t **enc,
                      uint64_t *n, char *err, size_t errlen);
 
+/* readmode 0 forward, 1 reverse, 2 complement, 3 reverse complement
+   (src/core/readmode_api.h:24-27): the sequence as the reference reads it in
+   that mode, in place.  Complement only for DNA (3 - code), specials stay. */
+void ora_apply_readmode(uint8_t *enc, uint64_t n, int readmode);
+/* -mirrored (src/core/encseq_api.h:190-198): enc + separator + reverse
+   complement of enc; returns a malloc'ed sequence of 2n+1 symbols */
+uint8_t *ora_mirror(const uint8_t *enc, uint64_t n);
+
 /* statistics of the encoded sequence that go into .prj */
 void ora_seqstats_compute(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                           uint64_t lengthofdbfilenames, uint64_t numofdbfiles,
                           ora_seqstats *st);
+
+/* statistics a mirrored encseq reports, from those of the original sequence
+   (src/core/encseq.c:4960-5054): doubled counts, +1 for the central separator,
+   and one range less when the original ends with a wildcard (it merges with
+   the central separator; encseq.c:4970-4976 tests position totallength-1 of
+   the unmirrored sequence); prefix/suffix lengths stay those of the original */
+void ora_seqstats_mirror(ora_seqstats *st, int last_symbol_is_wildcard);
 
 /* gt_recommendedprefixlength restated */
 uint32_t ora_recommended_prefixlength(uint32_t numofchars, uint64_t n);
@@ -84,7 +99,8 @@ int ora_check_suffix_array(const uint8_t *enc, uint64_t n, const uint64_t *sa,
 
 /* write NAME.prj exactly as sfx-outprj.c:38-83 does */
 int ora_write_prj(const char *path, const ora_seqstats *ss,
-                  const ora_esastats *es, int with_lcp);
+                  const ora_esastats *es, int with_lcp, int readmode,
+                  int mirrored);
 
 #ifdef __cplusplus
 }

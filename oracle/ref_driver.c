@@ -19,6 +19,7 @@
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
   usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
+                    [-dir fwd|rev|cpl|rcl] [-mirrored]
                     -db FASTA -indexname IDX [-time]
 */
 #include <stdio.h>
@@ -66,7 +67,8 @@ int main(int argc, char **argv)
 {
   const char *db = NULL, *indexname = NULL;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
-       showtime = false, haserr = false;
+       showtime = false, haserr = false, mirrored = false;
+  GtReadmode readmode = GT_READMODE_FORWARD;
   unsigned int userpl = 0, dc = 0, prefixlength, numofchars;
   int i;
   GtError *err;
@@ -89,6 +91,13 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-lcp")) want_lcp = true;
     else if (!strcmp(argv[i], "-bwt")) want_bwt = true;
     else if (!strcmp(argv[i], "-time")) showtime = true;
+    else if (!strcmp(argv[i], "-mirrored")) mirrored = true;
+    else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
+      const char *d = argv[++i];
+      readmode = !strcmp(d, "rev") ? GT_READMODE_REVERSE
+               : !strcmp(d, "cpl") ? GT_READMODE_COMPL
+               : !strcmp(d, "rcl") ? GT_READMODE_REVCOMPL : GT_READMODE_FORWARD;
+    }
     else if (!strcmp(argv[i], "-pl") && i + 1 < argc)
       userpl = (unsigned int) atoi(argv[++i]);
     else if (!strcmp(argv[i], "-dc") && i + 1 < argc)
@@ -129,6 +138,7 @@ int main(int argc, char **argv)
     gt_encseq_loader_do_not_require_des_tab(el);
     gt_encseq_loader_do_not_require_sds_tab(el);
     gt_encseq_loader_do_not_require_ssp_tab(el);
+    if (mirrored) gt_encseq_loader_mirror(el);   /* src/core/encseq_options.c -mirrored */
     encseq = gt_encseq_loader_load(el, indexname, err);
     gt_encseq_loader_delete(el);
     if (encseq == NULL) haserr = true;
@@ -160,7 +170,7 @@ int main(int argc, char **argv)
   longest.valueunsignedlong = 0;
   sfi = haserr ? NULL
                : gt_Sfxiterator_new_withadditionalvalues(encseq,
-                     GT_READMODE_FORWARD, prefixlength, 1U, 0UL, outlcpinfo,
+                     readmode, prefixlength, 1U, 0UL, outlcpinfo,
                      NULL, &strategy, NULL, false, NULL, err);
   if (sfi == NULL) haserr = true;
   while (!haserr) {
@@ -178,7 +188,7 @@ int main(int argc, char **argv)
         GtUchar cc = startpos == 0
                        ? (GtUchar) UNDEFBWTCHAR
                        : gt_encseq_get_encoded_char(encseq, startpos - 1,
-                                                    GT_READMODE_FORWARD);
+                                                    readmode);
         fputc((int) cc, fpbwt);
       }
     }
@@ -201,7 +211,7 @@ int main(int argc, char **argv)
       averagelcp = gt_Outlcpinfo_lcptabsum(outlcpinfo) /
                    numberofallsortedsuffixes;
     }
-    if (gt_outprjfile(indexname, GT_READMODE_FORWARD, encseq,
+    if (gt_outprjfile(indexname, readmode, encseq,
                       numberofallsortedsuffixes, prefixlength,
                       numoflargelcpvalues, averagelcp, maxbranchdepth,
                       &longest, err) != 0)

@@ -41,6 +41,12 @@ DNA = ["Arabidopsis-C99826.fna", "Atinsert.fna",
        "Small.fna", "Smalldup.fna", "TTT-small.fna", "trna_glutamine.fna",
        "Verysmall.fna"]
 PROTEIN = ["sw100K1.fsa", "sw100K2.fsa"]
+# readmode / mirror variants (testsuite/gt_suffixerator_include.rb:17-56 -dir,
+# :464-487 -mirrored) on a few fixtures; keys "<name>|<dir>|<mirrored>"
+VARIANT_FILES = ["Atinsert.fna", "Duplicate.fna", "RandomN.fna", "TTTN.fna",
+                 "Small.fna", "Verysmall.fna", "Reads1.fna"]
+VARIANTS = [("rev", False), ("cpl", False), ("rcl", False), ("fwd", True),
+            ("rcl", True)]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -87,6 +93,24 @@ def main():
                         fo.write(fi.read())
         golden[name] = entry
         print(name, entry["tables"]["suf"]["md5"])
+    variants = {}
+    for name in VARIANT_FILES:
+        src = os.path.join(REF, "testdata", name)
+        for d, mir in VARIANTS:
+            with tempfile.TemporaryDirectory() as tmp:
+                idx = os.path.join(tmp, "idx")
+                cmd = [BIN, "-dna", "-suf", "-lcp", "-bwt", "-dir", d, "-db", src,
+                       "-indexname", idx] + (["-mirrored"] if mir else [])
+                subprocess.run(cmd, check=True)
+                entry = {"tables": {}}
+                for ext in ("suf", "lcp", "llv", "bwt"):
+                    pth = idx + "." + ext
+                    entry["tables"][ext] = {"md5": md5(pth), "bytes": os.path.getsize(pth)}
+                with open(idx + ".prj") as f:
+                    entry["prj"] = f.read()
+            variants["%s|%s|%d" % (name, d, int(mir))] = entry
+    with open(os.path.join(OUT, "golden_variants.json"), "w") as f:
+        json.dump(variants, f, indent=1, sort_keys=True)
     with open(os.path.join(OUT, "golden.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
 

@@ -59,3 +59,21 @@ def test_cli_error_exit_code_and_message(cli, tmp_path):
                         str(tmp_path / "i")], capture_output=True, text=True)
     assert r.returncode == 1
     assert r.stderr.startswith("gt suffixerator: error: illegal character 'X': file \"")
+
+
+VARIANTS = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_variants.json")))
+
+
+@pytest.mark.parametrize("key", sorted(VARIANTS))
+def test_cli_readmodes_and_mirror(cli, key, tmp_path):
+    name, d, mir = key.split("|")
+    e = VARIANTS[key]
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-dir", d, "-db",
+                    ou.fixture_path(name), "-indexname", idx] +
+                   (["-mirrored"] if mir == "1" else []), check=True)
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    with open(idx + ".prj") as f:
+        assert f.read() == e["prj"]

@@ -35,7 +35,12 @@ def host():
     L.gtamd_sequence_stats.argtypes = [P, ctypes.c_uint64, ctypes.c_uint32,
                                        ctypes.POINTER(SeqStats)]
     L.gtamd_write_prj.argtypes = [ctypes.c_char_p, ctypes.POINTER(SeqStats),
-                                  ctypes.POINTER(EsaStats), ctypes.c_int]
+                                  ctypes.POINTER(EsaStats), ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_int]
+    L.gtamd_apply_readmode.argtypes = [P, ctypes.c_uint64, ctypes.c_int]
+    L.gtamd_mirror.restype = P
+    L.gtamd_mirror.argtypes = [P, ctypes.c_uint64]
+    L.gtamd_seqstats_mirror.argtypes = [ctypes.POINTER(SeqStats), ctypes.c_int]
     L.gtamd_suffixerator.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
                                      ctypes.c_char_p, ctypes.c_size_t]
     return L
@@ -78,7 +83,7 @@ def test_encoder_and_prj_match_reference(host, name, tmp_path):
                   maxbranchdepth=ora["maxbranchdepth"], lcptabsum=int(ora["lcptabsum"]),
                   prefixlength=ora["prefixlength"])
     out = str(tmp_path / "x.prj")
-    assert host.gtamd_write_prj(out.encode(), ctypes.byref(ss), ctypes.byref(es), 1) == 0
+    assert host.gtamd_write_prj(out.encode(), ctypes.byref(ss), ctypes.byref(es), 1, 0, 0) == 0
     with open(out) as f:
         assert f.read() == e["prj"]
 
@@ -119,7 +124,49 @@ def test_tool_argument_errors(host):
     assert run("-suf") == (-1, 'option "-db" is mandatory')
     rc, msg = run("-db", "a.fna", "b.fna", "-suf")
     assert rc == -1 and "option -indexname is mandatory" in msg
-    rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-dir", "rev", "-suf")
-    assert rc == -1 and "-dir rev is not supported" in msg
+    rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-dir", "sideways", "-suf")
+    assert rc == -1 and "must be fwd or rev or cpl or rcl" in msg
+    rc, msg = run("-protein", "-db", ou.fixture_path("sw100K1.fsa"), "-dir", "rcl", "-suf")
+    assert (rc, msg) == (-1, "option -rcl only can be used for DNA alphabets")
     rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-frobnicate")
     assert rc == -1 and "unknown option" in msg
+
+
+VARIANTS = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_variants.json")))
+
+
+@pytest.mark.parametrize("key", sorted(VARIANTS))
+def test_readmodes_and_mirror_match_reference(host, key, tmp_path):
+    """-dir rev|cpl|rcl and -mirrored (testsuite/gt_suffixerator_include.rb:17-56,
+    464-487): the host layer's sequence transforms + statistics, with the
+    tables the oracle derives from the transformed sequence, reproduce the
+    reference's files"""
+    import hashlib
+    name, d, mir = key.split("|")
+    e = VARIANTS[key]
+    readmode = {"fwd": 0, "rev": 1, "cpl": 2, "rcl": 3}[d]
+    enc = _encode(host, [ou.fixture_path(name)])
+    ss = SeqStats()
+    host.gtamd_sequence_stats(enc.ctypes.data, enc.size, 4, ctypes.byref(ss))
+    if mir == "1":
+        ptr = host.gtamd_mirror(enc.ctypes.data, enc.size)
+        host.gtamd_seqstats_mirror(ctypes.byref(ss), int(enc.size > 0 and enc[-1] == 254))
+        m = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                  shape=(2 * enc.size + 1,)).copy()
+        ctypes.CDLL(None).free(ctypes.c_void_p(ptr))
+        enc = m
+    enc = np.ascontiguousarray(enc)
+    host.gtamd_apply_readmode(enc.ctypes.data, enc.size, readmode)
+    ora = ou.esa(enc, 4)
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        assert hashlib.md5(np.ascontiguousarray(ora[ext]).tobytes()).hexdigest() == e["tables"][ext]["md5"], ext
+    st = ora["stats"]
+    es = EsaStats(totallength=enc.size, numberofallsortedsuffixes=enc.size + 1,
+                  longest=st["longest"], largelcpvalues=st["largelcpvalues"],
+                  maxbranchdepth=st["maxbranchdepth"], lcptabsum=int(st["lcptabsum"]),
+                  prefixlength=st["prefixlength"])
+    out = str(tmp_path / "x.prj")
+    assert host.gtamd_write_prj(out.encode(), ctypes.byref(ss), ctypes.byref(es), 1,
+                                readmode, int(mir)) == 0
+    with open(out) as f:
+        assert f.read() == e["prj"]

@@ -43,73 +43,209 @@ static int is_blank(int c)
   return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
 }
 
+/* whole file in memory (inputs of this layer are files the caller named; the
+   device path dominates for anything large) */
+static int slurp(const char *path, unsigned char **data, size_t *len)
+{
+  FILE *fp = fopen(path, "rb");
+  size_t cap = 1 << 16, n = 0, got;
+  unsigned char *buf;
+  if (fp == NULL) return -1;
+  buf = malloc(cap);
+  while (buf != NULL && (got = fread(buf + n, 1, cap - n, fp)) > 0) {
+    n += got;
+    if (n == cap) {
+      unsigned char *nb = realloc(buf, cap * 2);
+      if (nb == NULL) { free(buf); buf = NULL; break; }
+      buf = nb; cap *= 2;
+    }
+  }
+  fclose(fp);
+  if (buf == NULL) return -2;
+  *data = buf; *len = n;
+  return 0;
+}
+
+typedef struct {
+  const uint8_t *map;
+  bytebuf *out;
+  int seen_record;       /* any sequence so far, over all files */
+  uint64_t seqlen;       /* symbols of the FASTA sequence being read */
+} encstate;
+
+/* (multi-)FASTA, src/core/sequence_buffer_fasta.c:44-170 */
+static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
+                       size_t len, char *err, size_t errlen)
+{
+  uint64_t line = 1;
+  int in_header = 0;
+  for (size_t i = 0; i < len; i++) {
+    const int c = d[i];
+    if (in_header) {
+      if (c == '\n') { line++; in_header = 0; }
+      continue;
+    }
+    if (c == '\n') line++;
+    if (is_blank(c)) continue;
+    if (c == '>') {
+      if (st->seen_record) {
+        if (st->seqlen == 0) {
+          snprintf(err, errlen, "file '%s' contains an empty sequence", path);
+          return -1;
+        }
+        if (bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
+        st->seqlen = 0;
+      }
+      st->seen_record = 1;
+      in_header = 1;
+      continue;
+    }
+    if (st->map[c] == SYM_UNDEF) {
+      snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu", c,
+               path, (unsigned long long) line);
+      return -1;
+    }
+    if (bb_push(st->out, st->map[c]) != 0) goto nomem;
+    st->seqlen++;
+  }
+  return 0;
+nomem:
+  snprintf(err, errlen, "out of memory while reading '%s'", path);
+  return -1;
+}
+
+/* FASTQ, block grammar of src/core/seq_iterator_fastq.c:96-305: "@name",
+   sequence lines up to a '+', "+[name]", then exactly as many quality
+   characters as the sequence has symbols (over any number of lines) */
+static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
+                       size_t len, char *err, size_t errlen)
+{
+  size_t i = 0;
+  uint64_t line = 1;
+  while (i < len) {
+    size_t name0, name1, nsym = 0, nq = 0, q0, q1;
+    if (d[i] != '@') {
+      snprintf(err, errlen, "'@' expected, '%c' encountered instead in line %llu",
+               d[i], (unsigned long long) line);
+      return -1;
+    }
+    name0 = ++i;
+    while (i < len && d[i] != '\n') i++;
+    if (i >= len) goto premature;
+    name1 = i++; line++;
+    if (st->seen_record && bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
+    st->seen_record = 1;
+    for (; i < len && d[i] != '+'; i++) {
+      const int c = d[i];
+      if (c == '\n') { line++; continue; }
+      if (c == ' ') continue;
+      if (st->map[c] == SYM_UNDEF) {
+        /* the reference maps the sequence after it has read it completely */
+        uint64_t l2 = line;
+        for (size_t k = i; k < len && d[k] != '+'; k++) l2 += d[k] == '\n';
+        snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu", c,
+                 path, (unsigned long long) l2);
+        return -1;
+      }
+      if (bb_push(st->out, st->map[c]) != 0) goto nomem;
+      nsym++;
+    }
+    if (i >= len) goto premature;
+    if (nsym == 0) {
+      snprintf(err, errlen, "empty sequence given in file '%s', line %llu", path,
+               (unsigned long long) (line - 1));
+      return -1;
+    }
+    q0 = ++i;                                   /* behind the '+' */
+    while (i < len && d[i] != '\n') i++;
+    if (i >= len) goto premature;
+    q1 = i++; line++;
+    if (q1 > q0 && (q1 - q0 != name1 - name0 || memcmp(d + q0, d + name0, q1 - q0) != 0)) {
+      snprintf(err, errlen, "sequence description '%.*s' is not equal to qualities "
+               "description '%.*s' in line %llu", (int) (name1 - name0), d + name0,
+               (int) (q1 - q0), d + q0, (unsigned long long) (line - 1));
+      return -1;
+    }
+    while (nq < nsym) {
+      if (i >= len) {
+        /* the reference notices the short quality string first
+           (src/core/seq_iterator_fastq.c:297-304) */
+        snprintf(err, errlen, "lengths of character sequence and qualities sequence "
+                 "differ (%llu <-> %llu)", (unsigned long long) nq,
+                 (unsigned long long) nsym);
+        return -1;
+      }
+      if (d[i] == '\n') line++;
+      else if (d[i] != ' ') nq++;
+      i++;
+    }
+    if (i >= len) goto premature;
+    if (d[i] != '\n') {
+      snprintf(err, errlen, "qualities string of sequence length %llu is not ended "
+               "by newline in file '%s', line %llu -- this may be a sign for sequence "
+               "and qualities strings of different length", (unsigned long long) nsym,
+               path, (unsigned long long) line);
+      return -1;
+    }
+    i++; line++;
+  }
+  return 0;
+premature:
+  snprintf(err, errlen, "premature end of file '%s' in line %llu: file ended before "
+           "end of block", path, (unsigned long long) (line - 1));
+  return -1;
+nomem:
+  snprintf(err, errlen, "out of memory while reading '%s'", path);
+  return -1;
+}
+
 int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
                        uint8_t **enc, uint64_t *n, char *err, size_t errlen)
 {
   uint8_t map[256];
   bytebuf out = {NULL, 0, 0};
-  int seen_header = 0;           /* any '>' so far, over all files */
-  uint64_t seqlen = 0;           /* symbols of the sequence being read */
-  static unsigned char buf[1 << 16];
+  encstate st = {map, &out, 0, 0};
+  int last_was_fasta = 1;
 
   build_symbolmap(map, protein);
   for (size_t f = 0; f < numfiles; f++) {
-    FILE *fp = fopen(paths[f], "rb");
-    uint64_t line = 1;
-    int in_header = 0;
-    size_t got;
-    if (fp == NULL) {
-      snprintf(err, errlen, "cannot open file '%s'", paths[f]);
+    unsigned char *data = NULL;
+    size_t len = 0;
+    int rc = slurp(paths[f], &data, &len);
+    if (rc != 0) {
+      snprintf(err, errlen, rc == -1 ? "cannot open file '%s'"
+                                     : "out of memory while reading '%s'", paths[f]);
       free(out.p);
       return -1;
     }
-    while ((got = fread(buf, 1, sizeof buf, fp)) > 0) {
-      for (size_t i = 0; i < got; i++) {
-        const int c = buf[i];
-        if (in_header) {
-          if (c == '\n') { line++; in_header = 0; }
-          continue;
-        }
-        if (c == '\n') line++;
-        if (is_blank(c)) continue;
-        if (c == '>') {
-          if (seen_header) {
-            if (seqlen == 0) {
-              snprintf(err, errlen, "file '%s' contains an empty sequence", paths[f]);
-              goto fail;
-            }
-            if (bb_push(&out, GTAMD_SEPARATOR) != 0) goto nomem;
-            seqlen = 0;
-          }
-          seen_header = 1;
-          in_header = 1;
-          continue;
-        }
-        if (map[c] == SYM_UNDEF) {
-          snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu",
-                   c, paths[f], (unsigned long long) line);
-          goto fail;
-        }
-        if (bb_push(&out, map[c]) != 0) goto nomem;
-        seqlen++;
+    /* format by the first character, as the reference guesses it
+       (src/core/sequence_buffer.c) */
+    if (len > 0 && data[0] == '@') {
+      /* a FASTQ file always ends a record: the next file starts a new one */
+      if (st.seen_record && last_was_fasta && st.seqlen == 0) rc = -3;
+      else rc = parse_fastq(&st, paths[f], data, len, err, errlen);
+      last_was_fasta = 0;
+      st.seqlen = 1;
+    } else {
+      if (st.seen_record && !last_was_fasta) {
+        /* FASTA after FASTQ: its first '>' must emit the separator */
+        st.seqlen = 1;
       }
+      rc = parse_fasta(&st, paths[f], data, len, err, errlen);
+      last_was_fasta = 1;
     }
-    fclose(fp);
-    continue;
-nomem:
-    snprintf(err, errlen, "out of memory while reading '%s'", paths[f]);
-fail:
-    fclose(fp);
-    free(out.p);
-    return -1;
+    free(data);
+    if (rc == -3)
+      snprintf(err, errlen, "file '%s' contains an empty sequence", paths[f]);
+    if (rc != 0) { free(out.p); return -1; }
   }
-  if (!seen_header) {
+  if (!st.seen_record) {
     snprintf(err, errlen, "no sequences in multiple fasta file(s) %s ...",
              numfiles ? paths[0] : "");
     free(out.p);
     return -1;
   }
-  if (seqlen == 0) {
+  if (last_was_fasta && st.seqlen == 0) {
     snprintf(err, errlen, "file '%s' contains an empty sequence", paths[numfiles - 1]);
     free(out.p);
     return -1;

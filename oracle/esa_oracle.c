@@ -57,6 +57,49 @@ int ora_encode_fasta(const char *path, int protein, uint8_t **encout,
   }
   if (protein) protein_symbolmap(map); else dna_symbolmap(map);
   enc = malloc(cap);
+  c = fgetc(fp);
+  if (c != EOF) ungetc(c, fp);
+  if (c == '@') {
+    /* FASTQ blocks, src/core/seq_iterator_fastq.c:96-305: "@name", sequence
+       up to '+', "+[name]", as many quality characters as symbols */
+    for (;;) {
+      uint64_t nsym = 0, nq = 0;
+      c = fgetc(fp);
+      if (c == EOF) break;
+      if (c != '@') goto fastqerr;
+      while ((c = fgetc(fp)) != EOF && c != '\n') ;
+      if (c == EOF) goto fastqerr;
+      if (!first) { if (n + 1 >= cap) { cap *= 2; enc = realloc(enc, cap); } enc[n++] = ORA_SEPARATOR; }
+      first = 0;
+      while ((c = fgetc(fp)) != EOF && c != '+') {
+        if (c == '\n' || c == ' ') continue;
+        if (map[c & 255] == 253) {
+          snprintf(err, errlen, "illegal character '%c': file \"%s\"", c, path);
+          free(enc); fclose(fp);
+          return -1;
+        }
+        if (n + 1 >= cap) { cap *= 2; enc = realloc(enc, cap); }
+        enc[n++] = map[c & 255];
+        nsym++;
+      }
+      if (c == EOF || nsym == 0) goto fastqerr;
+      while ((c = fgetc(fp)) != EOF && c != '\n') ;
+      while (nq < nsym && (c = fgetc(fp)) != EOF)
+        if (c != '\n' && c != ' ') nq++;
+      if (nq < nsym || fgetc(fp) != '\n') goto fastqerr;
+    }
+    fclose(fp);
+    if (first) goto fastqerr2;
+    *encout = enc;
+    *nout = n;
+    return 0;
+fastqerr:
+    fclose(fp);
+fastqerr2:
+    snprintf(err, errlen, "malformed FASTQ file '%s'", path);
+    free(enc);
+    return -1;
+  }
   while ((c = fgetc(fp)) != EOF) {
     if (indesc) {
       if (c == '\n') { line++; indesc = 0; }

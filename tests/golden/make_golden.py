@@ -41,6 +41,9 @@ DNA = ["Arabidopsis-C99826.fna", "Atinsert.fna",
        "Small.fna", "Smalldup.fna", "TTT-small.fna", "trna_glutamine.fna",
        "Verysmall.fna"]
 PROTEIN = ["sw100K1.fsa", "sw100K2.fsa"]
+# FASTQ inputs of the suite (testsuite/gt_suffixerator_include.rb:157-160)
+FASTQ = ["fastq_long.fastq", "test10_multiline.fastq", "test1.fastq",
+         "test5_tricky.fastq"]
 # readmode / mirror variants (testsuite/gt_suffixerator_include.rb:17-56 -dir,
 # :464-487 -mirrored) on a few fixtures; keys "<name>|<dir>|<mirrored>"
 VARIANT_FILES = ["Atinsert.fna", "Duplicate.fna", "RandomN.fna", "TTTN.fna",
@@ -65,7 +68,7 @@ def main():
     os.makedirs(os.path.join(OUT, "fixtures"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "tables"), exist_ok=True)
     golden = {}
-    for name, flag in [(f, "-dna") for f in DNA] + [(f, "-protein") for f in PROTEIN]:
+    for name, flag in [(f, "-dna") for f in DNA + FASTQ] + [(f, "-protein") for f in PROTEIN]:
         src = os.path.join(REF, "testdata", name)
         if not os.path.exists(src):
             print("missing", src)

@@ -170,3 +170,22 @@ def test_readmodes_and_mirror_match_reference(host, key, tmp_path):
                                 readmode, int(mir)) == 0
     with open(out) as f:
         assert f.read() == e["prj"]
+
+
+def test_fastq_errors_use_the_reference_wording(host, tmp_path):
+    """messages of src/core/seq_iterator_fastq.c, checked against the reference
+    binary when this test was written"""
+    p = tmp_path / "e.fastq"
+    cases = [("@a\nACGT\n+\nIIII\nX\n", "'@' expected, 'X' encountered instead in line 5"),
+             ("@a\nACGT\n+\nII", r"lengths of character sequence and qualities sequence differ \(2 <-> 4\)"),
+             ("@a\n\n+\n\n", "empty sequence given in file '.*e.fastq', line 2"),
+             ("@a\nACGT\n+b\nIIII\n", "sequence description 'a' is not equal to qualities description 'b' in line 3"),
+             ("@a\nACGT\n+\nIIIII\n", "qualities string of sequence length 4 is not ended by newline in file '.*e.fastq', line 4"),
+             ("@a\nACXT\n+\nIIII\n", "illegal character 'X': file \".*e.fastq\"")]
+    for text, pattern in cases:
+        p.write_text(text)
+        with pytest.raises(ValueError, match=pattern):
+            _encode(host, [str(p)])
+    p.write_text("@r1\nACGT\nAC\n+r1\nII\nII@+\n@r2\nNNA\n+\n@@@\n")
+    enc = _encode(host, [str(p)])
+    assert enc.tolist() == [0, 1, 2, 3, 0, 1, 255, 254, 254, 0]

@@ -1,6 +1,7 @@
 /* encseq_host.c -- FASTA reading, symbol encoding and sequence statistics of
    the host layer (see include/gtamd_host.h for the reference interfaces). */
 #include "gtamd_host.h"
+#include "gtamd_md5.h"
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -69,6 +70,7 @@ static int slurp(const char *path, unsigned char **data, size_t *len)
 typedef struct {
   const uint8_t *map;
   bytebuf *out;
+  bytebuf *desc;         /* NUL-separated descriptions, or NULL */
   int seen_record;       /* any sequence so far, over all files */
   uint64_t seqlen;       /* symbols of the FASTA sequence being read */
 } encstate;
@@ -82,7 +84,11 @@ static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
   for (size_t i = 0; i < len; i++) {
     const int c = d[i];
     if (in_header) {
-      if (c == '\n') { line++; in_header = 0; }
+      if (c == '\n') {
+        line++; in_header = 0;
+        if (st->desc != NULL && bb_push(st->desc, 0) != 0) goto nomem;
+      } else if (c != '\r' && st->desc != NULL && bb_push(st->desc, (uint8_t) c) != 0)
+        goto nomem;
       continue;
     }
     if (c == '\n') line++;
@@ -133,6 +139,11 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
     while (i < len && d[i] != '\n') i++;
     if (i >= len) goto premature;
     name1 = i++; line++;
+    if (st->desc != NULL) {
+      for (size_t k = name0; k < name1; k++)
+        if (bb_push(st->desc, d[k]) != 0) goto nomem;
+      if (bb_push(st->desc, 0) != 0) goto nomem;
+    }
     if (st->seen_record && bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
     st->seen_record = 1;
     for (; i < len && d[i] != '+'; i++) {
@@ -202,9 +213,19 @@ nomem:
 int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
                        uint8_t **enc, uint64_t *n, char *err, size_t errlen)
 {
+  return gtamd_encode_files_desc(paths, numfiles, protein, enc, n, NULL, NULL,
+                                 err, errlen);
+}
+
+int gtamd_encode_files_desc(const char *const *paths, size_t numfiles,
+                            int protein, uint8_t **enc, uint64_t *n,
+                            char **desc, uint64_t *desclen, char *err,
+                            size_t errlen)
+{
   uint8_t map[256];
   bytebuf out = {NULL, 0, 0};
-  encstate st = {map, &out, 0, 0};
+  bytebuf dbuf = {NULL, 0, 0};
+  encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0};
   int last_was_fasta = 1;
 
   build_symbolmap(map, protein);
@@ -237,7 +258,7 @@ int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
     free(data);
     if (rc == -3)
       snprintf(err, errlen, "file '%s' contains an empty sequence", paths[f]);
-    if (rc != 0) { free(out.p); return -1; }
+    if (rc != 0) { free(out.p); free(dbuf.p); return -1; }
   }
   if (!st.seen_record) {
     snprintf(err, errlen, "no sequences in multiple fasta file(s) %s ...",
@@ -250,9 +271,73 @@ int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
     free(out.p);
     return -1;
   }
+  /* a header that ends with the file (no newline) still counts */
+  if (desc != NULL && (dbuf.len == 0 || dbuf.p[dbuf.len - 1] != 0)) (void) bb_push(&dbuf, 0);
   *enc = out.p;
   *n = out.len;
+  if (desc != NULL) { *desc = (char *) dbuf.p; *desclen = dbuf.len; }
   return 0;
+}
+
+int gtamd_write_des_sds(const char *indexname, const char *desc,
+                        uint64_t desclen, int write_des, int write_sds)
+{
+  char path[4096];
+  FILE *fd = NULL, *fs = NULL;
+  uint64_t off = 0, longest = 0, pos = 0;
+  const uint64_t fin = ~(uint64_t) 0;
+  if (write_des) {
+    snprintf(path, sizeof path, "%s.des", indexname);
+    if ((fd = fopen(path, "wb")) == NULL) return -1;
+  }
+  if (write_sds) {
+    snprintf(path, sizeof path, "%s.sds", indexname);
+    if ((fs = fopen(path, "wb")) == NULL) { if (fd) fclose(fd); return -1; }
+  }
+  while (pos < desclen) {
+    const uint64_t l = strlen(desc + pos);
+    const int last = pos + l + 1 >= desclen;
+    if (l > longest) longest = l;
+    off += l;
+    if (fd) { fwrite(desc + pos, 1, l, fd); fputc('\n', fd); }
+    if (fs && !last) fwrite(&off, sizeof off, 1, fs);
+    off += 1;
+    pos += l + 1;
+  }
+  if (fd) { fwrite(&longest, sizeof longest, 1, fd); fwrite(&fin, sizeof fin, 1, fd); }
+  if (fd && fclose(fd) != 0) { if (fs) fclose(fs); return -1; }
+  if (fs && fclose(fs) != 0) return -1;
+  return 0;
+}
+
+int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
+                    int protein)
+{
+  static const char dna[] = "ACGT", prot[] = "LVIFKREDAGSTNQYWPHMC";
+  char path[4096], hex[33];
+  uint8_t block[4096];
+  size_t fill = 0;
+  gtamd_md5 st;
+  FILE *fp;
+  snprintf(path, sizeof path, "%s.md5", indexname);
+  if ((fp = fopen(path, "wb")) == NULL) return -1;
+  gtamd_md5_init(&st);
+  for (uint64_t i = 0; i <= n; i++) {
+    if (i == n || enc[i] == GTAMD_SEPARATOR) {
+      gtamd_md5_update(&st, block, fill);
+      fill = 0;
+      gtamd_md5_hex(&st, hex);
+      fwrite(hex, 1, 33, fp);
+      gtamd_md5_init(&st);
+      continue;
+    }
+    /* decoded symbol, upper case; a wildcard decodes to the alphabet's
+       wildcard character (n / X) */
+    block[fill++] = enc[i] == GTAMD_WILDCARD ? (uint8_t) (protein ? 'X' : 'N')
+                                             : (uint8_t) (protein ? prot[enc[i]] : dna[enc[i]]);
+    if (fill == sizeof block) { gtamd_md5_update(&st, block, fill); fill = 0; }
+  }
+  return fclose(fp) == 0 ? 0 : -1;
 }
 
 /* a run of `len` specials is stored as this many table entries when the run

@@ -50,17 +50,22 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
 
 static int yesno(int argc, const char **argv, int *i)
 {
-  /* options like -tis take an optional yes|no argument */
-  if (*i + 1 < argc && (!strcmp(argv[*i + 1], "yes") || !strcmp(argv[*i + 1], "no")))
+  /* options like -tis take an optional yes|no argument; returns the value */
+  if (*i + 1 < argc && (!strcmp(argv[*i + 1], "yes") || !strcmp(argv[*i + 1], "no"))) {
     (*i)++;
-  return 0;
+    return !strcmp(argv[*i], "yes");
+  }
+  return 1;
 }
 
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
 {
   const char *db[MAXDB], *indexname = NULL;
   size_t numdb = 0;
-  int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0;
+  int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0,
+      out_des = 1, out_sds = 1, out_md5 = 1;   /* defaults of encseq_options.c */
+  char *desc = NULL;
+  uint64_t desclen = 0;
   uint32_t want = 0, userpl = 0;
   char indexbuf[4096];
   uint8_t *enc = NULL;
@@ -104,9 +109,11 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       /* space/strategy knobs of the CPU algorithm: the tables do not depend on
          them, the device build ignores them */
       if (i + 1 < argc && argv[i + 1][0] != '-') i++;
-    } else if (!strcmp(a, "-tis") || !strcmp(a, "-des") || !strcmp(a, "-sds") ||
-               !strcmp(a, "-ssp") || !strcmp(a, "-md5") || !strcmp(a, "-showprogress")) {
-      yesno(argc, argv, &i);
+    } else if (!strcmp(a, "-des")) out_des = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-sds")) out_sds = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-md5")) out_md5 = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-tis") || !strcmp(a, "-ssp") || !strcmp(a, "-showprogress")) {
+      (void) yesno(argc, argv, &i);
     } else
       return fail(err, errlen, "unknown option: %s (try -help)", a);
   }
@@ -126,7 +133,18 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     /* wording of src/match/sfx-run.c:566-570 */
     return fail(err, errlen, "option -%s only can be used for DNA alphabets",
                 mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
-  if (gtamd_encode_files(db, numdb, protein, &enc, &n, err, errlen) != 0) return -1;
+  if (gtamd_encode_files_desc(db, numdb, protein, &enc, &n, &desc, &desclen, err, errlen) != 0)
+    return -1;
+  /* the sequence-side files describe the sequence as stored (before -dir) */
+  if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
+    free(enc); free(desc);
+    return fail(err, errlen, "cannot write description files of index '%s'", indexname);
+  }
+  free(desc);
+  if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
+    free(enc);
+    return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
+  }
   /* .prj describes the sequence as stored, the tables the sequence as read */
   gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
   if (mirrored) {

@@ -41,8 +41,26 @@ typedef struct {
 int gtamd_encode_files(const char *const *paths, size_t numfiles, int protein,
                        uint8_t **enc, uint64_t *n, char *err, size_t errlen);
 
+/* The same, also returning the sequence descriptions (header lines without
+   the leading '>' / '@'), NUL-separated in one malloc'ed block of *desclen
+   bytes, one per sequence.  desc may be NULL. */
+int gtamd_encode_files_desc(const char *const *paths, size_t numfiles,
+                            int protein, uint8_t **enc, uint64_t *n,
+                            char **desc, uint64_t *desclen, char *err,
+                            size_t errlen);
+
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                           gtamd_seqstats *st);
+
+/* INDEX.des (descriptions, each followed by '\n', then the length of the
+   longest one and ~0 as two 8-byte words) and INDEX.sds (8-byte end offset of
+   every description but the last), src/core/encseq_charproc.gen:118-130,
+   src/core/encseq.c:5613-5624.  INDEX.md5: per sequence the MD5 of its decoded
+   upper-case symbols as 32 hex digits + NUL (encseq_charproc.gen:52-92). */
+int gtamd_write_des_sds(const char *indexname, const char *desc,
+                        uint64_t desclen, int write_des, int write_sds);
+int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
+                    int protein);
 
 /* The sequence as the reference reads it with -dir fwd|rev|cpl|rcl (readmode
    0..3, src/core/readmode_api.h:24-27), in place; complement (3 - code) is

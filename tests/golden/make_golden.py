@@ -86,6 +86,10 @@ def main():
                 entry["tables"][ext] = {"md5": md5(p), "bytes": os.path.getsize(p)}
             with open(idx + ".prj") as f:
                 entry["prj"] = f.read()
+            # sequence-side files the encoder writes by default
+            entry["seqfiles"] = {ext: {"md5": md5(idx + "." + ext),
+                                       "bytes": os.path.getsize(idx + "." + ext)}
+                                 for ext in ("des", "sds", "md5")}
             if size <= MAX_FIXTURE:
                 shutil.copyfile(src, os.path.join(OUT, "fixtures", name))
             if size <= MAX_TABLES:

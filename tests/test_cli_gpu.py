@@ -36,6 +36,23 @@ def test_cli_writes_reference_files(cli, name, tmp_path):
         assert hashlib.md5(raw).hexdigest() == e["tables"][ext]["md5"], ext
     with open(idx + ".prj") as f:
         assert f.read() == e["prj"]
+    # sequence-side files written by default (-des -sds -md5 yes)
+    for ext in ("des", "sds", "md5"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
+
+
+def test_cli_fastq_input_and_switches(cli, tmp_path):
+    e = GOLDEN["test10_multiline.fastq"]
+    idx = str(tmp_path / "fq")
+    subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-des", "no", "-md5", "no", "-db",
+                    ou.fixture_path("test10_multiline.fastq"), "-indexname", idx], check=True)
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    assert not os.path.exists(idx + ".des") and not os.path.exists(idx + ".md5")
+    with open(idx + ".sds", "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"]["sds"]["md5"]
 
 
 def test_cli_suf_only_and_options_without_effect(cli, tmp_path):

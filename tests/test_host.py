@@ -32,6 +32,14 @@ def host():
                                      ctypes.c_int, ctypes.POINTER(P),
                                      ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
                                      ctypes.c_size_t]
+    L.gtamd_encode_files_desc.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t,
+                                          ctypes.c_int, ctypes.POINTER(P),
+                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(P),
+                                          ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
+                                          ctypes.c_size_t]
+    L.gtamd_write_des_sds.argtypes = [ctypes.c_char_p, P, ctypes.c_uint64, ctypes.c_int,
+                                      ctypes.c_int]
+    L.gtamd_write_md5.argtypes = [ctypes.c_char_p, P, ctypes.c_uint64, ctypes.c_int]
     L.gtamd_sequence_stats.argtypes = [P, ctypes.c_uint64, ctypes.c_uint32,
                                        ctypes.POINTER(SeqStats)]
     L.gtamd_write_prj.argtypes = [ctypes.c_char_p, ctypes.POINTER(SeqStats),
@@ -189,3 +197,29 @@ def test_fastq_errors_use_the_reference_wording(host, tmp_path):
     p.write_text("@r1\nACGT\nAC\n+r1\nII\nII@+\n@r2\nNNA\n+\n@@@\n")
     enc = _encode(host, [str(p)])
     assert enc.tolist() == [0, 1, 2, 3, 0, 1, 255, 254, 254, 0]
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_des_sds_md5_files_match_reference(host, name, tmp_path):
+    """INDEX.des / .sds / .md5 as the reference's encoder writes them"""
+    import hashlib
+    e = GOLDEN[name]
+    protein = e["alphabet"] == "protein"
+    arr = (ctypes.c_char_p * 1)(ou.fixture_path(name).encode())
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    dptr, dlen = ctypes.c_void_p(), ctypes.c_uint64()
+    err = ctypes.create_string_buffer(2048)
+    assert host.gtamd_encode_files_desc(arr, 1, int(protein), ctypes.byref(ptr),
+                                        ctypes.byref(n), ctypes.byref(dptr),
+                                        ctypes.byref(dlen), err, 2048) == 0, err.value
+    idx = str(tmp_path / "idx")
+    assert host.gtamd_write_des_sds(idx.encode(), dptr, dlen.value, 1, 1) == 0
+    assert host.gtamd_write_md5(idx.encode(), ptr, n.value, int(protein)) == 0
+    libc = ctypes.CDLL(None)
+    libc.free(ptr)
+    libc.free(dptr)
+    for ext in ("des", "sds", "md5"):
+        with open(idx + "." + ext, "rb") as f:
+            raw = f.read()
+        assert len(raw) == e["seqfiles"][ext]["bytes"], ext
+        assert hashlib.md5(raw).hexdigest() == e["seqfiles"][ext]["md5"], ext

@@ -898,34 +898,48 @@ __global__ __launch_bounds__(256) void k_round_apply(
     const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
     const u32 *__restrict__ uidx, const u32 *__restrict__ ugrp, u64 m,
     u32 rank_offset, u32 *__restrict__ sa32, u32 *__restrict__ rank,
-    u32 *__restrict__ keep) {
+    u32 *__restrict__ keep, u32 *__restrict__ blockcnt) {
+  __shared__ u32 s_cnt[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m) return;
-  const u32 p = cval[j], g = gnew[j], i = uidx[j];
-  // slot j stays inside its old group's range, so ugrp[j] is the old group of
-  // whichever suffix now sits here; the leading subgroup keeps that id
-  if (g != ugrp[j]) rank[p] = rank_offset + g;
-  const bool head = g == i;
-  const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
-  const bool resolved = head && nexthead;
-  if (resolved) sa32[i] = p;   // final place; unresolved ones move again
-  keep[j] = resolved ? 0u : 1u;
+  bool kept = false;
+  if (j < m) {
+    const u32 p = cval[j], g = gnew[j], i = uidx[j];
+    // slot j stays inside its old group's range, so ugrp[j] is the old group of
+    // whichever suffix now sits here; the leading subgroup keeps that id
+    if (g != ugrp[j]) rank[p] = rank_offset + g;
+    const bool head = g == i;
+    const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
+    const bool resolved = head && nexthead;
+    if (resolved) sa32[i] = p;   // final place; unresolved ones move again
+    kept = !resolved;
+    keep[j] = kept ? 1u : 0u;
+  }
+  // survivors of this block: the compaction scans these counts, not the flags
+  const u64 b = __ballot(kept);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (u32) __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// boff: exclusive scan of the block counts
 __global__ __launch_bounds__(256) void k_round_compact(
-    const u32 *__restrict__ keep, const u32 *__restrict__ off,
-    const u32 *__restrict__ uidx, const u32 *__restrict__ cval,
-    const u32 *__restrict__ gnew, u64 m, u32 *__restrict__ uidx2,
-    u32 *__restrict__ upos2, u32 *__restrict__ ugrp2, Stats *stats) {
+    const u32 *__restrict__ keep, const u32 *__restrict__ boff,
+    const u32 *__restrict__ blockcnt, const u32 *__restrict__ uidx,
+    const u32 *__restrict__ cval, const u32 *__restrict__ gnew, u64 m,
+    u32 *__restrict__ uidx2, u32 *__restrict__ upos2, u32 *__restrict__ ugrp2,
+    Stats *stats) {
+  __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m) return;
-  if (keep[j]) {
-    const u32 o = off[j];
+  const u32 k = j < m ? keep[j] : 0u;
+  u32 tot;
+  const u32 o = boff[blockIdx.x] + block_scan_excl_sum(k, &tot, s_scan);
+  if (k) {
     uidx2[o] = uidx[j];
     upos2[o] = cval[j];
     ugrp2[o] = gnew[j];
   }
-  if (j + 1 == m) stats->count = off[j] + keep[j];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    stats->count = boff[blockIdx.x] + blockcnt[blockIdx.x];
 }
 
 // total of an exclusively scanned count array (last offset + last count)
@@ -1802,11 +1816,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         HIP_TRY(hipGetLastError());
       }
       const u32 *cv = cvo;
+      // (koff doubles as the per-block survivor counts and their scan)
+      u32 *bcnt = koff, *boff = koff + g + 16;
       k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, ugrp, m, (u32) index_offset,
-                                       sa32, rank, keep);
+                                       sa32, rank, keep, bcnt);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, keep, koff, m, false, scanws2, st));
-      k_round_compact<<<g, 256, 0, st>>>(keep, koff, uidx, cv, hv, m, uidx2,
+      TRY(scan_u32(SCAN_SUM, bcnt, boff, g, false, scanws2, st));
+      k_round_compact<<<g, 256, 0, st>>>(keep, boff, bcnt, uidx, cv, hv, m, uidx2,
                                          upos2, ugrp2, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));

@@ -668,17 +668,6 @@ __global__ __launch_bounds__(256) void k_rank_scatter(
   }
 }
 
-// rank of the suffix h symbols further on, for every unresolved suffix
-__global__ __launch_bounds__(256) void k_round_gather(
-    const u32 *__restrict__ upos, u64 m, u64 h, u64 n,
-    const u32 *__restrict__ rank, u32 *__restrict__ k2) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m) return;
-  u64 q = (u64) upos[j] + h;
-  if (q > n) q = n;  // cannot happen for a tied suffix; keeps the load in range
-  k2[j] = rank[q];
-}
-
 // One doubling round for all tie groups that lie inside one tile of the
 // unresolved list: sort each group by k2 in LDS (bitonic network on the packed
 // key  local group | k2 | slot), derive the new group heads.  Groups that
@@ -690,10 +679,13 @@ constexpr int RT_PER = RT_TILE / RT_THREADS;   // 8
 
 __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     const u32 *__restrict__ uidx, const u32 *__restrict__ upos,
-    const u32 *__restrict__ ugrp, const u32 *__restrict__ k2, u64 m,
+    const u32 *__restrict__ ugrp, u32 *__restrict__ k2, u64 m,
     u32 *__restrict__ cv, u32 *__restrict__ hv, u32 *__restrict__ flg,
-    Stats *stats) {
+    Stats *stats, const u32 *__restrict__ rank, u64 h, u64 n) {
+  // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
+  // of reading a k2 array (which a part build fills through the exchange)
   __shared__ u64 s_key[RT_TILE];
+  __shared__ u32 s_k2[RT_TILE];
   __shared__ u32 s_grp[RT_TILE + 1];
   __shared__ u32 s_pos[RT_TILE];
   __shared__ u16 s_start[RT_TILE + 2];   // first slot of each local group
@@ -709,11 +701,19 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) c * RT_THREADS + tid;
     if (e < cnt) {
+      const u32 p = upos[base + e];
       s_grp[e] = ugrp[base + e];
-      s_pos[e] = upos[base + e];
+      s_pos[e] = p;
+      if (rank != nullptr) {
+        u64 q = (u64) p + h;
+        if (q > n) q = n;  // cannot happen for a tied suffix; keeps the load in range
+        s_k2[e] = rank[q];
+      } else
+        s_k2[e] = k2[base + e];
     } else {
       s_grp[e] = 0xFFFFFFFFu;   // padding: one trailing pseudo group
       s_pos[e] = 0;
+      s_k2[e] = 0;
     }
   }
   __syncthreads();
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   // does any group of this tile split in this round?  (inside a long repeat
   // most rounds leave a group as it is: every member's k2 is the same)
   int splits = 0;
-  u32 kprev = (tid > 0 && (u32) tid * RT_PER - 1 < cnt) ? k2[base + (u32) tid * RT_PER - 1] : 0u;
+  u32 kprev = tid > 0 ? s_k2[(u32) tid * RT_PER - 1] : 0u;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) tid * RT_PER + c;
@@ -742,12 +742,13 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     const u32 g = s_grp[e];
     const bool open = e < cnt && ((first_open && g == g_first) ||
                                   (last_open && g == g_last));
-    const u32 kraw = e < cnt ? k2[base + e] : 0u;
+    const u32 kraw = s_k2[e];
     const u32 kk = open ? 0u : kraw;
     splits |= (e < cnt && !open && !start && kraw != kprev);
     kprev = kraw;
     s_key[e] = ((u64) lg << 43) | ((u64) kk << 11) | (u64) e;
     if (e < cnt) flg[base + e] = open;
+    if (open && rank != nullptr) k2[base + e] = kraw;   // for the global path
     nflag += open;
   }
   // (the barrier also orders the s_key writes before the network's reads)
@@ -1786,15 +1787,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         TRY(exchange_ranks<BITS>(c, upos, m, h, rank, k2, ckey_a, cval_a, ckey_b,
                                  cval_b, sendq, rws2, &all_queries));
         if (all_queries == 0) break;
-      } else {
-        k_round_gather<<<g, 256, 0, st>>>(upos, m, h, n, rank, k2);
-        HIP_TRY(hipGetLastError());
       }
       rounds++;
       if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
       HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
       k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(
-          uidx, upos, ugrp, k2, m, cvo, hv, flg, c->d_stats);
+          uidx, upos, ugrp, k2, m, cvo, hv, flg, c->d_stats,
+          parts ? nullptr : rank, h, n);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 nf = c->h_stats->count2;

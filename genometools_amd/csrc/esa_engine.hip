@@ -1753,8 +1753,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       HIP_TRY(hipGetLastError());
       // one pass on the 8 leading position bits: windows of N/256 positions.
       // (Measured at 3 Gbp: direct scatter 120 ms; 256 windows 61 ms + 23 ms
-      // for the pass; 4096 windows 53 ms + 38 ms -- the gain is TLB reach, not
-      // L2 residency, so the single pass wins.)
+      // for the pass; 4096 windows 53 ms + 38 ms; 4096 windows pinned to XCDs
+      // (each window written inside one L2) no better -- the gain is TLB
+      // reach, not L2 residency, so the single pass wins.)
       const int nbp = bits_for(N - 1);
       const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
       TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,

@@ -1790,6 +1790,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         if (all_queries == 0) break;
       }
       rounds++;
+      if (getenv("GTAMD_DEBUG") != nullptr)
+        fprintf(stderr, "gtamd: round %u h=%llu tied=%llu\n", rounds, (unsigned long long) h,
+                (unsigned long long) m);
       if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
       HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
       k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(

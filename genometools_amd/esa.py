@@ -83,6 +83,13 @@ class EsaEngine:
         check(self._lib.gtamd_esa_set_sequence_bytes(self._ctx, ptr, n, 1))
         self.n = int(n)
 
+    def set_sequence_packed_device(self, twobit_ptr, specialbits_ptr, n):
+        """already packed, device-resident input (GtTwobitencoding words +
+        special bitmap, see include/gtamd_esa.h); read in place"""
+        check(self._lib.gtamd_esa_set_sequence_packed(self._ctx, twobit_ptr,
+                                                      specialbits_ptr, n))
+        self.n = int(n)
+
     # -- sharding -----------------------------------------------------------
     def set_part(self, part, numparts, comm=None):
         """build slice `part` of `numparts` lexicographic ranges; `comm` is a
@@ -197,6 +204,27 @@ def suffixerator_tables(enc, numofchars=4, want=WANT_SUF | WANT_LCP | WANT_BWT,
         eng.set_sequence(enc)
         eng.run(want)
         return eng.result()
+
+
+def pack_twobit(enc):
+    """host-side packing of encoded DNA symbols into the resident form of the
+    engine: GtTwobitencoding words (32 symbols per uint64, first symbol in the
+    top bits, src/core/intbits.h:78-83; a special keeps its kind: 0 wildcard,
+    1 separator) and the special bitmap with the virtual end bit set"""
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    n = int(enc.size)
+    codes = np.where(enc >= 254, (enc == 255).astype(np.uint8), enc).astype(np.uint64)
+    nw = max(1, -(-n // 32))
+    padded = np.zeros(nw * 32, dtype=np.uint64)
+    padded[:n] = codes
+    shifts = (np.uint64(62) - np.uint64(2) * np.arange(32, dtype=np.uint64))
+    twobit = np.bitwise_or.reduce(padded.reshape(nw, 32) << shifts, axis=1)
+    nsw = -(-(n + 1) // 64)
+    bits = np.zeros(nsw * 64, dtype=np.uint8)
+    bits[:n] = enc >= 254
+    bits[n] = 1
+    special = np.packbits(bits.reshape(nsw, 64), axis=1, bitorder="little").view(np.uint64).reshape(nsw)
+    return twobit, special
 
 
 def prj_text(seqstats, esastats, with_lcp=True):

@@ -193,3 +193,24 @@ def test_sfxiterator_adapter(gpu):
     sfi.delete()
     with pytest.raises(esa.EsaError, match="only forward"):
         esa.Sfxiterator(enc, readmode=1)
+
+
+def test_packed_device_input(gpu):
+    """gtamd_esa_set_sequence_packed: the caller's own GtTwobitencoding words
+    and special bitmap, resident on the device, read in place"""
+    import torch
+    for enc in (synth.generate(synth.MODEL_HUMANLIKE_DNA, 21, 300000),
+                synth.generate(synth.MODEL_UNIFORM_DNA, 22, 64),
+                synth.generate(synth.MODEL_UNIFORM_DNA, 23, 1000)[:31],
+                np.concatenate([[254, 255], synth.generate(0, 24, 500), [254] * 70]).astype(np.uint8)):
+        twobit, special = esa.pack_twobit(enc)
+        d_tb = torch.from_numpy(twobit.view(np.int64)).to("cuda:0")
+        d_sp = torch.from_numpy(special.view(np.int64)).to("cuda:0")
+        with esa.EsaEngine(enc.size, 4) as eng:
+            eng.set_sequence_packed_device(d_tb.data_ptr(), d_sp.data_ptr(), enc.size)
+            eng.run()
+            res = eng.result()
+        _assert_same_as_oracle(enc, 4, res)
+    with pytest.raises(esa.EsaError, match="2-bit DNA layout only"):
+        with esa.EsaEngine(100, 20) as eng:
+            eng.set_sequence_packed_device(d_tb.data_ptr(), d_sp.data_ptr(), 10)

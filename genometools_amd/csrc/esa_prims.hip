@@ -115,9 +115,10 @@ constexpr int RADIX = 256;
 constexpr int OS_MAXPASS = 8;
 constexpr u64 OS_AUX_WORDS = 2 * OS_MAXPASS * RADIX + 64;  // totals, bases, flag
 
-// Per-tile digit histogram.  hist is digit-major: hist[d * ntiles + tile], so
-// that one exclusive scan over the whole array yields every tile's global
-// write base for every digit.
+// Per-tile digit histogram, tile-major: hist[tile * 256 + d] (one coalesced
+// 1 KB row per tile, for this kernel's store and the scatter kernel's load).
+// The column scan below turns it into every tile's global write base per
+// digit.
 template <typename K>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
     const K *__restrict__ keys, u64 n, int shift, u32 mask,
@@ -140,7 +141,50 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
     u32 c = 0;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) c += h[i][tid];
-    hist[(u64) tid * ntiles + blockIdx.x] = c;
+    hist[(u64) blockIdx.x * RADIX + tid] = c;
+  }
+}
+
+// Exclusive scan of the tile-major histogram in digit-major order:
+//   out[t][d] = sum_{d' < d} total[d'] + sum_{t' < t} hist[t'][d]
+// (1) column sums of chunks of CS_ROWS tiles, (2) one block turns them into
+// chunk bases, (3) every chunk rewrites its rows with running column prefixes.
+// Thread d owns column d; every row access is one coalesced 1 KB line.
+constexpr int CS_ROWS = 512;
+
+__global__ __launch_bounds__(RADIX) void k_cs_chunksum(
+    const u32 *__restrict__ hist, u32 ntiles, u32 *__restrict__ chunksum) {
+  const u32 t0 = blockIdx.x * CS_ROWS;
+  const u32 t1 = t0 + CS_ROWS < ntiles ? t0 + CS_ROWS : ntiles;
+  u32 acc = 0;
+  for (u32 t = t0; t < t1; t++) acc += hist[(u64) t * RADIX + threadIdx.x];
+  chunksum[(u64) blockIdx.x * RADIX + threadIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(RADIX) void k_cs_chunkbase(u32 *__restrict__ chunksum,
+                                                        u32 nchunks) {
+  __shared__ u32 s_scan[4];
+  // column totals, then their exclusive scan over the digits
+  u32 tot = 0;
+  for (u32 c = 0; c < nchunks; c++) tot += chunksum[(u64) c * RADIX + threadIdx.x];
+  u32 all;
+  u32 run = block_scan_excl<SCAN_SUM>(tot, &all, s_scan);
+  for (u32 c = 0; c < nchunks; c++) {
+    const u32 v = chunksum[(u64) c * RADIX + threadIdx.x];
+    chunksum[(u64) c * RADIX + threadIdx.x] = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(RADIX) void k_cs_rows(u32 *__restrict__ hist, u32 ntiles,
+                                                   const u32 *__restrict__ chunkbase) {
+  const u32 t0 = blockIdx.x * CS_ROWS;
+  const u32 t1 = t0 + CS_ROWS < ntiles ? t0 + CS_ROWS : ntiles;
+  u32 run = chunkbase[(u64) blockIdx.x * RADIX + threadIdx.x];
+  for (u32 t = t0; t < t1; t++) {
+    const u32 v = hist[(u64) t * RADIX + threadIdx.x];
+    hist[(u64) t * RADIX + threadIdx.x] = run;
+    run += v;
   }
 }
 
@@ -167,7 +211,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist_bytes(
     u32 c = 0;
 #pragma unroll
     for (int i = 0; i < RS_WAVES; i++) c += h[i][tid];
-    hist[(u64) tid * ntiles + blockIdx.x] = c;
+    hist[(u64) blockIdx.x * RADIX + tid] = c;
   }
 }
 
@@ -238,7 +282,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
   // this tile's global write base per digit: strided, latency-bound load,
   // issued first so that it is back long before it is needed
   u32 gbase = 0;
-  if (tid < RADIX) gbase = hist_scanned[(u64) tid * ntiles + tile];
+  if (tid < RADIX) gbase = hist_scanned[(u64) tile * RADIX + tid];
 
   K key[RS_ITEMS];
   V val[RS_ITEMS];
@@ -521,10 +565,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_scatter(
 
 }  // namespace
 
+// chunk sums of the column scan (one 256-word row per CS_ROWS tiles)
+static u64 cs_workspace_words(u64 ntiles) {
+  return (ntiles / CS_ROWS + 2) * RADIX;
+}
+
 u64 radix_workspace_words(u64 n) {
   u64 ntiles = div_up(n, RS_TILE);
   u64 hist = ntiles * RADIX;
-  return hist + scan_workspace_words(hist) + 64 + OS_AUX_WORDS;
+  return hist + cs_workspace_words(ntiles) + 64 + OS_AUX_WORDS;
 }
 
 // tuning switch (A/B measurements): GTAMD_XCD_REMAP=0 disables the remap
@@ -568,7 +617,7 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
   V *vin = vals_a, *vout = vals_b;
   // ---- chained-scan path for big sorts
   bool chained[OS_MAXPASS] = {false};
-  u32 *aux = scanws + scan_workspace_words((u64) ntiles * RADIX) + 32;
+  u32 *aux = scanws + cs_workspace_words(ntiles) + 32;
   u32 *d_totals = aux, *d_bases = aux + OS_MAXPASS * RADIX,
       *d_flag = aux + 2 * OS_MAXPASS * RADIX;
   int *d_shifts = reinterpret_cast<int *>(d_flag + 8), *d_widths = d_shifts + OS_MAXPASS;
@@ -635,7 +684,15 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
       k_rs_hist<K><<<ntiles, RS_THREADS, 0, st>>>(kin, n, shifts[p], mask, hist,
                                                ntiles);
     HIP_TRY(hipGetLastError());
-    TRY(scan_u32(SCAN_SUM, hist, hist, (u64) ntiles * RADIX, false, scanws, st));
+    {
+      const u32 nchunks = (ntiles + CS_ROWS - 1) / CS_ROWS;
+      k_cs_chunksum<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
+      HIP_TRY(hipGetLastError());
+      k_cs_chunkbase<<<1, RADIX, 0, st>>>(scanws, nchunks);
+      HIP_TRY(hipGetLastError());
+      k_cs_rows<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
+      HIP_TRY(hipGetLastError());
+    }
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
     if (g_xcd_mode == 2)
       k_rs_scatter<K, V, 2><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(

@@ -100,6 +100,26 @@ def main():
                         fo.write(fi.read())
         golden[name] = entry
         print(name, entry["tables"]["suf"]["md5"])
+    # our own edge-case inputs (tests/golden/extra/), reference output
+    extra_dir = os.path.join(OUT, "extra")
+    for name in sorted(f for f in os.listdir(extra_dir) if f.endswith((".fna", ".faa"))):
+        src = os.path.join(extra_dir, name)
+        flag = "-protein" if name.endswith(".faa") else "-dna"
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            subprocess.run([BIN, flag, "-suf", "-lcp", "-bwt", "-db", src,
+                            "-indexname", idx], check=True)
+            entry = {"alphabet": flag[1:], "input_bytes": os.path.getsize(src),
+                     "input_md5": md5(src), "fixture": True, "extra": True, "tables": {}}
+            for ext in ("suf", "lcp", "llv", "bwt"):
+                pth = idx + "." + ext
+                entry["tables"][ext] = {"md5": md5(pth), "bytes": os.path.getsize(pth)}
+            with open(idx + ".prj") as f:
+                entry["prj"] = f.read()
+            entry["seqfiles"] = {ext: {"md5": md5(idx + "." + ext),
+                                       "bytes": os.path.getsize(idx + "." + ext)}
+                                 for ext in ("des", "sds", "md5")}
+        golden["extra/" + name] = entry
     variants = {}
     for name in VARIANT_FILES:
         src = os.path.join(REF, "testdata", name)

@@ -164,4 +164,6 @@ def golden_table(name, ext):
 
 
 def fixture_path(name):
+    if name.startswith("extra/"):
+        return os.path.join(GOLDEN_DIR, name)
     return os.path.join(GOLDEN_DIR, "fixtures", name)

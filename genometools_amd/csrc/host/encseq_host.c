@@ -2,6 +2,7 @@
    the host layer (see include/gtamd_host.h for the reference interfaces). */
 #include "gtamd_host.h"
 #include "gtamd_md5.h"
+#include "host_internal.h"
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,8 @@ static void build_symbolmap(uint8_t map[256], int protein)
     for (int i = 0; wild[i]; i++) map[(uint8_t) wild[i]] = GTAMD_WILDCARD;
   }
 }
+
+void gtamd_symbolmap(uint8_t map[256], int protein) { build_symbolmap(map, protein); }
 
 typedef struct { uint8_t *p; uint64_t len, cap; } bytebuf;
 
@@ -67,20 +70,26 @@ static int slurp(const char *path, unsigned char **data, size_t *len)
   return 0;
 }
 
+typedef struct { uint64_t seqlen, desclen; size_t file; } fastq_record;
+
 typedef struct {
   const uint8_t *map;
   bytebuf *out;
   bytebuf *desc;         /* NUL-separated descriptions, or NULL */
   int seen_record;       /* any sequence so far, over all files */
   uint64_t seqlen;       /* symbols of the FASTA sequence being read */
+  gtamd_encinfo *info;   /* original-character histogram and file lengths, or NULL */
+  size_t file;           /* index of the file being read */
+  fastq_record *rec;     /* FASTQ records so far (for the file length table) */
+  size_t nrec, caprec;
 } encstate;
 
 /* (multi-)FASTA, src/core/sequence_buffer_fasta.c:44-170 */
 static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
                        size_t len, char *err, size_t errlen)
 {
-  uint64_t line = 1;
-  int in_header = 0;
+  uint64_t line = 1, added = 0;
+  int in_header = 0, first_in_file = 1;
   for (size_t i = 0; i < len; i++) {
     const int c = d[i];
     if (in_header) {
@@ -101,8 +110,12 @@ static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
         }
         if (bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
         st->seqlen = 0;
+        /* the separator in front of a file's first sequence is not counted
+           for that file (sequence_buffer_fasta.c:133-146) */
+        if (!first_in_file) added++;
       }
       st->seen_record = 1;
+      first_in_file = 0;
       in_header = 1;
       continue;
     }
@@ -113,6 +126,14 @@ static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
     }
     if (bb_push(st->out, st->map[c]) != 0) goto nomem;
     st->seqlen++;
+    added++;
+    if (st->info != NULL) st->info->originaldistribution[c]++;
+  }
+  if (st->info != NULL) {
+    /* bytes read / symbols and separators contributed by this file
+       (sequence_buffer_fasta.c:86-94,104,144,156) */
+    st->info->filelengthtab[st->file].length = len;
+    st->info->filelengthtab[st->file].effectivelength = added;
   }
   return 0;
 nomem:
@@ -159,6 +180,7 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
         return -1;
       }
       if (bb_push(st->out, st->map[c]) != 0) goto nomem;
+      if (st->info != NULL) st->info->originaldistribution[c]++;
       nsym++;
     }
     if (i >= len) goto premature;
@@ -199,6 +221,18 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
       return -1;
     }
     i++; line++;
+    if (st->info != NULL) {
+      if (st->nrec == st->caprec) {
+        const size_t ncap = st->caprec ? 2 * st->caprec : 1024;
+        fastq_record *nr = realloc(st->rec, ncap * sizeof *nr);
+        if (nr == NULL) goto nomem;
+        st->rec = nr; st->caprec = ncap;
+      }
+      st->rec[st->nrec].seqlen = nsym;
+      st->rec[st->nrec].desclen = name1 - name0;
+      st->rec[st->nrec].file = st->file;
+      st->nrec++;
+    }
   }
   return 0;
 premature:
@@ -222,22 +256,88 @@ int gtamd_encode_files_desc(const char *const *paths, size_t numfiles,
                             char **desc, uint64_t *desclen, char *err,
                             size_t errlen)
 {
+  return gtamd_encode_files_info(paths, numfiles, protein, enc, n, desc, desclen,
+                                 NULL, err, errlen);
+}
+
+void gtamd_encinfo_free(gtamd_encinfo *info)
+{
+  if (info != NULL) { free(info->filelengthtab); info->filelengthtab = NULL; }
+}
+
+/* The file length table as the reference's FASTQ reader accounts it: it fills
+   an output buffer of 8192 symbols per call and books what it read per call,
+   including the description lengths and the quirks at buffer boundaries
+   (src/core/sequence_buffer_fastq.c:42-191, OUTBUFSIZE sequence_buffer_rep.h:30) */
+static void fastq_filelengths(const fastq_record *rec, size_t nrec, size_t lastfile,
+                              gtamd_filelength *tab)
+{
+  const uint64_t OUTBUF = 8192;
+  uint64_t overflow = 0;
+  size_t r = 0, filenum = 0;
+  int carry = 0, complete = 0;
+  while (!complete) {
+    uint64_t out = 0, add = 0, rd = 0;
+    if (carry) { out++; rd++; add++; carry = 0; }
+    if (overflow > 0) {
+      const uint64_t k = overflow < OUTBUF - out ? overflow : OUTBUF - out;
+      out += k; add += k; rd += k; overflow -= k;
+      if (overflow > 0) continue;           /* counts of this call are dropped */
+      out++; rd++;
+    }
+    for (;;) {
+      const size_t newfile = r < nrec ? rec[r].file : lastfile;
+      if (filenum != newfile) {
+        tab[filenum].length += rd; tab[filenum].effectivelength += add;
+        rd = add = 0; filenum = newfile;
+      }
+      if (r == nrec) { complete = 1; out--; add--; break; }
+      for (uint64_t c = 0; c < rec[r].seqlen; c++) {
+        if (out >= OUTBUF) overflow++;
+        else { out++; add++; rd++; }
+      }
+      if (overflow == 0) {
+        if (out >= OUTBUF) carry = 1;
+        else { out++; add++; }
+      }
+      rd += rec[r].desclen + 1;
+      r++;
+      if (out >= OUTBUF) break;
+    }
+    tab[filenum].length += rd; tab[filenum].effectivelength += add;
+  }
+}
+
+int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
+                            int protein, uint8_t **enc, uint64_t *n,
+                            char **desc, uint64_t *desclen,
+                            gtamd_encinfo *info, char *err, size_t errlen)
+{
   uint8_t map[256];
   bytebuf out = {NULL, 0, 0};
   bytebuf dbuf = {NULL, 0, 0};
-  encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0};
-  int last_was_fasta = 1;
+  encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0, info, 0, NULL, 0, 0};
+  int last_was_fasta = 1, rc = 0;
 
   build_symbolmap(map, protein);
-  for (size_t f = 0; f < numfiles; f++) {
+  if (info != NULL) {
+    memset(info, 0, sizeof *info);
+    info->numfiles = numfiles;
+    info->filelengthtab = calloc(numfiles ? numfiles : 1, sizeof *info->filelengthtab);
+    if (info->filelengthtab == NULL) {
+      snprintf(err, errlen, "out of memory");
+      return -1;
+    }
+  }
+  for (size_t f = 0; f < numfiles && rc == 0; f++) {
     unsigned char *data = NULL;
     size_t len = 0;
-    int rc = slurp(paths[f], &data, &len);
+    st.file = f;
+    rc = slurp(paths[f], &data, &len);
     if (rc != 0) {
       snprintf(err, errlen, rc == -1 ? "cannot open file '%s'"
                                      : "out of memory while reading '%s'", paths[f]);
-      free(out.p);
-      return -1;
+      break;
     }
     /* format by the first character, as the reference guesses it
        (src/core/sequence_buffer.c) */
@@ -258,19 +358,24 @@ int gtamd_encode_files_desc(const char *const *paths, size_t numfiles,
     free(data);
     if (rc == -3)
       snprintf(err, errlen, "file '%s' contains an empty sequence", paths[f]);
-    if (rc != 0) { free(out.p); free(dbuf.p); return -1; }
   }
-  if (!st.seen_record) {
+  if (rc == 0 && !st.seen_record) {
     snprintf(err, errlen, "no sequences in multiple fasta file(s) %s ...",
              numfiles ? paths[0] : "");
-    free(out.p);
-    return -1;
+    rc = -1;
   }
-  if (last_was_fasta && st.seqlen == 0) {
+  if (rc == 0 && last_was_fasta && st.seqlen == 0) {
     snprintf(err, errlen, "file '%s' contains an empty sequence", paths[numfiles - 1]);
-    free(out.p);
+    rc = -1;
+  }
+  if (rc != 0) {
+    free(out.p); free(dbuf.p); free(st.rec);
+    gtamd_encinfo_free(info);
     return -1;
   }
+  if (info != NULL && st.nrec > 0)
+    fastq_filelengths(st.rec, st.nrec, numfiles - 1, info->filelengthtab);
+  free(st.rec);
   /* a header that ends with the file (no newline) still counts */
   if (desc != NULL && (dbuf.len == 0 || dbuf.p[dbuf.len - 1] != 0)) (void) bb_push(&dbuf, 0);
   *enc = out.p;
@@ -365,46 +470,92 @@ static void run_feed(runstat *r, int member, int last)
   }
 }
 
-void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
-                          gtamd_seqstats *st)
+uint64_t gtamd_swtable_bytes(int width_kind, int withrangelengths, uint64_t n,
+                             uint64_t items)
+{
+  static const uint64_t width[3] = {1, 2, 4}, maxv[3] = {UCHAR_MAX, USHRT_MAX, UINT32_MAX};
+  if (items == 0) return 0;
+  return (withrangelengths ? 2 : 1) * width[width_kind] * items
+         + 8 * (n / maxv[width_kind] + 1);
+}
+
+void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
+                            gtamd_seqanalysis *an)
 {
   runstat sp, wc;
-  uint64_t seqlen = 0, firstlen = 0, nsep = 0;
+  gtamd_seqstats *st = &an->ss;
+  uint64_t seqlen = 0, nsep = 0, nonspecial = 0, eqvalue = 0, best;
   int equal = 1;
+  memset(an, 0, sizeof *an);
   memset(&sp, 0, sizeof sp); memset(&wc, 0, sizeof wc);
   sp.at_start = wc.at_start = 1;
-  for (uint64_t i = 0; i < n; i++) {
-    const uint8_t c = enc[i];
-    run_feed(&sp, c >= GTAMD_WILDCARD, i + 1 == n);
-    run_feed(&wc, c == GTAMD_WILDCARD, i + 1 == n);
+  an->minseqlen = an->maxseqlen = ~(uint64_t) 0;
+  for (uint64_t i = 0; i <= n; i++) {
+    const uint8_t c = i < n ? enc[i] : GTAMD_SEPARATOR;
+    if (i < n) {
+      run_feed(&sp, c >= GTAMD_WILDCARD, i + 1 == n);
+      run_feed(&wc, c == GTAMD_WILDCARD, i + 1 == n);
+    }
+    if (c < GTAMD_WILDCARD) { an->chardist[c]++; nonspecial++; }
+    else {
+      if (nonspecial > an->lengthoflongestnonspecial) an->lengthoflongestnonspecial = nonspecial;
+      nonspecial = 0;
+    }
     if (c == GTAMD_SEPARATOR) {
-      if (nsep == 0) firstlen = seqlen; else if (seqlen != firstlen) equal = 0;
-      nsep++; seqlen = 0;
+      /* end of a sequence (the last one ends with the input) */
+      if (an->maxseqlen == ~(uint64_t) 0 || seqlen > an->maxseqlen) an->maxseqlen = seqlen;
+      if (an->minseqlen == ~(uint64_t) 0 || seqlen < an->minseqlen) an->minseqlen = seqlen;
+      if (eqvalue > 0) { if (seqlen != eqvalue) equal = 0; }
+      else eqvalue = seqlen;
+      if (i < n) nsep++;
+      seqlen = 0;
     } else seqlen++;
   }
-  if (nsep > 0 && seqlen != firstlen) equal = 0;
-  memset(st, 0, sizeof *st);
+  /* more specials than separators: some sequence holds a wildcard */
+  if (sp.chars > nsep) equal = 0;
+  an->equallength = equal;
+  an->equallength_value = equal ? eqvalue : 0;
   st->totallength = n; st->numofchars = numofchars; st->numofsequences = nsep + 1;
   st->specialcharacters = sp.chars; st->realspecialranges = sp.runs;
   st->lengthofspecialprefix = sp.prefix; st->lengthofspecialsuffix = sp.suffix;
   st->wildcards = wc.chars; st->realwildcardranges = wc.runs;
   st->lengthofwildcardprefix = wc.prefix; st->lengthofwildcardsuffix = wc.suffix;
-  /* which table width the reference would store the ranges with decides the
-     "ranges" numbers: smallest representation, bit access as the start value,
-     equal-length sequence sets and non-DNA alphabets use the first variant
-     (src/core/encseq_access_type.c:95-162; SW table size encseq.c:924-949) */
-  st->specialranges = sp.tab[0]; st->wildcardranges = wc.tab[0];
-  if (numofchars == 4 && !(equal && wc.chars == 0)) {
-    static const uint64_t width[3] = {1, 2, 4}, maxv[3] = {UCHAR_MAX, USHRT_MAX, UINT32_MAX};
-    uint64_t best = (wc.tab[0] > 0 || nsep > 0) ? 8 * ((n + 64 + 63) / 64) : 0;
+  /* the "ranges" numbers are those of the smallest of the three table
+     representations, whatever access type is used in the end
+     (src/core/encseq.c:5215-5256, sizes encseq.c:924-949) */
+  best = 0;
+  for (int k = 0; k < 3; k++) {
+    const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc.tab[k]);
+    if (k == 0 || size < best) {
+      best = size; st->specialranges = sp.tab[k]; st->wildcardranges = wc.tab[k];
+    }
+  }
+  /* access type: non-DNA alphabets are bit-packed; DNA takes the smallest of
+     bit access and the three table types, or "equal length" when all sequences
+     have the same length and hold no wildcard
+     (src/core/encseq_access_type.c:96-162) */
+  an->sat_wildcardranges = wc.tab[0];
+  if (numofchars != 4) an->sat = GTAMD_SAT_BYTECOMPRESS;
+  else if (equal) an->sat = GTAMD_SAT_EQUALLENGTH;
+  else {
+    an->sat = GTAMD_SAT_BITACCESS;
+    best = (wc.tab[0] > 0 || nsep > 0) ? 8 * (1 + (n + 63) / 64) : 0;
     for (int k = 0; k < 3; k++) {
-      const uint64_t size = wc.tab[k] == 0 ? 0
-        : 2 * width[k] * wc.tab[k] + 8 * (n / maxv[k] + 1);
+      const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc.tab[k]);
       if (size < best) {
-        best = size; st->specialranges = sp.tab[k]; st->wildcardranges = wc.tab[k];
+        best = size; an->sat = GTAMD_SAT_UCHARTABLES + k;
+        an->sat_wildcardranges = wc.tab[k];
       }
     }
   }
+}
+
+void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
+                          gtamd_seqstats *st)
+{
+  gtamd_seqanalysis an;
+  gtamd_analyse_sequence(enc, n, numofchars, &an);
+  *st = an.ss;
 }
 
 void gtamd_apply_readmode(uint8_t *enc, uint64_t n, int readmode)

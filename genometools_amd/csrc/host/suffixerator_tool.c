@@ -60,10 +60,10 @@ static int yesno(int argc, const char **argv, int *i)
 
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
 {
-  const char *db[MAXDB], *indexname = NULL;
+  const char *db[MAXDB], *indexname = NULL, *inputindex = NULL;
   size_t numdb = 0;
   int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0,
-      out_des = 1, out_sds = 1, out_md5 = 1;   /* defaults of encseq_options.c */
+      out_des = 1, out_sds = 1, out_md5 = 1, out_ssp = 1;   /* defaults of encseq_options.c */
   char *desc = NULL;
   uint64_t desclen = 0;
   uint32_t want = 0, userpl = 0;
@@ -71,6 +71,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   uint8_t *enc = NULL;
   uint64_t n = 0;
   gtamd_seqstats ss;
+  gtamd_encinfo info;
   gtamd_esa_stats es;
   gtamd_esa_ctx *ctx;
   int rc = -1;
@@ -83,6 +84,9 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
         db[numdb++] = argv[++i];
       }
       if (numdb == 0) return fail(err, errlen, "missing argument to option \"-%s\"", "db");
+    } else if (!strcmp(a, "-ii")) {
+      if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "ii");
+      inputindex = argv[++i];
     } else if (!strcmp(a, "-indexname")) {
       if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "indexname");
       indexname = argv[++i];
@@ -112,14 +116,25 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     } else if (!strcmp(a, "-des")) out_des = yesno(argc, argv, &i);
     else if (!strcmp(a, "-sds")) out_sds = yesno(argc, argv, &i);
     else if (!strcmp(a, "-md5")) out_md5 = yesno(argc, argv, &i);
-    else if (!strcmp(a, "-tis") || !strcmp(a, "-ssp") || !strcmp(a, "-showprogress")) {
+    else if (!strcmp(a, "-ssp")) out_ssp = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-tis") || !strcmp(a, "-showprogress")) {
       (void) yesno(argc, argv, &i);
     } else
       return fail(err, errlen, "unknown option: %s (try -help)", a);
   }
-  if (numdb == 0) return fail(err, errlen, "option \"-%s\" is mandatory", "db");
+  /* src/match/sfx-opt.c:78-88 */
+  if (numdb == 0 && inputindex == NULL)
+    return fail(err, errlen, "either option \"-db\" or option \"-%s\" is mandatory", "ii");
   if (dna && protein)
     return fail(err, errlen, "option \"-dna\" and option \"-%s\" exclude each other", "protein");
+  if (inputindex != NULL && (numdb > 0 || dna || protein))
+    return fail(err, errlen, "option \"-%s\" and option \"-ii\" exclude each other",
+                numdb > 0 ? "db" : dna ? "dna" : "protein");
+  if (indexname == NULL && inputindex != NULL) {
+    const char *base = strrchr(inputindex, '/');
+    snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : inputindex);
+    indexname = indexbuf;
+  }
   if (indexname == NULL) {
     /* default: basename of the single -db file (encseq_options.c:112-131) */
     const char *base;
@@ -133,20 +148,38 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     /* wording of src/match/sfx-run.c:566-570 */
     return fail(err, errlen, "option -%s only can be used for DNA alphabets",
                 mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
-  if (gtamd_encode_files_desc(db, numdb, protein, &enc, &n, &desc, &desclen, err, errlen) != 0)
-    return -1;
-  /* the sequence-side files describe the sequence as stored (before -dir) */
-  if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
-    free(enc); free(desc);
-    return fail(err, errlen, "cannot write description files of index '%s'", indexname);
+  if (inputindex != NULL) {
+    /* an existing encoded sequence: nothing on the sequence side is rewritten;
+       .prj repeats the statistics stored with it (src/match/sfx-run.c:454-493) */
+    if (gtamd_read_esq(inputindex, &enc, &n, &protein, &ss, err, errlen) != 0) return -1;
+    if (protein && (readmode >= 2 || mirrored)) {
+      free(enc);
+      return fail(err, errlen, "option -%s only can be used for DNA alphabets",
+                  mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
+    }
+  } else {
+    if (gtamd_encode_files_info(db, numdb, protein, &enc, &n, &desc, &desclen, &info, err, errlen) != 0)
+      return -1;
+    /* the encoded sequence itself, in the reference's format (always written:
+       -tis is kept for backwards compatibility only, src/match/sfx-opt.c) */
+    if (gtamd_write_esq(indexname, db, numdb, enc, n, protein, &info, out_ssp, err, errlen) != 0) {
+      free(enc); free(desc); gtamd_encinfo_free(&info);
+      return -1;
+    }
+    gtamd_encinfo_free(&info);
+    /* the sequence-side files describe the sequence as stored (before -dir) */
+    if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
+      free(enc); free(desc);
+      return fail(err, errlen, "cannot write description files of index '%s'", indexname);
+    }
+    free(desc);
+    if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
+      free(enc);
+      return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
+    }
+    /* .prj describes the sequence as stored, the tables the sequence as read */
+    gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
   }
-  free(desc);
-  if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
-    free(enc);
-    return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
-  }
-  /* .prj describes the sequence as stored, the tables the sequence as read */
-  gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
   if (mirrored) {
     uint8_t *m = gtamd_mirror(enc, n);
     if (m == NULL) { free(enc); return fail(err, errlen, "out of memory (%s)", "-mirrored"); }

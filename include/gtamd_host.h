@@ -49,6 +49,47 @@ int gtamd_encode_files_desc(const char *const *paths, size_t numfiles,
                             char **desc, uint64_t *desclen, char *err,
                             size_t errlen);
 
+/* What the encoder saw besides the symbols: how often every original input
+   byte occurred in the sequences, and per input file the bytes read and the
+   symbols (with separators) it contributed -- GtFilelengthvalues,
+   src/core/filelengthvalues.h:22-26, filled in
+   src/core/sequence_buffer_fasta.c:56-94 / sequence_buffer_fastq.c:113-188. */
+typedef struct { uint64_t length, effectivelength; } gtamd_filelength;
+typedef struct {
+  uint64_t originaldistribution[256];
+  gtamd_filelength *filelengthtab;      /* numfiles entries, malloc'ed */
+  size_t numfiles;
+} gtamd_encinfo;
+
+int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
+                            int protein, uint8_t **enc, uint64_t *n,
+                            char **desc, uint64_t *desclen,
+                            gtamd_encinfo *info, char *err, size_t errlen);
+void gtamd_encinfo_free(gtamd_encinfo *info);
+
+/* INDEX.esq -- the encoded sequence in the reference's own on-disk format, so
+   that an index written here can be mapped by GenomeTools' tools
+   (gt_encseq_loader_load) -- and INDEX.ssp, the separator positions, when the
+   reference would write it: header and sequence sections of
+   src/core/encseq.c:1195-1402 with the access type the reference chooses
+   (src/core/encseq_access_type.c:96-162): "equallength", "bit", "uchar",
+   "ushort", "uint32" for DNA, "bytecompress" for protein.  paths are stored as
+   given.  write_ssp mirrors the -ssp option.  0, or -1 with a message. */
+int gtamd_write_esq(const char *indexname, const char *const *paths,
+                    size_t numfiles, const uint8_t *enc, uint64_t n,
+                    int protein, const gtamd_encinfo *info, int write_ssp,
+                    char *err, size_t errlen);
+
+/* The way back (option -ii, src/match/sfx-run.c:454-493 /
+   gt_encseq_loader_load): the symbols of an existing INDEX.esq, written by
+   GenomeTools or by gtamd_write_esq, for every access type ("direct",
+   "bytecompress", "equallength", "bit", "uchar", "ushort", "uint32"; the last
+   three also need INDEX.ssp when there is more than one sequence).  DNA and
+   protein alphabets only.  *enc is malloc'ed; ss (may be NULL) receives the
+   sequence statistics stored in the header. */
+int gtamd_read_esq(const char *indexname, uint8_t **enc, uint64_t *n,
+                   int *protein, gtamd_seqstats *ss, char *err, size_t errlen);
+
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                           gtamd_seqstats *st);
 
@@ -84,7 +125,9 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
      -db FILE...  -indexname NAME  -dna | -protein  -suf -lcp -bwt
      -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored   and, accepted without
      effect on the tables,
-     -parts N  -memlimit X  -dc V  -tis -des -sds -ssp -md5 [yes|no]
+     -parts N  -memlimit X  -dc V  -tis [yes|no]
+   -des -sds -md5 -ssp [yes|no] select the sequence-side files; INDEX.esq is
+   always written, as the reference does.
    argv[0] is the tool name.  Returns 0, or -1 with the message in err (the
    caller prints "gt suffixerator: error: <err>" and exits 1, src/gt.c:48-52). */
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen);

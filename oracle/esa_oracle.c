@@ -242,15 +242,15 @@ void ora_seqstats_compute(const uint8_t *enc, uint64_t n, uint32_t numofchars,
       nseq++; seqlen = 0;
     } else if (i < n) seqlen++;
   }
-  if (nseq > 0 && seqlen != firstlen) eqlen = 0;
-  st->specialranges = sp_tab[0];
-  st->wildcardranges = wc_tab[0];
-  if (numofchars == 4 && !(eqlen && st->wildcards == 0)) {
-    uint64_t cmin = (wc_tab[0] > 0 || st->numofsequences > 1)
-                      ? 8 * ((n + 64 + 63) / 64) : 0;
+  (void) eqlen; (void) firstlen;
+  /* the stored-range counts are those of the smallest of the three table
+     widths, whatever access type the encoder picks afterwards and for every
+     alphabet (doupdatesumranges, src/core/encseq.c:5215-5256) */
+  {
+    uint64_t cmin = 0;
     for (k = 0; k < 3; k++) {
       uint64_t tmp = sw_table_size(k, n, wc_tab[k]);
-      if (tmp < cmin) {
+      if (k == 0 || tmp < cmin) {
         cmin = tmp;
         st->specialranges = sp_tab[k];
         st->wildcardranges = wc_tab[k];

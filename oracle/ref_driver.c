@@ -19,8 +19,8 @@
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
   usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
-                    [-dir fwd|rev|cpl|rcl] [-mirrored]
-                    -db FASTA -indexname IDX [-time]
+                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE]
+                    -db FASTA... -indexname IDX [-time]
 */
 #include <stdio.h>
 #include <stdlib.h>
@@ -65,7 +65,8 @@ static FILE *open_tab(const char *indexname, const char *suffix)
 
 int main(int argc, char **argv)
 {
-  const char *db = NULL, *indexname = NULL;
+  const char *db[64], *indexname = NULL, *sat = NULL;
+  int numdb = 0;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
        showtime = false, haserr = false, mirrored = false;
   GtReadmode readmode = GT_READMODE_FORWARD;
@@ -102,12 +103,17 @@ int main(int argc, char **argv)
       userpl = (unsigned int) atoi(argv[++i]);
     else if (!strcmp(argv[i], "-dc") && i + 1 < argc)
       dc = (unsigned int) atoi(argv[++i]);
-    else if (!strcmp(argv[i], "-db") && i + 1 < argc) db = argv[++i];
+    else if (!strcmp(argv[i], "-db") && i + 1 < argc) {
+      /* one or more files, up to the next option */
+      while (i + 1 < argc && argv[i + 1][0] != '-' && numdb < 64)
+        db[numdb++] = argv[++i];
+    }
+    else if (!strcmp(argv[i], "-sat") && i + 1 < argc) sat = argv[++i];
     else if (!strcmp(argv[i], "-indexname") && i + 1 < argc)
       indexname = argv[++i];
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
   }
-  if (db == NULL || indexname == NULL) {
+  if (numdb == 0 || indexname == NULL) {
     fprintf(stderr, "need -db and -indexname\n");
     return 2;
   }
@@ -127,8 +133,15 @@ int main(int argc, char **argv)
   ee = gt_encseq_encoder_new();
   if (dna) gt_encseq_encoder_set_input_dna(ee);
   else gt_encseq_encoder_set_input_protein(ee);
+  if (sat != NULL) {
+    /* -sat of src/core/encseq_options.c: force an access type */
+    if (gt_encseq_encoder_use_representation(ee, sat, err) != 0) {
+      fprintf(stderr, "gt suffixerator: error: %s\n", gt_error_get(err));
+      return EXIT_FAILURE;
+    }
+  }
   dbs = gt_str_array_new();
-  gt_str_array_add_cstr(dbs, db);
+  for (i = 0; i < numdb; i++) gt_str_array_add_cstr(dbs, db[i]);
   if (gt_encseq_encoder_encode(ee, dbs, indexname, err) != 0) haserr = true;
   gt_encseq_encoder_delete(ee);
   gt_str_array_delete(dbs);

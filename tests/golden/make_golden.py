@@ -50,6 +50,16 @@ VARIANT_FILES = ["Atinsert.fna", "Duplicate.fna", "RandomN.fna", "TTTN.fna",
                  "Small.fna", "Verysmall.fna", "Reads1.fna"]
 VARIANTS = [("rev", False), ("cpl", False), ("rcl", False), ("fwd", True),
             ("rcl", True)]
+MULTI = [["part1.fna", "part2.fna"], ["reads_a.fastq", "reads_b.fastq"],
+         ["long_reads.fastq"], ["part2.fna", "part1.fna", "part2.fna"]]
+ALL_DNA_SAT = ["direct", "bit", "uchar", "ushort", "uint32"]
+FORCED_SAT = [("Duplicate.fna", ALL_DNA_SAT), ("TTTN.fna", ALL_DNA_SAT),
+              ("Atinsert_seqrange_3-7.fna", ALL_DNA_SAT),
+              ("extra/starts_ends_special.fna", ALL_DNA_SAT),
+              ("extra/gt_in_line.fna", ALL_DNA_SAT + ["eqlen"]),
+              ("Reads1.fna", ["eqlen"]),
+              ("extra/protein_specials.faa", ["direct", "bytecompress"]),
+              ("extra/protein_long_x.faa", ["direct", "bytecompress"])]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -60,6 +70,26 @@ def md5(path):
         for blk in iter(lambda: f.read(1 << 20), b""):
             h.update(blk)
     return h.hexdigest()
+
+
+SEQFILES = ("des", "sds", "md5", "esq", "ssp")
+
+
+def seqfiles(idx):
+    """md5 of the sequence-side files the encoder wrote (INDEX.ssp only exists
+    for more than one sequence and not for the equal-length access type)"""
+    return {ext: {"md5": md5(idx + "." + ext),
+                  "bytes": os.path.getsize(idx + "." + ext)}
+            for ext in SEQFILES if os.path.exists(idx + "." + ext)}
+
+
+def run_ref(flag, srcs, idx, extra=()):
+    """INDEX.esq stores the -db arguments as typed: run from the input's
+    directory with bare file names so the stored names do not depend on where
+    the reference checkout lives"""
+    subprocess.run([BIN, flag, "-suf", "-lcp", "-bwt", *extra, "-indexname", idx,
+                    "-db"] + [os.path.basename(x) for x in srcs], check=True,
+                   cwd=os.path.dirname(srcs[0]))
 
 
 def main():
@@ -76,8 +106,7 @@ def main():
         size = os.path.getsize(src)
         with tempfile.TemporaryDirectory() as tmp:
             idx = os.path.join(tmp, "idx")
-            subprocess.run([BIN, flag, "-suf", "-lcp", "-bwt", "-db", src,
-                            "-indexname", idx], check=True)
+            run_ref(flag, [src], idx)
             entry = {"alphabet": flag[1:], "input_bytes": size,
                      "input_md5": md5(src),
                      "fixture": size <= MAX_FIXTURE, "tables": {}}
@@ -87,9 +116,7 @@ def main():
             with open(idx + ".prj") as f:
                 entry["prj"] = f.read()
             # sequence-side files the encoder writes by default
-            entry["seqfiles"] = {ext: {"md5": md5(idx + "." + ext),
-                                       "bytes": os.path.getsize(idx + "." + ext)}
-                                 for ext in ("des", "sds", "md5")}
+            entry["seqfiles"] = seqfiles(idx)
             if size <= MAX_FIXTURE:
                 shutil.copyfile(src, os.path.join(OUT, "fixtures", name))
             if size <= MAX_TABLES:
@@ -107,8 +134,7 @@ def main():
         flag = "-protein" if name.endswith(".faa") else "-dna"
         with tempfile.TemporaryDirectory() as tmp:
             idx = os.path.join(tmp, "idx")
-            subprocess.run([BIN, flag, "-suf", "-lcp", "-bwt", "-db", src,
-                            "-indexname", idx], check=True)
+            run_ref(flag, [src], idx)
             entry = {"alphabet": flag[1:], "input_bytes": os.path.getsize(src),
                      "input_md5": md5(src), "fixture": True, "extra": True, "tables": {}}
             for ext in ("suf", "lcp", "llv", "bwt"):
@@ -116,10 +142,44 @@ def main():
                 entry["tables"][ext] = {"md5": md5(pth), "bytes": os.path.getsize(pth)}
             with open(idx + ".prj") as f:
                 entry["prj"] = f.read()
-            entry["seqfiles"] = {ext: {"md5": md5(idx + "." + ext),
-                                       "bytes": os.path.getsize(idx + "." + ext)}
-                                 for ext in ("des", "sds", "md5")}
+            entry["seqfiles"] = seqfiles(idx)
         golden["extra/" + name] = entry
+    # several input files in one index (tests/golden/multi/): file length
+    # table, separators between files, FASTQ buffer accounting
+    multi = {}
+    multi_dir = os.path.join(OUT, "multi")
+    for files in MULTI:
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            run_ref("-dna", [os.path.join(multi_dir, f) for f in files], idx)
+            entry = {"files": files, "tables": {}}
+            for ext in ("suf", "lcp", "llv", "bwt"):
+                pth = idx + "." + ext
+                entry["tables"][ext] = {"md5": md5(pth), "bytes": os.path.getsize(pth)}
+            with open(idx + ".prj") as f:
+                entry["prj"] = f.read()
+            entry["seqfiles"] = seqfiles(idx)
+        multi["+".join(files)] = entry
+    with open(os.path.join(OUT, "golden_multi.json"), "w") as f:
+        json.dump(multi, f, indent=1, sort_keys=True)
+    # reference-written INDEX.esq/.ssp with every access type forced (-sat),
+    # kept as files: input of the .esq reader's tests (tests/golden/esq/)
+    esq_dir = os.path.join(OUT, "esq")
+    os.makedirs(esq_dir, exist_ok=True)
+    for name, sats in FORCED_SAT:
+        src = (os.path.join(OUT, name) if name.startswith("extra/")
+               else os.path.join(REF, "testdata", name))
+        flag = "-protein" if name.endswith(".faa") else "-dna"
+        for sat in sats:
+            with tempfile.TemporaryDirectory() as tmp:
+                idx = os.path.join(tmp, "idx")
+                subprocess.run([BIN, flag, "-sat", sat, "-indexname", idx, "-db",
+                                os.path.basename(src)], check=True,
+                               cwd=os.path.dirname(src))
+                for ext in ("esq", "ssp"):
+                    if os.path.exists(idx + "." + ext):
+                        shutil.copyfile(idx + "." + ext, os.path.join(
+                            esq_dir, "%s.%s.%s" % (os.path.basename(name), sat, ext)))
     variants = {}
     for name in VARIANT_FILES:
         src = os.path.join(REF, "testdata", name)

@@ -27,8 +27,10 @@ def cli(gpu):
 def test_cli_writes_reference_files(cli, name, tmp_path):
     e = GOLDEN[name]
     idx = str(tmp_path / "idx")
+    # INDEX.esq stores the -db argument as typed: bare name, run from its directory
     subprocess.run([cli, "-" + e["alphabet"], "-suf", "-lcp", "-bwt", "-tis", "-des",
-                    "-ssp", "-db", ou.fixture_path(name), "-indexname", idx], check=True)
+                    "-ssp", "-db", os.path.basename(ou.fixture_path(name)), "-indexname", idx],
+                   check=True, cwd=os.path.dirname(ou.fixture_path(name)))
     for ext in ("suf", "lcp", "llv", "bwt"):
         with open(idx + "." + ext, "rb") as f:
             raw = f.read()
@@ -36,10 +38,42 @@ def test_cli_writes_reference_files(cli, name, tmp_path):
         assert hashlib.md5(raw).hexdigest() == e["tables"][ext]["md5"], ext
     with open(idx + ".prj") as f:
         assert f.read() == e["prj"]
-    # sequence-side files written by default (-des -sds -md5 yes)
-    for ext in ("des", "sds", "md5"):
+    # sequence-side files written by default (-des -sds -md5 -ssp yes), and
+    # the encoded sequence itself
+    for ext in ("des", "sds", "md5", "esq", "ssp"):
+        assert os.path.exists(idx + "." + ext) == (ext in e["seqfiles"]), ext
+        if ext in e["seqfiles"]:
+            with open(idx + "." + ext, "rb") as f:
+                assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
+
+
+@pytest.mark.parametrize("stem", ["Duplicate.fna.ushort", "TTTN.fna.bit",
+                                  "Atinsert_seqrange_3-7.fna.uint32", "Reads1.fna.eqlen",
+                                  "protein_long_x.faa.bytecompress", "gt_in_line.fna.direct"])
+def test_cli_ii_builds_tables_from_a_reference_written_index(cli, stem, tmp_path):
+    """-ii INDEX: the encoded sequence comes from an INDEX.esq the reference
+    wrote (tests/golden/esq/, one per access type); tables and .prj must be
+    those of a run from the FASTA file"""
+    import shutil
+    name = stem.rsplit(".", 1)[0]
+    e = GOLDEN[name if name in GOLDEN else "extra/" + name]
+    src = str(tmp_path / "in")
+    for ext in ("esq", "ssp"):
+        f = os.path.join(ou.GOLDEN_DIR, "esq", "%s.%s" % (stem, ext))
+        if os.path.exists(f):
+            shutil.copyfile(f, src + "." + ext)
+    idx = str(tmp_path / "out")
+    subprocess.run([cli, "-ii", src, "-suf", "-lcp", "-bwt", "-indexname", idx], check=True)
+    for ext in ("suf", "lcp", "llv", "bwt"):
         with open(idx + "." + ext, "rb") as f:
-            assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    assert not os.path.exists(idx + ".esq") and not os.path.exists(idx + ".des")
+    got = dict(l.split("=") for l in open(idx + ".prj").read().splitlines())
+    want = dict(l.split("=") for l in e["prj"].splitlines())
+    # a forced access type changes how ranges are stored, nothing else
+    for k in ("specialranges", "wildcardranges"):
+        got.pop(k), want.pop(k)
+    assert got == want
 
 
 def test_cli_fastq_input_and_switches(cli, tmp_path):

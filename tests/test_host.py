@@ -13,12 +13,20 @@ from genometools_amd import _lib
 from genometools_amd._lib import EsaStats
 
 GOLDEN = ou.golden()
+with open(os.path.join(ou.GOLDEN_DIR, "golden_multi.json")) as _f:
+    import json as _json
+    MULTI = _json.load(_f)
 HOST_DIR = os.path.join(_lib.HERE, "csrc", "host")
 HOST_LIB = os.path.join(_lib.HERE, "libgtamd_host.so")
 
 
 class SeqStats(ctypes.Structure):
     _fields_ = ou.SeqStats._fields_
+
+
+class EncInfo(ctypes.Structure):           # gtamd_encinfo, include/gtamd_host.h
+    _fields_ = [("originaldistribution", ctypes.c_uint64 * 256),
+                ("filelengthtab", ctypes.c_void_p), ("numfiles", ctypes.c_size_t)]
 
 
 @pytest.fixture(scope="module")
@@ -37,6 +45,21 @@ def host():
                                           ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(P),
                                           ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p,
                                           ctypes.c_size_t]
+    L.gtamd_encode_files_info.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_size_t,
+                                          ctypes.c_int, ctypes.POINTER(P),
+                                          ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(P),
+                                          ctypes.POINTER(ctypes.c_uint64),
+                                          ctypes.POINTER(EncInfo), ctypes.c_char_p,
+                                          ctypes.c_size_t]
+    L.gtamd_encinfo_free.argtypes = [ctypes.POINTER(EncInfo)]
+    L.gtamd_write_esq.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p),
+                                  ctypes.c_size_t, P, ctypes.c_uint64, ctypes.c_int,
+                                  ctypes.POINTER(EncInfo), ctypes.c_int, ctypes.c_char_p,
+                                  ctypes.c_size_t]
+    L.gtamd_read_esq.argtypes = [ctypes.c_char_p, ctypes.POINTER(P),
+                                 ctypes.POINTER(ctypes.c_uint64),
+                                 ctypes.POINTER(ctypes.c_int), ctypes.POINTER(SeqStats),
+                                 ctypes.c_char_p, ctypes.c_size_t]
     L.gtamd_write_des_sds.argtypes = [ctypes.c_char_p, P, ctypes.c_uint64, ctypes.c_int,
                                       ctypes.c_int]
     L.gtamd_write_md5.argtypes = [ctypes.c_char_p, P, ctypes.c_uint64, ctypes.c_int]
@@ -129,7 +152,7 @@ def test_tool_argument_errors(host):
         err = ctypes.create_string_buffer(2048)
         rc = host.gtamd_suffixerator(len(args) + 1, argv, err, 2048)
         return rc, err.value.decode()
-    assert run("-suf") == (-1, 'option "-db" is mandatory')
+    assert run("-suf") == (-1, 'either option "-db" or option "-ii" is mandatory')
     rc, msg = run("-db", "a.fna", "b.fna", "-suf")
     assert rc == -1 and "option -indexname is mandatory" in msg
     rc, msg = run("-db", ou.fixture_path("Atinsert.fna"), "-dir", "sideways", "-suf")
@@ -223,3 +246,193 @@ def test_des_sds_md5_files_match_reference(host, name, tmp_path):
             raw = f.read()
         assert len(raw) == e["seqfiles"][ext]["bytes"], ext
         assert hashlib.md5(raw).hexdigest() == e["seqfiles"][ext]["md5"], ext
+
+
+def _write_all_seqfiles(host, paths, protein, idx, write_ssp=1):
+    """encode paths and write every sequence-side file of index idx; INDEX.esq
+    stores the input names as typed -- bare file names, as make_golden.py ran
+    the reference"""
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    names = (ctypes.c_char_p * len(paths))(*[os.path.basename(p).encode() for p in paths])
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    dptr, dlen = ctypes.c_void_p(), ctypes.c_uint64()
+    info = EncInfo()
+    err = ctypes.create_string_buffer(2048)
+    assert host.gtamd_encode_files_info(arr, len(paths), int(protein), ctypes.byref(ptr),
+                                        ctypes.byref(n), ctypes.byref(dptr),
+                                        ctypes.byref(dlen), ctypes.byref(info),
+                                        err, 2048) == 0, err.value
+    assert host.gtamd_write_esq(idx.encode(), names, len(paths), ptr, n.value,
+                                int(protein), ctypes.byref(info), write_ssp,
+                                err, 2048) == 0, err.value
+    assert host.gtamd_write_des_sds(idx.encode(), dptr, dlen.value, 1, 1) == 0
+    assert host.gtamd_write_md5(idx.encode(), ptr, n.value, int(protein)) == 0
+    host.gtamd_encinfo_free(ctypes.byref(info))
+    libc = ctypes.CDLL(None)
+    libc.free(ptr)
+    libc.free(dptr)
+
+
+def _check_seqfiles(idx, expected):
+    import hashlib
+    for ext in ("des", "sds", "md5", "esq", "ssp"):
+        assert os.path.exists(idx + "." + ext) == (ext in expected), ext
+        if ext in expected:
+            with open(idx + "." + ext, "rb") as f:
+                raw = f.read()
+            assert len(raw) == expected[ext]["bytes"], ext
+            assert hashlib.md5(raw).hexdigest() == expected[ext]["md5"], ext
+
+
+# access type (word 2 of INDEX.esq) the reference chose for some fixtures: all
+# seven layouts the writer knows are pinned by at least one of them
+ACCESS_TYPES = {"sw100K1.fsa": 1, "extra/protein_long_x.faa": 1, "Reads1.fna": 2,
+                "Atinsert.fna": 3, "Duplicate.fna": 4, "RandomN.fna": 5,
+                "extra/uint32_tables.fna": 6, "extra/equal_length_one_n.fna": 5}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_esq_and_ssp_files_match_reference(host, name, tmp_path):
+    """INDEX.esq (header, access type, packed sequence, wildcard tables) and
+    INDEX.ssp byte for byte as the reference's encoder writes them"""
+    e = GOLDEN[name]
+    idx = str(tmp_path / "idx")
+    _write_all_seqfiles(host, [ou.fixture_path(name)], e["alphabet"] == "protein", idx)
+    _check_seqfiles(idx, e["seqfiles"])
+    if name in ACCESS_TYPES:
+        with open(idx + ".esq", "rb") as f:
+            words = np.frombuffer(f.read(32), dtype="<u8")
+        assert words[2] == ACCESS_TYPES[name] and words[1] == 3
+
+
+@pytest.mark.parametrize("key", sorted(MULTI))
+def test_several_input_files_match_reference(host, key, tmp_path):
+    """file length table, separators between files, the FASTQ reader's
+    accounting across its 8192-symbol buffer"""
+    e = MULTI[key]
+    idx = str(tmp_path / "idx")
+    paths = [os.path.join(ou.GOLDEN_DIR, "multi", f) for f in e["files"]]
+    _write_all_seqfiles(host, paths, False, idx)
+    _check_seqfiles(idx, e["seqfiles"])
+    enc = _encode(host, paths)
+    prj = dict(l.split("=") for l in e["prj"].splitlines())
+    ss = SeqStats()
+    host.gtamd_sequence_stats(enc.ctypes.data, enc.size, 4, ctypes.byref(ss))
+    for k in ("totallength", "specialcharacters", "specialranges", "wildcardranges",
+              "numofsequences"):
+        assert getattr(ss, k) == int(prj[k]), k
+
+
+def test_ssp_is_optional_unless_the_access_type_needs_it(host, tmp_path):
+    # bit access (Atinsert): -ssp no drops the file; table access (Duplicate)
+    # keeps it, the reference cannot find sequence boundaries without it
+    # (src/core/encseq.c:4609-4619)
+    idx = str(tmp_path / "a")
+    _write_all_seqfiles(host, [ou.fixture_path("Atinsert.fna")], False, idx, write_ssp=0)
+    assert not os.path.exists(idx + ".ssp")
+    idx = str(tmp_path / "d")
+    _write_all_seqfiles(host, [ou.fixture_path("Duplicate.fna")], False, idx, write_ssp=0)
+    assert os.path.exists(idx + ".ssp")
+
+
+def _read_esq(host, idx):
+    ptr, n, protein = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_int()
+    ss = SeqStats()
+    err = ctypes.create_string_buffer(2048)
+    if host.gtamd_read_esq(idx.encode(), ctypes.byref(ptr), ctypes.byref(n),
+                           ctypes.byref(protein), ctypes.byref(ss), err, 2048) != 0:
+        raise ValueError(err.value.decode())
+    enc = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                shape=(n.value,)).copy()
+    ctypes.CDLL(None).free(ptr)
+    return enc, bool(protein.value), ss
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_esq_reader_returns_the_encoded_sequence(host, name, tmp_path):
+    """-ii: INDEX.esq (+ .ssp) -- byte-identical to the reference's files, see
+    test_esq_and_ssp_files_match_reference -- decodes to the symbols and the
+    statistics the encoder produced, for every access type"""
+    e = GOLDEN[name]
+    protein = e["alphabet"] == "protein"
+    idx = str(tmp_path / "idx")
+    _write_all_seqfiles(host, [ou.fixture_path(name)], protein, idx)
+    enc, was_protein, ss = _read_esq(host, idx)
+    assert was_protein == protein
+    assert np.array_equal(enc, _encode(host, [ou.fixture_path(name)], protein))
+    prj = dict(l.split("=") for l in e["prj"].splitlines())
+    for key in ("totallength", "specialcharacters", "specialranges", "realspecialranges",
+                "lengthofspecialprefix", "lengthofspecialsuffix", "wildcards",
+                "wildcardranges", "realwildcardranges", "lengthofwildcardprefix",
+                "lengthofwildcardsuffix", "numofsequences"):
+        assert getattr(ss, key) == int(prj[key]), key
+
+
+def test_esq_reader_rejects_damaged_files(host, tmp_path):
+    idx = str(tmp_path / "idx")
+    with pytest.raises(ValueError, match="cannot open file '.*idx.esq'"):
+        _read_esq(host, idx)
+    _write_all_seqfiles(host, [ou.fixture_path("Duplicate.fna")], False, idx)
+    good = open(idx + ".esq", "rb").read()
+    open(idx + ".esq", "wb").write(good[:len(good) - 16])
+    with pytest.raises(ValueError, match="truncated or inconsistent"):
+        _read_esq(host, idx)
+    open(idx + ".esq", "wb").write(good)
+    os.unlink(idx + ".ssp")        # table access needs the separator positions
+    with pytest.raises(ValueError, match="cannot open file '.*idx.ssp'"):
+        _read_esq(host, idx)
+    open(idx + ".esq", "wb").write(good[:8] + (2).to_bytes(8, "little") + good[16:])
+    with pytest.raises(ValueError, match="unsupported format version"):
+        _read_esq(host, idx)
+
+
+def test_tool_ii_reuses_an_existing_index(host, tmp_path):
+    """-ii INDEX without table options: only INDEX.prj is (re)written, from the
+    statistics stored in INDEX.esq (src/match/sfx-opt.c:78-88,108-118)"""
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"suffixerator", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        return host.gtamd_suffixerator(len(args) + 1, argv, err, 2048), err.value.decode()
+    idx = str(tmp_path / "first")
+    assert run("-db", ou.fixture_path("Atinsert.fna"), "-indexname", idx) == (0, "")
+    for ext in ("esq", "ssp", "des", "sds", "md5", "prj"):
+        assert os.path.exists(idx + "." + ext), ext
+    second = str(tmp_path / "second")
+    assert run("-ii", idx, "-indexname", second) == (0, "")
+    assert sorted(os.listdir(tmp_path)) == sorted(
+        ["first." + e for e in ("esq", "ssp", "des", "sds", "md5", "prj")] + ["second.prj"])
+    assert open(second + ".prj").read() == open(idx + ".prj").read()
+    assert run("-ii", idx, "-db", "x.fna") == (-1, 'option "-db" and option "-ii" exclude each other')
+    assert run("-ii", idx, "-dna") == (-1, 'option "-dna" and option "-ii" exclude each other')
+    rc, msg = run("-ii", str(tmp_path / "nosuch"))
+    assert rc == -1 and "cannot open file" in msg
+
+
+ESQ_DIR = os.path.join(ou.GOLDEN_DIR, "esq")
+REF_ESQ = sorted(f[:-4] for f in os.listdir(ESQ_DIR) if f.endswith(".esq"))
+
+
+@pytest.mark.parametrize("stem", REF_ESQ)
+def test_esq_reader_on_files_written_by_the_reference(host, stem, tmp_path):
+    """tests/golden/esq/<input>.<sat>.esq[.ssp]: written by the reference with
+    each access type forced (-sat direct|bytecompress|eqlen|bit|uchar|ushort|
+    uint32, make_golden.py); the reader must return the encoder's symbols"""
+    import shutil
+    name, sat = stem.rsplit(".", 1)
+    idx = str(tmp_path / "idx")
+    for ext in ("esq", "ssp"):
+        src = os.path.join(ESQ_DIR, "%s.%s" % (stem, ext))
+        if os.path.exists(src):
+            shutil.copyfile(src, idx + "." + ext)
+    with open(idx + ".esq", "rb") as f:
+        words = np.frombuffer(f.read(24), dtype="<u8")
+    assert words[2] == {"direct": 0, "bytecompress": 1, "eqlen": 2, "bit": 3, "uchar": 4,
+                        "ushort": 5, "uint32": 6}[sat]
+    protein = name.endswith(".faa")
+    fixture = ou.fixture_path(name if name in GOLDEN else "extra/" + name)
+    enc, was_protein, ss = _read_esq(host, idx)
+    assert was_protein == protein
+    assert np.array_equal(enc, _encode(host, [fixture], protein))
+    assert ss.totallength == enc.size
+    assert ss.specialcharacters == int((enc >= 254).sum())
+    assert ss.numofsequences == int((enc == 255).sum()) + 1

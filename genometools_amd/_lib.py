@@ -12,9 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in
-           ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip")]
+           ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip", "esa_encode.hip")]
 HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h")] + \
-          [os.path.join(ROOT, "include", "gtamd_esa.h")]
+          [os.path.join(ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -61,7 +61,25 @@ class EsaTiming(ctypes.Structure):
                 ("scatter_items", ctypes.c_uint64)]
 
 
-# every symbol include/gtamd_esa.h declares: (restype, argtypes)
+class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd_encode.h
+    _fields_ = [(name, ctypes.c_uint64) for name in
+                ("totallength", "numofsequences", "specialcharacters",
+                 "realspecialranges")] + \
+               [("specialrangestab", ctypes.c_uint64 * 3)] + \
+               [(name, ctypes.c_uint64) for name in
+                ("lengthofspecialprefix", "lengthofspecialsuffix", "wildcards",
+                 "realwildcardranges")] + \
+               [("wildcardrangestab", ctypes.c_uint64 * 3)] + \
+               [(name, ctypes.c_uint64) for name in
+                ("lengthofwildcardprefix", "lengthofwildcardsuffix",
+                 "lengthoflongestnonspecial", "minseqlen", "maxseqlen",
+                 "equallength")] + \
+               [("characterdistribution", ctypes.c_uint64 * 32),
+                ("originaldistribution", ctypes.c_uint64 * 256)]
+
+
+# every symbol include/gtamd_esa.h and include/gtamd_encode.h declare:
+# (restype, argtypes)
 _P = ctypes.c_void_p
 _U64 = ctypes.c_uint64
 _U32 = ctypes.c_uint32
@@ -87,6 +105,23 @@ ABI = {
     "gtamd_esa_build": (_INT, [_P, _U64, _U32, _U32, _P, _P, _P, _P, _U64,
                                ctypes.POINTER(_U64), ctypes.POINTER(EsaStats)]),
     "gtamd_synth_bytes": (_INT, [_INT, _INT, _U64, _U64, _P]),
+    # include/gtamd_encode.h
+    "gtamd_encoder_create": (_P, [_INT, _INT]),
+    "gtamd_encoder_destroy": (None, [_P]),
+    "gtamd_encoder_add_file": (_INT, [_P, ctypes.c_char_p, _P, _U64]),
+    "gtamd_encoder_finish": (_INT, [_P]),
+    "gtamd_encoder_length": (_U64, [_P]),
+    "gtamd_encoder_device_symbols": (_P, [_P]),
+    "gtamd_encoder_copy_symbols": (_INT, [_P, _P, _U64, _U64]),
+    "gtamd_encoder_get_summary": (_INT, [_P, ctypes.POINTER(EncodeSummary)]),
+    "gtamd_encoder_file_lengths": (_INT, [_P, ctypes.c_size_t, ctypes.POINTER(_U64),
+                                          ctypes.POINTER(_U64)]),
+    "gtamd_encoder_num_descriptions": (_U64, [_P]),
+    "gtamd_encoder_get_descriptions": (_INT, [_P, _P, _P, _P]),
+    "gtamd_encoder_get_timing": (_INT, [_P, ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(_U64)]),
 }
 
 _lib = None

@@ -1,0 +1,735 @@
+// esa_encode.hip -- device-side FASTA encoder and sequence statistics
+// (C ABI: include/gtamd_encode.h).  gfx950 only.
+//
+// The reference's reader is a two-state machine over the input bytes
+// (src/core/sequence_buffer_fasta.c:104-158): outside a description '>' opens
+// one and emits a separator (except for the first record), white space is
+// dropped, every other byte goes through the symbol map; inside a description
+// only '\n' matters, it closes it.  The state after a byte is therefore the
+// kind of the most recent '>' / '\n' at or before it, which makes the machine
+// a max-scan:
+//   k_fa_last    per 4096-byte tile: kind of the last '>' / '\n' in the tile
+//   scan_u32     exclusive MAX over tiles -> state at the start of every tile
+//   k_fa_tile<0> per tile: in-tile max-scan for the state of every thread's 16
+//                bytes, then count symbols + separators and descriptions;
+//                first illegal character, first description, histogram of the
+//                original characters
+//   scan_u32     exclusive SUM of the two per-tile counts
+//   k_fa_tile<1> the same walk again, now writing symbols, separators and the
+//                byte range of every description
+// HBM traffic per input byte: 3 reads of the byte + 1 written symbol; the tile
+// arrays are 1/512 of that.
+//
+// Statistics (encseq_charproc.gen, encseq.c:5061-5127) are run-length
+// properties of four symbol classes (special, wildcard, non-special,
+// non-separator).  k_run_summary folds every 4096-symbol tile into one
+// summary per class with an associative merge (runs that touch a tile edge
+// stay open); the host folds the ~n/4096 tile summaries with the same merge.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string>
+#include <vector>
+#include "../../include/gtamd_encode.h"
+#include "../../include/gtamd_esa.h"
+#include "esa_prims.h"
+#include "esa_devutil.h"
+
+namespace {
+
+constexpr int EN_THREADS = 256;
+constexpr int EN_PER = 16;                       // bytes per thread
+constexpr int EN_TILE = EN_THREADS * EN_PER;     // 4096
+constexpr u8 LUT_BLANK = 252, LUT_UNDEF = 253;
+constexpr u64 NONE64 = ~(u64) 0;
+
+void build_lut(u8 lut[256], bool protein) {
+  memset(lut, LUT_UNDEF, 256);
+  // src/core/alphabet.c:84-91 (DNA), :345-356, :480-503 (protein)
+  if (protein) {
+    const char *letters = "LVIFKREDAGSTNQYWPHMC", *wild = "XUBZJO*-";
+    for (int i = 0; letters[i]; i++) lut[(u8) letters[i]] = (u8) i;
+    for (int i = 0; wild[i]; i++) lut[(u8) wild[i]] = GTAMD_WILDCARD;
+  } else {
+    const char *lower = "acgt", *upper = "ACGT", *wild = "nsywrkvbdhmNSYWRKVBDHM";
+    for (int i = 0; i < 4; i++) lut[(u8) lower[i]] = lut[(u8) upper[i]] = (u8) i;
+    lut[(u8) 'u'] = lut[(u8) 'U'] = 3;
+    for (int i = 0; wild[i]; i++) lut[(u8) wild[i]] = GTAMD_WILDCARD;
+  }
+  // isspace() of the C locale
+  lut[' '] = lut['\t'] = lut['\n'] = lut['\r'] = lut['\v'] = lut['\f'] = LUT_BLANK;
+}
+
+__device__ __forceinline__ void load16(const u8 *raw, u64 len, u64 off, u8 b[EN_PER]) {
+  if (off + EN_PER <= len) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(raw + off);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < EN_PER; j++) b[j] = (u8) (w[j >> 2] >> (8 * (j & 3)));
+  } else {
+#pragma unroll
+    for (int j = 0; j < EN_PER; j++) b[j] = off + j < len ? raw[off + j] : (u8) ' ';
+  }
+}
+
+// kind of the last '>' / '\n' among 16 bytes: 0 none, else 2*(index in tile+1)+('>')
+__device__ __forceinline__ u32 last_marker(const u8 b[EN_PER], u32 first) {
+  u32 last = 0;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    if (b[j] == '\n') last = 2 * (first + j + 1);
+    else if (b[j] == '>') last = 2 * (first + j + 1) + 1;
+  }
+  return last;
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_fa_last(const u8 *raw, u64 len,
+                                                       u32 *tile_last) {
+  __shared__ u32 lds[EN_THREADS / 64];
+  const u64 tile = blockIdx.x;
+  u8 b[EN_PER];
+  load16(raw, len, tile * EN_TILE + (u64) threadIdx.x * EN_PER, b);
+  u32 last = last_marker(b, threadIdx.x * EN_PER), total;
+  (void) block_scan_excl<SCAN_MAX, EN_THREADS>(last, &total, lds);
+  if (threadIdx.x == 0)
+    tile_last[tile] = total == 0 ? 0 : (u32) (((tile + 1) << 1) | (total & 1));
+}
+
+struct FaGlobals {
+  unsigned long long first_illegal;   // file offset of the first byte without a code
+  unsigned long long first_desc;      // file offset of the first '>' that opens a description
+  unsigned long long origdist[256];
+};
+
+struct FaEmit {
+  u8 *enc;            // output symbols (already offset to this file's start)
+  u64 *desc_start;    // already offset to this file's first description
+  u64 *desc_end;
+  u64 first_desc;     // as counted by the first walk (NONE64: none)
+  int drop_first;     // the first description of all input emits no separator
+};
+
+// EMIT = 0: count; EMIT = 1: write
+template <int EMIT>
+__global__ __launch_bounds__(EN_THREADS) void k_fa_tile(
+    const u8 *raw, u64 len, const u8 *lut_g, const u32 *tile_state,
+    u32 *tile_syms, u32 *tile_descs, FaGlobals *g, const u32 *sym_off,
+    const u32 *desc_off, FaEmit em) {
+  __shared__ u32 lds[EN_THREADS / 64];
+  __shared__ u8 lut[256];
+  __shared__ u32 hist[256];
+  const u64 tile = blockIdx.x;
+  const u32 first = threadIdx.x * EN_PER;
+  lut[threadIdx.x] = lut_g[threadIdx.x];
+  if (!EMIT) hist[threadIdx.x] = 0;
+  u8 b[EN_PER];
+  load16(raw, len, tile * EN_TILE + first, b);
+  u32 total;
+  const u32 before = block_scan_excl<SCAN_MAX, EN_THREADS>(last_marker(b, first),
+                                                           &total, lds);
+  // (block_scan_excl synchronises: lut and hist are visible from here on)
+  u32 state = before != 0 ? (before & 1) : (tile_state[tile] & 1);
+  const u32 state0 = state;
+  u32 nsym = 0, ndesc = 0;
+  u64 illegal = NONE64, firstdesc = NONE64;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    const u8 c = b[j];
+    if (state) {
+      if (c == '\n') state = 0;
+    } else if (c == '>') {
+      state = 1;
+      if (firstdesc == NONE64) firstdesc = tile * EN_TILE + first + j;
+      ndesc++; nsym++;                     // a separator goes with it
+    } else {
+      const u8 code = lut[c];
+      if (code == LUT_BLANK) continue;
+      if (code == LUT_UNDEF) {
+        if (illegal == NONE64) illegal = tile * EN_TILE + first + j;
+        continue;
+      }
+      nsym++;
+      if (!EMIT) atomicAdd(&hist[c], 1u);
+    }
+  }
+  if (!EMIT) {
+    u32 tot_s, tot_d;
+    (void) block_scan_excl<SCAN_SUM, EN_THREADS>(nsym, &tot_s, lds);
+    (void) block_scan_excl<SCAN_SUM, EN_THREADS>(ndesc, &tot_d, lds);
+    if (threadIdx.x == 0) { tile_syms[tile] = tot_s; tile_descs[tile] = tot_d; }
+    if (illegal != NONE64) atomicMin(&g->first_illegal, (unsigned long long) illegal);
+    if (firstdesc != NONE64) atomicMin(&g->first_desc, (unsigned long long) firstdesc);
+    __syncthreads();
+    if (hist[threadIdx.x] != 0)
+      atomicAdd(&g->origdist[threadIdx.x], (unsigned long long) hist[threadIdx.x]);
+    return;
+  }
+  u32 dummy;
+  u64 so = (u64) sym_off[tile] + block_scan_excl<SCAN_SUM, EN_THREADS>(nsym, &dummy, lds);
+  u64 dn = (u64) desc_off[tile] + block_scan_excl<SCAN_SUM, EN_THREADS>(ndesc, &dummy, lds);
+  state = state0;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    const u8 c = b[j];
+    const u64 at = tile * EN_TILE + first + j;
+    if (state) {
+      // dn >= 1 here: a description is open
+      if (c == '\n') { state = 0; em.desc_end[dn - 1] = at; }
+    } else if (c == '>') {
+      state = 1;
+      em.desc_start[dn++] = at + 1;
+      if (!(em.drop_first && at == em.first_desc))
+        em.enc[so - (em.drop_first && at > em.first_desc ? 1 : 0)] = (u8) GTAMD_SEPARATOR;
+      so++;
+    } else {
+      const u8 code = lut[c];
+      if (code >= LUT_BLANK && code != GTAMD_WILDCARD) continue;   // blank or undefined
+      em.enc[so - (em.drop_first && at > em.first_desc ? 1 : 0)] = code;
+      so++;
+    }
+  }
+}
+
+// ---- run summaries ---------------------------------------------------------
+// Summary of one symbol class over a stretch of symbols: runs that touch the
+// left / right edge stay open (pre / suf), runs strictly inside are closed and
+// counted.  A stretch consisting of members only has pre == suf == len.
+template <typename T> struct RunSum {
+  T len, pre, suf, members, runs, pieces[3], maxrun, minrun;
+};
+
+template <typename T> __host__ __device__ inline RunSum<T> rs_empty() {
+  RunSum<T> r;
+  r.len = r.pre = r.suf = r.members = r.runs = 0;
+  r.pieces[0] = r.pieces[1] = r.pieces[2] = 0;
+  r.maxrun = 0; r.minrun = ~(T) 0;
+  return r;
+}
+
+template <typename T> __host__ __device__ inline RunSum<T> rs_single(bool member) {
+  RunSum<T> r;
+  r.len = 1; r.pre = r.suf = r.members = member ? 1 : 0;
+  r.runs = 0; r.pieces[0] = r.pieces[1] = r.pieces[2] = 0;
+  r.maxrun = 0; r.minrun = ~(T) 0;
+  return r;
+}
+
+template <typename T> __host__ __device__ inline void rs_close(RunSum<T> &r, T len) {
+  // stored ranges of a run in an 8-/16-/32-bit table (encseq.c:5061-5074)
+  r.runs++;
+  r.pieces[0] += (len + 255) / 256;
+  r.pieces[1] += (len + 65535) / 65536;
+  r.pieces[2] += 1;
+  if (len > r.maxrun) r.maxrun = len;
+  if (len < r.minrun) r.minrun = len;
+}
+
+template <typename T>
+__host__ __device__ inline RunSum<T> rs_merge(const RunSum<T> &a, const RunSum<T> &b) {
+  if (a.len == 0) return b;
+  if (b.len == 0) return a;
+  RunSum<T> r;
+  r.len = a.len + b.len; r.members = a.members + b.members;
+  r.runs = a.runs + b.runs;
+  for (int k = 0; k < 3; k++) r.pieces[k] = a.pieces[k] + b.pieces[k];
+  r.maxrun = a.maxrun > b.maxrun ? a.maxrun : b.maxrun;
+  r.minrun = a.minrun < b.minrun ? a.minrun : b.minrun;
+  const bool a_all = a.pre == a.len, b_all = b.pre == b.len;
+  if (a_all && b_all) r.pre = r.suf = r.len;
+  else if (a_all) { r.pre = a.len + b.pre; r.suf = b.suf; }
+  else if (b_all) { r.pre = a.pre; r.suf = a.suf + b.len; }
+  else {
+    r.pre = a.pre; r.suf = b.suf;
+    if (a.suf + b.pre > 0) rs_close<T>(r, a.suf + b.pre);
+  }
+  return r;
+}
+
+enum { CL_SPECIAL = 0, CL_WILDCARD, CL_NONSPECIAL, CL_NONSEPARATOR, CL_COUNT };
+
+__device__ __forceinline__ bool in_class(int cl, u8 c) {
+  return cl == CL_SPECIAL ? c >= GTAMD_WILDCARD
+       : cl == CL_WILDCARD ? c == GTAMD_WILDCARD
+       : cl == CL_NONSPECIAL ? c < GTAMD_WILDCARD : c != GTAMD_SEPARATOR;
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_run_summary(
+    const u8 *enc, u64 n, RunSum<u32> *tiles, unsigned long long *chardist) {
+  __shared__ RunSum<u32> red[EN_THREADS];
+  __shared__ u32 hist[32];
+  __shared__ u32 anyspecial;
+  const u64 tile = blockIdx.x, base = tile * EN_TILE + (u64) threadIdx.x * EN_PER;
+  if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) anyspecial = 0;
+  __syncthreads();
+  u8 b[EN_PER];
+  int cnt = 0;
+  if (base + EN_PER <= n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(enc + base);
+    const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < EN_PER; j++) b[j] = (u8) (w[j >> 2] >> (8 * (j & 3)));
+    cnt = EN_PER;
+  } else {
+    for (int j = 0; j < EN_PER; j++)
+      if (base + j < n) { b[j] = enc[base + j]; cnt = j + 1; }
+  }
+  bool special = false;
+  for (int j = 0; j < cnt; j++) {
+    if (b[j] >= GTAMD_WILDCARD) special = true;
+    else atomicAdd(&hist[b[j] & 31], 1u);
+  }
+  if (special) anyspecial = 1;
+  __syncthreads();
+  if (threadIdx.x < 32 && hist[threadIdx.x] != 0)
+    atomicAdd(&chardist[threadIdx.x], (unsigned long long) hist[threadIdx.x]);
+  const u64 tile_len64 = n - tile * EN_TILE < EN_TILE ? n - tile * EN_TILE : EN_TILE;
+  const u32 tile_len = (u32) tile_len64;
+  if (!anyspecial) {
+    // the common tile: letters only -- no special, no wildcard, one open run of
+    // non-specials and non-separators
+    if (threadIdx.x < CL_COUNT) {
+      RunSum<u32> r = rs_single<u32>(threadIdx.x >= CL_NONSPECIAL);
+      r.len = tile_len;
+      r.pre = r.suf = r.members = threadIdx.x >= CL_NONSPECIAL ? tile_len : 0;
+      tiles[tile * CL_COUNT + threadIdx.x] = r;
+    }
+    return;
+  }
+  for (int cl = 0; cl < CL_COUNT; cl++) {
+    RunSum<u32> r = rs_empty<u32>();
+    for (int j = 0; j < cnt; j++) r = rs_merge<u32>(r, rs_single<u32>(in_class(cl, b[j])));
+    red[threadIdx.x] = r;
+    __syncthreads();
+    for (int stride = 1; stride < EN_THREADS; stride <<= 1) {
+      RunSum<u32> m;
+      const bool act = (threadIdx.x & (2 * stride - 1)) == 0;
+      if (act) m = rs_merge<u32>(red[threadIdx.x], red[threadIdx.x + stride]);
+      __syncthreads();
+      if (act) red[threadIdx.x] = m;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) tiles[tile * CL_COUNT + cl] = red[0];
+    __syncthreads();
+  }
+}
+
+// first position of an empty sequence: a separator at either end of the
+// sequence or behind another separator
+__global__ void k_empty_sequence(const u8 *enc, u64 n, unsigned long long *first) {
+  const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || enc[i] != GTAMD_SEPARATOR) return;
+  if (i == 0 || i + 1 == n || enc[i - 1] == GTAMD_SEPARATOR)
+    atomicMin(first, (unsigned long long) i);
+}
+
+struct InputFile {
+  std::string name;
+  const u8 *bytes;
+  u64 length;
+  u64 out_start, out_len, ndesc, desc_base;   // filled by finish
+};
+
+template <typename T> int dev_alloc(T **p, u64 count) {
+  *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(p), (count ? count : 1) * sizeof(T)) != hipSuccess) {
+    gtamd_set_error("cannot allocate %llu bytes of device memory for the encoder",
+                    (unsigned long long) (count * sizeof(T)));
+    return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+struct gtamd_encoder {
+  int device;
+  bool protein, finished;
+  std::vector<InputFile> files;
+  hipStream_t st;
+  hipEvent_t ev[4];
+  u8 *d_enc;
+  u64 n, cap_enc;
+  u64 *d_desc_start, *d_desc_end;
+  u64 ndesc, cap_desc;
+  gtamd_encode_summary sum;
+  float total_ms, parse_ms, stats_ms;
+  u64 input_bytes;
+};
+
+static void enc_free(gtamd_encoder *e) {
+  if (e->d_enc) (void) hipFree(e->d_enc);
+  if (e->d_desc_start) (void) hipFree(e->d_desc_start);
+  if (e->d_desc_end) (void) hipFree(e->d_desc_end);
+  e->d_enc = nullptr; e->d_desc_start = e->d_desc_end = nullptr;
+  e->cap_enc = e->cap_desc = 0;
+}
+
+extern "C" gtamd_encoder *gtamd_encoder_create(int device, int protein) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
+    gtamd_set_error("no HIP device %d available (this library has no CPU fallback)",
+                    device);
+    return nullptr;
+  }
+  gtamd_encoder *e = new gtamd_encoder();
+  e->device = device; e->protein = protein != 0; e->finished = false;
+  e->d_enc = nullptr; e->d_desc_start = e->d_desc_end = nullptr;
+  e->n = e->cap_enc = e->ndesc = e->cap_desc = 0;
+  e->total_ms = e->parse_ms = e->stats_ms = 0; e->input_bytes = 0;
+  memset(&e->sum, 0, sizeof e->sum);
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&e->st) != hipSuccess) {
+    gtamd_set_error("cannot create a stream on device %d", device);
+    delete e;
+    return nullptr;
+  }
+  for (auto &ev : e->ev) (void) hipEventCreate(&ev);
+  return e;
+}
+
+extern "C" void gtamd_encoder_destroy(gtamd_encoder *e) {
+  if (e == nullptr) return;
+  (void) hipSetDevice(e->device);
+  enc_free(e);
+  for (auto &ev : e->ev) (void) hipEventDestroy(ev);
+  (void) hipStreamDestroy(e->st);
+  delete e;
+}
+
+extern "C" int gtamd_encoder_add_file(gtamd_encoder *e, const char *name,
+                                      const uint8_t *bytes, uint64_t length) {
+  if (e == nullptr || name == nullptr || (bytes == nullptr && length > 0)) {
+    gtamd_set_error("invalid argument to gtamd_encoder_add_file");
+    return -1;
+  }
+  if (length >= ((u64) 1 << 32) - EN_TILE) {
+    gtamd_set_error("file '%s' is too large for the device encoder (%llu bytes, "
+                    "limit 4 GiB per file)", name, (unsigned long long) length);
+    return -1;
+  }
+  InputFile f;
+  f.name = name; f.bytes = bytes; f.length = length;
+  f.out_start = f.out_len = f.ndesc = f.desc_base = 0;
+  e->files.push_back(f);
+  e->finished = false;
+  return 0;
+}
+
+// descriptions seen so far do not fit: grow both arrays, keep the contents
+static int grow_desc(gtamd_encoder *e, u64 need) {
+  if (need <= e->cap_desc) return 0;
+  const u64 cap = need + need / 2 + 1024;
+  u64 *ns, *ne;
+  TRY(dev_alloc(&ns, cap));
+  TRY(dev_alloc(&ne, cap));
+  if (e->ndesc > 0) {
+    HIP_TRY(hipMemcpyAsync(ns, e->d_desc_start, e->ndesc * 8, hipMemcpyDeviceToDevice, e->st));
+    HIP_TRY(hipMemcpyAsync(ne, e->d_desc_end, e->ndesc * 8, hipMemcpyDeviceToDevice, e->st));
+  }
+  HIP_TRY(hipStreamSynchronize(e->st));
+  if (e->d_desc_start) (void) hipFree(e->d_desc_start);
+  if (e->d_desc_end) (void) hipFree(e->d_desc_end);
+  e->d_desc_start = ns; e->d_desc_end = ne; e->cap_desc = cap;
+  return 0;
+}
+
+static u64 count_lines(const u8 *bytes, u64 upto) {
+  u64 line = 1;
+  for (const u8 *p = bytes, *end = bytes + upto;
+       (p = static_cast<const u8 *>(memchr(p, '\n', (size_t) (end - p)))) != nullptr; p++)
+    line++;
+  return line;
+}
+
+template <typename T> static RunSum<u64> widen(const RunSum<T> &a) {
+  RunSum<u64> r;
+  r.len = a.len; r.pre = a.pre; r.suf = a.suf; r.members = a.members; r.runs = a.runs;
+  for (int k = 0; k < 3; k++) r.pieces[k] = a.pieces[k];
+  r.maxrun = a.maxrun; r.minrun = a.minrun == ~(T) 0 ? ~(u64) 0 : (u64) a.minrun;
+  return r;
+}
+
+static int encode_files(gtamd_encoder *e, u8 *d_raw, u8 *d_lut, u32 *d_tile,
+                        u32 *d_ws, FaGlobals *d_glob, u64 max_tiles) {
+  bool seen_record = false;
+  u32 *t_last = d_tile, *t_state = d_tile + max_tiles, *t_syms = d_tile + 2 * max_tiles,
+      *t_descs = d_tile + 3 * max_tiles, *t_soff = d_tile + 4 * max_tiles,
+      *t_doff = d_tile + 5 * max_tiles;
+  e->n = 0; e->ndesc = 0;
+  for (size_t fi = 0; fi < e->files.size(); fi++) {
+    InputFile &f = e->files[fi];
+    const u64 ntiles = div_up(f.length, EN_TILE);
+    f.out_start = e->n; f.out_len = 0; f.ndesc = 0; f.desc_base = e->ndesc;
+    if (ntiles == 0) continue;
+    HIP_TRY(hipMemcpyAsync(d_raw, f.bytes, f.length, hipMemcpyHostToDevice, e->st));
+    FaGlobals init;
+    memset(&init, 0, sizeof init);
+    init.first_illegal = init.first_desc = NONE64;
+    HIP_TRY(hipMemcpyAsync(d_glob, &init, sizeof init, hipMemcpyHostToDevice, e->st));
+    k_fa_last<<<(u32) ntiles, EN_THREADS, 0, e->st>>>(d_raw, f.length, t_last);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_MAX, t_last, t_state, ntiles, false, d_ws, e->st));
+    k_fa_tile<0><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(
+        d_raw, f.length, d_lut, t_state, t_syms, t_descs, d_glob, nullptr, nullptr,
+        FaEmit());
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, t_syms, t_soff, ntiles, false, d_ws, e->st));
+    TRY(scan_u32(SCAN_SUM, t_descs, t_doff, ntiles, false, d_ws, e->st));
+    FaGlobals got;
+    u32 last[4];   // last tile: offsets and counts
+    HIP_TRY(hipMemcpyAsync(&got, d_glob, sizeof got, hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipMemcpyAsync(&last[0], t_soff + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipMemcpyAsync(&last[1], t_syms + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipMemcpyAsync(&last[2], t_doff + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipMemcpyAsync(&last[3], t_descs + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
+    HIP_TRY(hipStreamSynchronize(e->st));
+    if (got.first_illegal != NONE64) {
+      // wording of src/core/sequence_buffer_inline.h:37-41
+      gtamd_set_error("illegal character '%c': file \"%s\", line %llu",
+                      f.bytes[got.first_illegal], f.name.c_str(),
+                      (unsigned long long) count_lines(f.bytes, got.first_illegal));
+      return -1;
+    }
+    const u64 emitted = (u64) last[0] + last[1], ndesc = (u64) last[2] + last[3];
+    const bool drop = !seen_record && got.first_desc != NONE64;
+    for (int c = 0; c < 256; c++) e->sum.originaldistribution[c] += got.origdist[c];
+    TRY(grow_desc(e, e->ndesc + ndesc));
+    if (ndesc > 0)
+      HIP_TRY(hipMemsetAsync(e->d_desc_end + e->ndesc, 0xff, ndesc * 8, e->st));
+    FaEmit em;
+    em.enc = e->d_enc + e->n;
+    em.desc_start = e->d_desc_start + e->ndesc;
+    em.desc_end = e->d_desc_end + e->ndesc;
+    em.first_desc = got.first_desc;
+    em.drop_first = drop ? 1 : 0;
+    k_fa_tile<1><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(
+        d_raw, f.length, d_lut, t_state, nullptr, nullptr, nullptr, t_soff, t_doff, em);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->st));   // d_raw is reused by the next file
+    f.out_len = emitted - (drop ? 1 : 0);
+    f.ndesc = ndesc;
+    e->n += f.out_len;
+    e->ndesc += ndesc;
+    if (ndesc > 0) seen_record = true;
+  }
+  if (!seen_record) {
+    // src/core/sequence_buffer_fasta.c:163-168
+    gtamd_set_error("no sequences in multiple fasta file(s) %s ...",
+                    e->files.empty() ? "" : e->files[0].name.c_str());
+    return -1;
+  }
+  return 0;
+}
+
+static int summarise(gtamd_encoder *e) {
+  const u64 n = e->n, ntiles = div_up(n, EN_TILE);
+  if (n == 0) {
+    gtamd_set_error("file '%s' contains an empty sequence", e->files.back().name.c_str());
+    return -1;
+  }
+  RunSum<u32> *d_tiles;
+  unsigned long long *d_small;     // 32 counters + first empty sequence
+  TRY(dev_alloc(&d_tiles, ntiles * CL_COUNT));
+  if (dev_alloc(&d_small, 33) != 0) { (void) hipFree(d_tiles); return -1; }
+  std::vector<RunSum<u32>> tiles(ntiles * CL_COUNT);
+  unsigned long long small[33];
+  memset(small, 0, sizeof small);
+  small[32] = NONE64;
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(d_small, small, sizeof small, hipMemcpyHostToDevice, e->st) != hipSuccess) { rc = -1; break; }
+    k_empty_sequence<<<(u32) div_up(n, 256), 256, 0, e->st>>>(e->d_enc, n, d_small + 32);
+    k_run_summary<<<(u32) ntiles, EN_THREADS, 0, e->st>>>(e->d_enc, n, d_tiles, d_small);
+    if (hipGetLastError() != hipSuccess) { rc = -1; break; }
+    if (hipMemcpyAsync(tiles.data(), d_tiles, tiles.size() * sizeof(RunSum<u32>),
+                       hipMemcpyDeviceToHost, e->st) != hipSuccess) { rc = -1; break; }
+    if (hipMemcpyAsync(small, d_small, sizeof small, hipMemcpyDeviceToHost, e->st) != hipSuccess) { rc = -1; break; }
+    if (hipStreamSynchronize(e->st) != hipSuccess) { rc = -1; break; }
+  } while (0);
+  (void) hipFree(d_tiles);
+  (void) hipFree(d_small);
+  if (rc != 0) { gtamd_set_error("device statistics of the encoded sequence failed"); return -1; }
+  if (small[32] != NONE64) {
+    // the file whose '>' produced the offending separator (or the last one)
+    size_t fi = e->files.size() - 1;
+    for (size_t k = 0; k < e->files.size(); k++)
+      if (small[32] >= e->files[k].out_start &&
+          small[32] < e->files[k].out_start + e->files[k].out_len) { fi = k; break; }
+    if (small[32] + 1 == n) fi = e->files.size() - 1;
+    gtamd_set_error("file '%s' contains an empty sequence", e->files[fi].name.c_str());
+    return -1;
+  }
+  RunSum<u64> tot[CL_COUNT];
+  for (int cl = 0; cl < CL_COUNT; cl++) tot[cl] = rs_empty<u64>();
+  for (u64 t = 0; t < ntiles; t++)
+    for (int cl = 0; cl < CL_COUNT; cl++)
+      tot[cl] = rs_merge<u64>(tot[cl], widen(tiles[t * CL_COUNT + cl]));
+  // the runs at the two ends of the whole sequence are closed now
+  u64 pre[CL_COUNT], suf[CL_COUNT];
+  for (int cl = 0; cl < CL_COUNT; cl++) {
+    RunSum<u64> &r = tot[cl];
+    pre[cl] = r.pre; suf[cl] = r.suf;
+    if (r.len > 0 && r.pre == r.len) rs_close<u64>(r, r.len);
+    else {
+      if (r.pre > 0) rs_close<u64>(r, r.pre);
+      if (r.suf > 0) rs_close<u64>(r, r.suf);
+    }
+  }
+  gtamd_encode_summary &s = e->sum;
+  s.totallength = n;
+  s.numofsequences = tot[CL_NONSEPARATOR].runs;
+  s.specialcharacters = tot[CL_SPECIAL].members;
+  s.realspecialranges = tot[CL_SPECIAL].runs;
+  s.wildcards = tot[CL_WILDCARD].members;
+  s.realwildcardranges = tot[CL_WILDCARD].runs;
+  for (int k = 0; k < 3; k++) {
+    s.specialrangestab[k] = tot[CL_SPECIAL].pieces[k];
+    s.wildcardrangestab[k] = tot[CL_WILDCARD].pieces[k];
+  }
+  s.lengthofspecialprefix = pre[CL_SPECIAL]; s.lengthofspecialsuffix = suf[CL_SPECIAL];
+  s.lengthofwildcardprefix = pre[CL_WILDCARD]; s.lengthofwildcardsuffix = suf[CL_WILDCARD];
+  s.lengthoflongestnonspecial = tot[CL_NONSPECIAL].maxrun;
+  s.minseqlen = tot[CL_NONSEPARATOR].minrun;
+  s.maxseqlen = tot[CL_NONSEPARATOR].maxrun;
+  s.equallength = s.minseqlen == s.maxseqlen && s.wildcards == 0 ? 1 : 0;
+  for (int c = 0; c < 32; c++) s.characterdistribution[c] = small[c];
+  return 0;
+}
+
+extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
+  if (e == nullptr) { gtamd_set_error("null encoder"); return -1; }
+  if (e->files.empty()) { gtamd_set_error("option \"-db\" is mandatory"); return -1; }
+  HIP_TRY(hipSetDevice(e->device));
+  u64 total = 0, longest = 0;
+  for (const InputFile &f : e->files) {
+    total += f.length;
+    if (f.length > longest) longest = f.length;
+  }
+  enc_free(e);
+  e->finished = false;
+  memset(&e->sum, 0, sizeof e->sum);
+  e->input_bytes = total;
+  const u64 max_tiles = div_up(longest, EN_TILE) + 1;
+  u8 lut[256], *d_raw = nullptr, *d_lut = nullptr;
+  u32 *d_tile = nullptr, *d_ws = nullptr;
+  FaGlobals *d_glob = nullptr;
+  build_lut(lut, e->protein);
+  int rc = -1;
+  do {
+    if (dev_alloc(&e->d_enc, total + EN_TILE) != 0) break;
+    e->cap_enc = total + EN_TILE;
+    if (dev_alloc(&d_raw, longest + EN_TILE) != 0 || dev_alloc(&d_lut, 256) != 0 ||
+        dev_alloc(&d_tile, 6 * max_tiles) != 0 ||
+        dev_alloc(&d_ws, scan_workspace_words(max_tiles)) != 0 ||
+        dev_alloc(&d_glob, 1) != 0)
+      break;
+    if (hipMemcpyAsync(d_lut, lut, 256, hipMemcpyHostToDevice, e->st) != hipSuccess) {
+      gtamd_set_error("cannot copy the symbol map to the device");
+      break;
+    }
+    (void) hipEventRecord(e->ev[0], e->st);
+    if (encode_files(e, d_raw, d_lut, d_tile, d_ws, d_glob, max_tiles) != 0) break;
+    (void) hipEventRecord(e->ev[1], e->st);
+    if (summarise(e) != 0) break;
+    (void) hipEventRecord(e->ev[2], e->st);
+    if (hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("device encoder failed: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    (void) hipEventElapsedTime(&e->parse_ms, e->ev[0], e->ev[1]);
+    (void) hipEventElapsedTime(&e->stats_ms, e->ev[1], e->ev[2]);
+    (void) hipEventElapsedTime(&e->total_ms, e->ev[0], e->ev[2]);
+    rc = 0;
+  } while (0);
+  if (d_raw) (void) hipFree(d_raw);
+  if (d_lut) (void) hipFree(d_lut);
+  if (d_tile) (void) hipFree(d_tile);
+  if (d_ws) (void) hipFree(d_ws);
+  if (d_glob) (void) hipFree(d_glob);
+  if (rc != 0) { enc_free(e); e->n = 0; e->ndesc = 0; return -1; }
+  e->finished = true;
+  return 0;
+}
+
+static int need_finished(const gtamd_encoder *e) {
+  if (e == nullptr || !e->finished) {
+    gtamd_set_error("gtamd_encoder_finish has not completed");
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" uint64_t gtamd_encoder_length(const gtamd_encoder *e) {
+  return e != nullptr && e->finished ? e->n : 0;
+}
+
+extern "C" const uint8_t *gtamd_encoder_device_symbols(const gtamd_encoder *e) {
+  return e != nullptr && e->finished ? e->d_enc : nullptr;
+}
+
+extern "C" int gtamd_encoder_copy_symbols(const gtamd_encoder *e, uint8_t *dst,
+                                          uint64_t first, uint64_t count) {
+  TRY(need_finished(e));
+  if (first > e->n || count > e->n - first) {
+    gtamd_set_error("range [%llu, +%llu) exceeds the %llu encoded symbols",
+                    (unsigned long long) first, (unsigned long long) count,
+                    (unsigned long long) e->n);
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (count > 0) HIP_TRY(hipMemcpy(dst, e->d_enc + first, count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int gtamd_encoder_get_summary(const gtamd_encoder *e, gtamd_encode_summary *s) {
+  TRY(need_finished(e));
+  *s = e->sum;
+  return 0;
+}
+
+extern "C" int gtamd_encoder_file_lengths(const gtamd_encoder *e, size_t file,
+                                          uint64_t *length, uint64_t *effectivelength) {
+  TRY(need_finished(e));
+  if (file >= e->files.size()) { gtamd_set_error("no input file %zu", file); return -1; }
+  const InputFile &f = e->files[file];
+  // symbols plus the separators between the file's own sequences
+  // (src/core/sequence_buffer_fasta.c:133-146,156)
+  const u64 own_separators = f.ndesc > 0 ? f.ndesc - 1 : 0;
+  u64 separators_written = f.ndesc;
+  if (f.ndesc > 0 && f.desc_base == 0) separators_written--;   // first record of all
+  *length = f.length;
+  *effectivelength = f.out_len - separators_written + own_separators;
+  return 0;
+}
+
+extern "C" uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *e) {
+  return e != nullptr && e->finished ? e->ndesc : 0;
+}
+
+extern "C" int gtamd_encoder_get_descriptions(const gtamd_encoder *e, uint32_t *file,
+                                              uint64_t *start, uint64_t *end) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->ndesc == 0) return 0;
+  HIP_TRY(hipMemcpy(start, e->d_desc_start, e->ndesc * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(end, e->d_desc_end, e->ndesc * 8, hipMemcpyDeviceToHost));
+  for (size_t fi = 0; fi < e->files.size(); fi++) {
+    const InputFile &f = e->files[fi];
+    for (u64 k = 0; k < f.ndesc; k++) {
+      file[f.desc_base + k] = (uint32_t) fi;
+      // a description that the end of the file cuts off
+      if (end[f.desc_base + k] == NONE64) end[f.desc_base + k] = f.length;
+    }
+  }
+  return 0;
+}
+
+extern "C" int gtamd_encoder_get_timing(const gtamd_encoder *e, float *total_ms,
+                                        float *parse_ms, float *stats_ms,
+                                        uint64_t *input_bytes) {
+  TRY(need_finished(e));
+  if (total_ms) *total_ms = e->total_ms;
+  if (parse_ms) *parse_ms = e->parse_ms;
+  if (stats_ms) *stats_ms = e->stats_ms;
+  if (input_bytes) *input_bytes = e->input_bytes;
+  return 0;
+}

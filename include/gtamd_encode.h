@@ -1,0 +1,95 @@
+/*
+  gtamd_encode.h -- C ABI of the device-side sequence encoder: FASTA bytes in,
+  encoded symbols (0..sigma-1, 254 wildcard, 255 separator) resident in HBM
+  out, together with every number the reference's encoder derives while it
+  reads the input.  It replaces the read side of gt_encseq_encoder_encode:
+
+    gt_sequence_buffer_fasta_advance    src/core/sequence_buffer_fasta.c:41-171
+      (the two-state reader: '>' opens a description anywhere outside one,
+       '\n' closes it, white space is skipped, consecutive sequences -- also
+       across files -- are joined by one separator)
+    process_char                        src/core/sequence_buffer_inline.h:26-58
+      (symbol map, "illegal character" error, character distribution)
+    gt_inputfiles2sequencekeyvalues     src/core/encseq.c:5421-5673 with
+      encseq_charproc.gen (special/wildcard ranges, prefix/suffix lengths,
+       longest non-special stretch, min/max sequence length, equal-length
+       test, file length table, distribution of the original characters)
+
+  The reference reads the input byte by byte, twice; here one file is one
+  device buffer and every step is a tile-parallel kernel (tile-local state
+  machine + scans over tile summaries).  FASTQ input stays with the host
+  reader (include/gtamd_host.h).
+
+  Conventions as in gtamd_esa.h: 0 / -1, message from gtamd_esa_last_error(),
+  worded like the reference's ("illegal character 'X': file \"f\", line 3",
+  "file 'f' contains an empty sequence", "no sequences in multiple fasta
+  file(s) f ...").  No CPU fallback.
+*/
+#ifndef GTAMD_ENCODE_H
+#define GTAMD_ENCODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gtamd_encoder gtamd_encoder;
+
+/* what gt_inputfiles2sequencekeyvalues returns besides the symbols; the three
+   "tab" entries are the stored-range counts for 8-, 16- and 32-bit range
+   tables (currentspecialrangevalue, src/core/encseq.c:5061-5074) */
+typedef struct {
+  uint64_t totallength, numofsequences;
+  uint64_t specialcharacters, realspecialranges, specialrangestab[3],
+           lengthofspecialprefix, lengthofspecialsuffix;
+  uint64_t wildcards, realwildcardranges, wildcardrangestab[3],
+           lengthofwildcardprefix, lengthofwildcardsuffix;
+  uint64_t lengthoflongestnonspecial, minseqlen, maxseqlen;
+  uint64_t equallength;                  /* 1: all sequences equally long and
+                                            without wildcard */
+  uint64_t characterdistribution[32];    /* per symbol code */
+  uint64_t originaldistribution[256];    /* per input byte, sequences only */
+} gtamd_encode_summary;
+
+gtamd_encoder *gtamd_encoder_create(int device, int protein);
+void gtamd_encoder_destroy(gtamd_encoder *enc);
+
+/* One input file, in -db order: its name (for messages) and its bytes in host
+   memory, which must stay valid until gtamd_encoder_finish returns. */
+int gtamd_encoder_add_file(gtamd_encoder *enc, const char *name,
+                           const uint8_t *bytes, uint64_t length);
+
+/* Encode all files added so far into one sequence. */
+int gtamd_encoder_finish(gtamd_encoder *enc);
+
+uint64_t gtamd_encoder_length(const gtamd_encoder *enc);
+/* the symbols in device memory (valid until destroy), e.g. for
+   gtamd_esa_set_sequence_bytes(ctx, ptr, n, 1) */
+const uint8_t *gtamd_encoder_device_symbols(const gtamd_encoder *enc);
+int gtamd_encoder_copy_symbols(const gtamd_encoder *enc, uint8_t *dst,
+                               uint64_t first, uint64_t count);
+int gtamd_encoder_get_summary(const gtamd_encoder *enc, gtamd_encode_summary *s);
+
+/* GtFilelengthvalues of input file `file` */
+int gtamd_encoder_file_lengths(const gtamd_encoder *enc, size_t file,
+                               uint64_t *length, uint64_t *effectivelength);
+
+/* Descriptions: one per sequence, as byte ranges [start, end) of the file they
+   came from (start is behind the '>', end is the terminating newline or the
+   end of the file; a carriage return inside is the caller's to drop, as the
+   reference does).  Arrays of gtamd_encoder_num_descriptions() entries. */
+uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *enc);
+int gtamd_encoder_get_descriptions(const gtamd_encoder *enc, uint32_t *file,
+                                   uint64_t *start, uint64_t *end);
+
+/* device time of the last finish (ms, HIP events) and the bytes it read */
+int gtamd_encoder_get_timing(const gtamd_encoder *enc, float *total_ms,
+                             float *parse_ms, float *stats_ms,
+                             uint64_t *input_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads and exports
-every symbol include/gtamd_esa.h declares; host-only entry points work; compute
+every symbol include/gtamd_esa.h and include/gtamd_encode.h declare; host-only entry points work; compute
 entry points fail loudly without a device (no CPU fallback)."""
 import os
 import re
@@ -9,14 +9,17 @@ import pytest
 
 from genometools_amd import _lib
 
-HEADER = os.path.join(_lib.ROOT, "include", "gtamd_esa.h")
+HEADERS = [os.path.join(_lib.ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h")]
 
 
 def _declared_symbols():
-    with open(HEADER) as f:
-        text = f.read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gtamd_[a-z_0-9]+)\s*\(", text)))
+    found = set()
+    for header in HEADERS:
+        with open(header) as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        found.update(re.findall(r"\b(gtamd_[a-z_0-9]+)\s*\(", text))
+    return sorted(found)
 
 
 def test_library_builds_and_loads():
@@ -66,6 +69,8 @@ def test_no_cpu_fallback():
     if lib.gtamd_device_count() > 0:
         pytest.skip("a device is present")
     assert not lib.gtamd_esa_create(0, 1000, 4)
+    assert b"no HIP device" in lib.gtamd_esa_last_error()
+    assert not lib.gtamd_encoder_create(0, 0)
     assert b"no HIP device" in lib.gtamd_esa_last_error()
     enc = np.zeros(10, dtype=np.uint8)
     suf = np.zeros(11, dtype=np.uint64)

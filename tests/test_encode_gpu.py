@@ -1,0 +1,193 @@
+"""Device FASTA encoder (csrc/esa_encode.hip, include/gtamd_encode.h) against
+the C host reader -- itself pinned to the reference's encoder by the golden
+.prj/.esq/.des files -- and against numpy restatements of the run statistics."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from genometools_amd import encode, synth
+from genometools_amd._lib import EsaError
+from test_host import EncInfo, host  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+GOLDEN = ou.golden()
+FASTA = sorted(n for n in GOLDEN if not n.endswith(".fastq"))
+MULTI_FASTA = [["part1.fna", "part2.fna"], ["part2.fna", "part1.fna", "part2.fna"]]
+
+
+def _host_encode(host, paths, protein):
+    """symbols, descriptions, original-character histogram and file lengths of
+    the host reader"""
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    dptr, dlen = ctypes.c_void_p(), ctypes.c_uint64()
+    info = EncInfo()
+    err = ctypes.create_string_buffer(2048)
+    if host.gtamd_encode_files_info(arr, len(paths), int(protein), ctypes.byref(ptr),
+                                    ctypes.byref(n), ctypes.byref(dptr), ctypes.byref(dlen),
+                                    ctypes.byref(info), err, 2048) != 0:
+        raise ValueError(err.value.decode())
+    enc = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)),
+                                shape=(n.value,)).copy()
+    desc = ctypes.string_at(dptr, dlen.value).split(b"\0")[:-1]
+    fl = np.ctypeslib.as_array(ctypes.cast(info.filelengthtab, ctypes.POINTER(ctypes.c_uint64)),
+                               shape=(2 * len(paths),)).copy().reshape(-1, 2)
+    orig = list(info.originaldistribution)
+    host.gtamd_encinfo_free(ctypes.byref(info))
+    libc = ctypes.CDLL(None)
+    libc.free(ptr)
+    libc.free(dptr)
+    return enc, desc, orig, [tuple(int(x) for x in row) for row in fl]
+
+
+def _runs(mask):
+    """lengths of the maximal runs of True"""
+    m = np.concatenate([[False], mask, [False]]).astype(np.int8)
+    d = np.diff(m)
+    return np.flatnonzero(d == -1) - np.flatnonzero(d == 1)
+
+
+def _expected_summary(enc, sigma):
+    sp, wc = _runs(enc >= 254), _runs(enc == 254)
+    seqs, nonsp = _runs(enc != 255), _runs(enc < 254)
+
+    def lead(mask):
+        return int(np.argmin(mask)) if not mask.all() else mask.size
+
+    def pieces(r, maxv):
+        return int(((r + maxv) // (maxv + 1)).sum())
+    return {
+        "totallength": enc.size, "numofsequences": int((enc == 255).sum()) + 1,
+        "specialcharacters": int((enc >= 254).sum()), "realspecialranges": sp.size,
+        "specialrangestab": [pieces(sp, 255), pieces(sp, 65535), sp.size],
+        "lengthofspecialprefix": lead(enc >= 254),
+        "lengthofspecialsuffix": lead((enc >= 254)[::-1]),
+        "wildcards": int((enc == 254).sum()), "realwildcardranges": wc.size,
+        "wildcardrangestab": [pieces(wc, 255), pieces(wc, 65535), wc.size],
+        "lengthofwildcardprefix": lead(enc == 254),
+        "lengthofwildcardsuffix": lead((enc == 254)[::-1]),
+        "lengthoflongestnonspecial": int(nonsp.max()) if nonsp.size else 0,
+        "minseqlen": int(seqs.min()), "maxseqlen": int(seqs.max()),
+        "equallength": int(seqs.min() == seqs.max() and not (enc == 254).any()),
+        "characterdistribution": [int((enc == c).sum()) for c in range(sigma)] + [0] * (32 - sigma),
+    }
+
+
+def _check(host, paths, protein):
+    want_enc, want_desc, want_orig, want_fl = _host_encode(host, paths, protein)
+    with encode.DeviceEncoder(protein=protein) as de:
+        de.encode(paths)
+        got = de.symbols()
+        assert de.length == want_enc.size
+        assert np.array_equal(got, want_enc)
+        assert de.descriptions() == want_desc
+        assert de.file_lengths() == want_fl
+        s = de.summary()
+    assert s["originaldistribution"] == want_orig
+    exp = _expected_summary(want_enc, 20 if protein else 4)
+    for k, v in exp.items():
+        assert s[k] == v, k
+    return s
+
+
+@pytest.mark.parametrize("name", FASTA)
+def test_device_encoder_matches_host_reader(gpu, host, name):
+    e = GOLDEN[name]
+    s = _check(host, [ou.fixture_path(name)], e["alphabet"] == "protein")
+    # and the reference's own numbers (.prj written by gt suffixerator)
+    prj = dict(l.split("=") for l in e["prj"].splitlines())
+    for k in ("totallength", "specialcharacters", "realspecialranges", "wildcards",
+              "realwildcardranges", "lengthofspecialprefix", "lengthofspecialsuffix",
+              "lengthofwildcardprefix", "lengthofwildcardsuffix", "numofsequences"):
+        assert s[k] == int(prj[k]), k
+    assert int(prj["specialranges"]) in s["specialrangestab"]
+    assert int(prj["wildcardranges"]) in s["wildcardrangestab"]
+
+
+@pytest.mark.parametrize("files", MULTI_FASTA)
+def test_device_encoder_joins_files(gpu, host, files):
+    _check(host, [os.path.join(ou.GOLDEN_DIR, "multi", f) for f in files], False)
+
+
+def test_device_encoder_state_machine_corner_cases(gpu, host, tmp_path):
+    cases = {
+        # no '>' before the first symbols; a description cut off by the end of file
+        "headless.fna": b"ACGT\nAC\n>second\nGG\n>third no newline",
+        # '>' in the middle of a line opens a description there
+        "midline.fna": b">a\nACGT>b rest of line\nTTTT\n",
+        # CRLF, blank lines, tabs and form feeds inside the sequence
+        "blanks.fna": b">x y\r\nAC GT\r\n\r\n\tNN\x0cA\r\n>z\r\nT\r\n",
+        # '>' inside a description does not open another one
+        "gt_in_desc.fna": b">a > b >> c\nACGT\n>d\nA\n",
+    }
+    for name, raw in cases.items():
+        p = tmp_path / name
+        p.write_bytes(raw)
+        if name == "headless.fna":
+            with pytest.raises(EsaError, match="headless.fna' contains an empty sequence"):
+                encode.DeviceEncoder().encode([str(p)])
+            with pytest.raises(ValueError, match="contains an empty sequence"):
+                _host_encode(host, [str(p)], False)
+            p.write_bytes(raw + b"\nA")
+        _check(host, [str(p)], False)
+    # tile boundaries: descriptions and line ends around multiples of 4096
+    rng = np.random.default_rng(7)
+    for width in (4093, 4094, 4095, 4096, 4097, 8191):
+        seq = "".join(rng.choice(list("ACGTN"), size=3 * width))
+        p = tmp_path / ("w%d.fna" % width)
+        p.write_text(">%s\n%s\n>%s\n%s" % ("d" * (width - 2), seq[:width], "e" * 5000,
+                                           seq[width:]))
+        _check(host, [str(p)], False)
+
+
+def test_device_encoder_errors_use_the_reference_wording(gpu, tmp_path):
+    p = tmp_path / "bad.fna"
+    p.write_text(">a\nACGT\nACXT\n")
+    with pytest.raises(EsaError, match=r"illegal character 'X': file \".*bad.fna\", line 3"):
+        encode.DeviceEncoder().encode([str(p)])
+    p.write_text(">a\n>b\nACGT\n")
+    with pytest.raises(EsaError, match="bad.fna' contains an empty sequence"):
+        encode.DeviceEncoder().encode([str(p)])
+    p.write_text(">a\nacgt\n>b\n")
+    with pytest.raises(EsaError, match="contains an empty sequence"):
+        encode.DeviceEncoder().encode([str(p)])
+    p.write_text("ACGT\nACGT\n")
+    with pytest.raises(EsaError, match=r"no sequences in multiple fasta file\(s\) .*bad.fna"):
+        encode.DeviceEncoder().encode([str(p)])
+    p.write_text(">p\nlvif\n")
+    with pytest.raises(EsaError, match="illegal character 'l'"):
+        encode.DeviceEncoder(protein=True).encode([str(p)])
+    # the first illegal byte of a large input, far from the start
+    big = np.frombuffer(b">x\n" + b"ACGT" * 3_000_000 + b"\n", dtype=np.uint8).copy()
+    big[9_000_001] = ord("!")
+    big[11_000_000] = ord("?")
+    q = tmp_path / "big.fna"
+    big.tofile(q)
+    with pytest.raises(EsaError, match=r"illegal character '!': file \".*big.fna\", line 2"):
+        encode.DeviceEncoder().encode([str(q)])
+
+
+def test_device_encoder_large_input_and_engine_handover(gpu, host, tmp_path):
+    """64 Mbp human-like genome as a 70-column FASTA: same symbols and numbers
+    as the host reader; the encoded sequence goes to the ESA engine without
+    leaving the device"""
+    from genometools_amd import esa
+    n = 64_000_000
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 43, n)
+    path = str(tmp_path / "h64m.fna")
+    synth.write_fasta(path, enc)
+    s = _check(host, [path], False)
+    assert s["totallength"] == n
+    with encode.DeviceEncoder() as de:
+        de.encode([path])
+        t = de.timing()
+        print("device encoder: %.1f MB in %.2f ms (parse %.2f, statistics %.2f)"
+              % (t["input_bytes"] / 1e6, t["total_ms"], t["parse_ms"], t["stats_ms"]))
+        with esa.EsaEngine(n, 4) as eng:
+            eng.set_sequence_device(de.device_pointer, de.length)
+            eng.run(esa.WANT_SUF)
+            suf = eng.table(esa.TAB_SUF)
+    assert ou.check_suffix_array(enc, suf)[0] == 0

@@ -322,6 +322,108 @@ __global__ void k_empty_sequence(const u8 *enc, u64 n, unsigned long long *first
     atomicMin(first, (unsigned long long) i);
 }
 
+// ---- sections of INDEX.esq from the symbols in HBM -------------------------
+// (layouts: src/core/encseq.c:85-99, 2594-2607, 2771-2835, 2324-2447)
+
+// two bits per symbol, 32 symbols per word, first symbol in the top bits;
+// specials: bit access stores wildcard = 0 / separator = 1, the other access
+// types store the least frequent letter
+__global__ void k_esq_twobit(const u8 *enc, u64 n, u64 units, int bitaccess,
+                             u32 fill, u64 *words) {
+  const u64 w = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= units) return;
+  const u64 base = w * 32;
+  u64 v = 0;
+  if (base + 32 <= n) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(enc + base);
+    const uint4 q[2] = {p[0], p[1]};
+    const u32 *x = reinterpret_cast<const u32 *>(q);
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+      const u32 c = (x[j >> 2] >> (8 * (j & 3))) & 255;
+      const u64 code = c < GTAMD_WILDCARD ? c
+                     : bitaccess ? (c == GTAMD_SEPARATOR ? 1u : 0u) : fill;
+      v |= code << (62 - 2 * j);
+    }
+  } else {
+    for (int j = 0; j < 32 && base + j < n; j++) {
+      const u32 c = enc[base + j];
+      const u64 code = c < GTAMD_WILDCARD ? c
+                     : bitaccess ? (c == GTAMD_SEPARATOR ? 1u : 0u) : fill;
+      v |= code << (62 - 2 * j);
+    }
+  }
+  words[w] = v;
+}
+
+// one bit per position, first position in the top bit; the 64 positions behind
+// the sequence are set as well
+__global__ void k_esq_specialbits(const u8 *enc, u64 n, u64 units, u64 *words) {
+  const u64 w = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= units) return;
+  const u64 base = w * 64;
+  u64 v = 0;
+  for (int j = 0; j < 64; j++) {
+    const u64 pos = base + j;
+    const bool bit = pos < n ? enc[pos] >= GTAMD_WILDCARD : pos < n + 64;
+    v |= (u64) bit << (63 - j);
+  }
+  words[w] = v;
+}
+
+// bits per symbol, most significant bit first: 8 symbols -> `bits` bytes;
+// wildcard = sigma, separator = sigma + 1
+__global__ void k_esq_bitpack(const u8 *enc, u64 n, u32 sigma, u32 bits, u64 nbytes,
+                              u8 *out) {
+  const u64 t = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t * 8 >= n) return;
+  u64 v = 0;
+  for (int j = 0; j < 8; j++) {
+    const u64 pos = t * 8 + j;
+    u32 c = pos < n ? enc[pos] : 0;
+    if (pos < n && c >= GTAMD_WILDCARD) c = c == GTAMD_WILDCARD ? sigma : sigma + 1;
+    v = (v << bits) | c;
+  }
+  for (u32 k = 0; k < bits; k++) {
+    const u64 at = t * bits + k;
+    if (at < nbytes) out[at] = (u8) (v >> (8 * (bits - 1 - k)));
+  }
+}
+
+enum { POS_WILDCARD_START = 0, POS_WILDCARD_END, POS_SEPARATOR };
+
+// positions of one kind in increasing order: count per tile, then (after a scan
+// of the counts) write
+template <int EMIT>
+__global__ __launch_bounds__(EN_THREADS) void k_positions(
+    const u8 *enc, u64 n, int kind, u32 *tile_count, const u32 *tile_off, u64 *out) {
+  __shared__ u32 lds[EN_THREADS / 64];
+  const u64 tile = blockIdx.x, base = tile * EN_TILE + (u64) threadIdx.x * EN_PER;
+  u8 b[EN_PER + 2];          // b[0] = symbol before, b[EN_PER + 1] = symbol behind
+  for (int j = 0; j < EN_PER + 2; j++) {
+    const u64 pos = base + j;             // position + 1
+    b[j] = pos >= 1 && pos - 1 < n ? enc[pos - 1] : (u8) 0;
+  }
+  u32 flags = 0, cnt = 0;
+  for (int j = 0; j < EN_PER; j++) {
+    if (base + j >= n) break;
+    const u8 c = b[j + 1];
+    const bool hit = kind == POS_SEPARATOR ? c == GTAMD_SEPARATOR
+                   : kind == POS_WILDCARD_START ? c == GTAMD_WILDCARD && b[j] != GTAMD_WILDCARD
+                   : c == GTAMD_WILDCARD && b[j + 2] != GTAMD_WILDCARD;
+    if (hit) { flags |= 1u << j; cnt++; }
+  }
+  u32 total;
+  const u32 before = block_scan_excl<SCAN_SUM, EN_THREADS>(cnt, &total, lds);
+  if (!EMIT) {
+    if (threadIdx.x == 0) tile_count[tile] = total;
+    return;
+  }
+  u64 at = (u64) tile_off[tile] + before;
+  for (int j = 0; j < EN_PER; j++)
+    if (flags & (1u << j)) out[at++] = base + j;
+}
+
 struct InputFile {
   std::string name;
   const u8 *bytes;
@@ -732,4 +834,137 @@ extern "C" int gtamd_encoder_get_timing(const gtamd_encoder *e, float *total_ms,
   if (stats_ms) *stats_ms = e->stats_ms;
   if (input_bytes) *input_bytes = e->input_bytes;
   return 0;
+}
+
+// ---- INDEX.esq sections ---------------------------------------------------
+static int launch_1d(u64 items, u32 *blocks) {
+  const u64 b = div_up(items, 256);
+  if (b == 0 || b > 0x7fffffffull) { gtamd_set_error("launch of %llu items", (unsigned long long) items); return -1; }
+  *blocks = (u32) b;
+  return 0;
+}
+
+extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
+                                         unsigned fillcode, uint64_t *words) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  const u64 units = e->n < 32 ? 2 : 2 + (e->n - 1) / 32;
+  u64 *d;
+  u32 blocks;
+  TRY(dev_alloc(&d, units));
+  int rc = launch_1d(units, &blocks);
+  if (rc == 0) {
+    k_esq_twobit<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, units, bitaccess, fillcode & 3, d);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(words, d, units * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("packing the two-bit encoding on the device failed");
+      rc = -1;
+    }
+  }
+  (void) hipFree(d);
+  return rc;
+}
+
+extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *words) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  const u64 units = 1 + (e->n + 63) / 64;
+  u64 *d;
+  u32 blocks;
+  TRY(dev_alloc(&d, units));
+  int rc = launch_1d(units, &blocks);
+  if (rc == 0) {
+    k_esq_specialbits<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, units, d);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(words, d, units * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("packing the special bits on the device failed");
+      rc = -1;
+    }
+  }
+  (void) hipFree(d);
+  return rc;
+}
+
+extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *bytes) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  const u32 sigma = e->protein ? 20 : 4, bits = e->protein ? 5 : 3;
+  const u64 nbytes = (bits * e->n + 7) / 8;
+  u8 *d;
+  u32 blocks;
+  TRY(dev_alloc(&d, nbytes));
+  int rc = launch_1d(div_up(e->n, 8), &blocks);
+  if (rc == 0) {
+    k_esq_bitpack<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, sigma, bits, nbytes, d);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(bytes, d, nbytes, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("bit-packing the symbols on the device failed");
+      rc = -1;
+    }
+  }
+  (void) hipFree(d);
+  return rc;
+}
+
+// the `expected` positions of one kind, in increasing order, to host memory
+static int positions_to_host(const gtamd_encoder *e, int kind, u64 expected, u64 *out) {
+  if (expected == 0) return 0;
+  const u64 ntiles = div_up(e->n, EN_TILE);
+  u32 *d_cnt = nullptr, *d_ws = nullptr;
+  u64 *d_out = nullptr;
+  int rc = -1;
+  do {
+    if (dev_alloc(&d_cnt, 2 * ntiles) != 0 || dev_alloc(&d_out, expected) != 0 ||
+        dev_alloc(&d_ws, scan_workspace_words(ntiles)) != 0)
+      break;
+    k_positions<0><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(e->d_enc, e->n, kind, d_cnt,
+                                                          nullptr, nullptr);
+    if (hipGetLastError() != hipSuccess) { gtamd_set_error("k_positions launch failed"); break; }
+    if (scan_u32(SCAN_SUM, d_cnt, d_cnt + ntiles, ntiles, false, d_ws, e->st) != 0) break;
+    u32 last[2];
+    if (hipMemcpyAsync(&last[0], d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipMemcpyAsync(&last[1], d_cnt + 2 * ntiles - 1, 4, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("reading position counts from the device failed");
+      break;
+    }
+    if ((u64) last[0] + last[1] != expected) {
+      gtamd_set_error("found %llu positions, the sequence statistics say %llu",
+                      (unsigned long long) last[0] + last[1], (unsigned long long) expected);
+      break;
+    }
+    k_positions<1><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(e->d_enc, e->n, kind, nullptr,
+                                                          d_cnt + ntiles, d_out);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(out, d_out, expected * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
+        hipStreamSynchronize(e->st) != hipSuccess) {
+      gtamd_set_error("collecting positions on the device failed");
+      break;
+    }
+    rc = 0;
+  } while (0);
+  if (d_cnt) (void) hipFree(d_cnt);
+  if (d_out) (void) hipFree(d_out);
+  if (d_ws) (void) hipFree(d_ws);
+  return rc;
+}
+
+extern "C" int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *e, uint64_t *start,
+                                               uint64_t *length) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  const u64 runs = e->sum.realwildcardranges;
+  TRY(positions_to_host(e, POS_WILDCARD_START, runs, start));
+  TRY(positions_to_host(e, POS_WILDCARD_END, runs, length));
+  for (u64 r = 0; r < runs; r++) length[r] = length[r] - start[r] + 1;
+  return 0;
+}
+
+extern "C" int gtamd_encoder_get_separators(const gtamd_encoder *e, uint64_t *pos) {
+  TRY(need_finished(e));
+  HIP_TRY(hipSetDevice(e->device));
+  return positions_to_host(e, POS_SEPARATOR, e->sum.numofsequences - 1, pos);
 }

@@ -4,6 +4,8 @@
 #include "gtamd_md5.h"
 #include "host_internal.h"
 #include <limits.h>
+#include <pthread.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -415,34 +417,88 @@ int gtamd_write_des_sds(const char *indexname, const char *desc,
   return 0;
 }
 
-int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
-                    int protein)
+/* MD5 of one sequence: its decoded symbols in upper case, a wildcard decodes
+   to the alphabet's wildcard character (N / X) */
+static void md5_of_sequence(const uint8_t *enc, uint64_t len, int protein, char hex[33])
 {
   static const char dna[] = "ACGT", prot[] = "LVIFKREDAGSTNQYWPHMC";
-  char path[4096], hex[33];
   uint8_t block[4096];
   size_t fill = 0;
   gtamd_md5 st;
-  FILE *fp;
-  snprintf(path, sizeof path, "%s.md5", indexname);
-  if ((fp = fopen(path, "wb")) == NULL) return -1;
   gtamd_md5_init(&st);
-  for (uint64_t i = 0; i <= n; i++) {
-    if (i == n || enc[i] == GTAMD_SEPARATOR) {
-      gtamd_md5_update(&st, block, fill);
-      fill = 0;
-      gtamd_md5_hex(&st, hex);
-      fwrite(hex, 1, 33, fp);
-      gtamd_md5_init(&st);
-      continue;
-    }
-    /* decoded symbol, upper case; a wildcard decodes to the alphabet's
-       wildcard character (n / X) */
+  for (uint64_t i = 0; i < len; i++) {
     block[fill++] = enc[i] == GTAMD_WILDCARD ? (uint8_t) (protein ? 'X' : 'N')
                                              : (uint8_t) (protein ? prot[enc[i]] : dna[enc[i]]);
     if (fill == sizeof block) { gtamd_md5_update(&st, block, fill); fill = 0; }
   }
-  return fclose(fp) == 0 ? 0 : -1;
+  gtamd_md5_update(&st, block, fill);
+  gtamd_md5_hex(&st, hex);
+}
+
+typedef struct {
+  const uint8_t *enc;
+  const uint64_t *start, *len;     /* of the sequences of this batch */
+  uint64_t count;
+  int protein;
+  char *hex;                       /* 33 bytes per sequence */
+  uint64_t next;                   /* work counter, handed out under the lock */
+  pthread_mutex_t lock;
+} md5_batch;
+
+static void *md5_worker(void *arg)
+{
+  md5_batch *b = arg;
+  for (;;) {
+    uint64_t k;
+    pthread_mutex_lock(&b->lock);
+    k = b->next++;
+    pthread_mutex_unlock(&b->lock);
+    if (k >= b->count) return NULL;
+    md5_of_sequence(b->enc + b->start[k], b->len[k], b->protein, b->hex + 33 * k);
+  }
+}
+
+int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
+                    int protein)
+{
+  /* the sums of different sequences are independent: batches of sequences go
+     to a few threads, longest-first order does not matter at this grain */
+  enum { BATCH = 1 << 16, MAXTHREADS = 16 };
+  char path[4096];
+  uint64_t *start = malloc(sizeof *start * BATCH), *len = malloc(sizeof *len * BATCH),
+           pos = 0;
+  char *hex = malloc(33 * (size_t) BATCH);
+  long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+  int nthreads = ncpu < 1 ? 1 : ncpu > MAXTHREADS ? MAXTHREADS : (int) ncpu, rc = -1;
+  FILE *fp = NULL;
+  snprintf(path, sizeof path, "%s.md5", indexname);
+  if (start == NULL || len == NULL || hex == NULL || (fp = fopen(path, "wb")) == NULL) goto done;
+  while (pos <= n) {
+    md5_batch b;
+    pthread_t th[MAXTHREADS];
+    int started = 0;
+    uint64_t count = 0;
+    while (count < BATCH && pos <= n) {
+      const uint8_t *sep = pos < n ? memchr(enc + pos, GTAMD_SEPARATOR, n - pos) : NULL;
+      const uint64_t end = sep != NULL ? (uint64_t) (sep - enc) : n;
+      start[count] = pos; len[count] = end - pos; count++;
+      pos = end + 1;
+    }
+    b.enc = enc; b.start = start; b.len = len; b.count = count; b.protein = protein;
+    b.hex = hex; b.next = 0;
+    pthread_mutex_init(&b.lock, NULL);
+    for (int t = 1; t < nthreads && (uint64_t) t < count; t++)
+      if (pthread_create(&th[started], NULL, md5_worker, &b) == 0) started++;
+    (void) md5_worker(&b);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    pthread_mutex_destroy(&b.lock);
+    if (fwrite(hex, 33, count, fp) != count) goto done;
+  }
+  rc = 0;
+done:
+  if (fp != NULL && fclose(fp) != 0) rc = -1;
+  free(start); free(len); free(hex);
+  return rc;
 }
 
 /* a run of `len` specials is stored as this many table entries when the run
@@ -484,7 +540,7 @@ void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
 {
   runstat sp, wc;
   gtamd_seqstats *st = &an->ss;
-  uint64_t seqlen = 0, nsep = 0, nonspecial = 0, eqvalue = 0, best;
+  uint64_t seqlen = 0, nsep = 0, nonspecial = 0, eqvalue = 0;
   int equal = 1;
   memset(an, 0, sizeof *an);
   memset(&sp, 0, sizeof sp); memset(&wc, 0, sizeof wc);
@@ -520,34 +576,63 @@ void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
   st->lengthofspecialprefix = sp.prefix; st->lengthofspecialsuffix = sp.suffix;
   st->wildcards = wc.chars; st->realwildcardranges = wc.runs;
   st->lengthofwildcardprefix = wc.prefix; st->lengthofwildcardsuffix = wc.suffix;
+  gtamd_choose_access_type(an, sp.tab, wc.tab);
+}
+
+void gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
+                              const uint64_t wc_tab[3])
+{
+  gtamd_seqstats *st = &an->ss;
+  const uint64_t n = st->totallength, nsep = st->numofsequences - 1;
+  uint64_t best = 0;
   /* the "ranges" numbers are those of the smallest of the three table
      representations, whatever access type is used in the end
      (src/core/encseq.c:5215-5256, sizes encseq.c:924-949) */
-  best = 0;
   for (int k = 0; k < 3; k++) {
-    const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc.tab[k]);
+    const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc_tab[k]);
     if (k == 0 || size < best) {
-      best = size; st->specialranges = sp.tab[k]; st->wildcardranges = wc.tab[k];
+      best = size; st->specialranges = sp_tab[k]; st->wildcardranges = wc_tab[k];
     }
   }
   /* access type: non-DNA alphabets are bit-packed; DNA takes the smallest of
      bit access and the three table types, or "equal length" when all sequences
      have the same length and hold no wildcard
      (src/core/encseq_access_type.c:96-162) */
-  an->sat_wildcardranges = wc.tab[0];
-  if (numofchars != 4) an->sat = GTAMD_SAT_BYTECOMPRESS;
-  else if (equal) an->sat = GTAMD_SAT_EQUALLENGTH;
+  an->sat_wildcardranges = wc_tab[0];
+  if (st->numofchars != 4) an->sat = GTAMD_SAT_BYTECOMPRESS;
+  else if (an->equallength) an->sat = GTAMD_SAT_EQUALLENGTH;
   else {
     an->sat = GTAMD_SAT_BITACCESS;
-    best = (wc.tab[0] > 0 || nsep > 0) ? 8 * (1 + (n + 63) / 64) : 0;
+    best = (wc_tab[0] > 0 || nsep > 0) ? 8 * (1 + (n + 63) / 64) : 0;
     for (int k = 0; k < 3; k++) {
-      const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc.tab[k]);
+      const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc_tab[k]);
       if (size < best) {
         best = size; an->sat = GTAMD_SAT_UCHARTABLES + k;
-        an->sat_wildcardranges = wc.tab[k];
+        an->sat_wildcardranges = wc_tab[k];
       }
     }
   }
+}
+
+void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofchars,
+                                 gtamd_seqanalysis *an)
+{
+  gtamd_seqstats *st = &an->ss;
+  memset(an, 0, sizeof *an);
+  st->totallength = s->totallength; st->numofchars = numofchars;
+  st->numofsequences = s->numofsequences;
+  st->specialcharacters = s->specialcharacters; st->realspecialranges = s->realspecialranges;
+  st->lengthofspecialprefix = s->lengthofspecialprefix;
+  st->lengthofspecialsuffix = s->lengthofspecialsuffix;
+  st->wildcards = s->wildcards; st->realwildcardranges = s->realwildcardranges;
+  st->lengthofwildcardprefix = s->lengthofwildcardprefix;
+  st->lengthofwildcardsuffix = s->lengthofwildcardsuffix;
+  an->lengthoflongestnonspecial = s->lengthoflongestnonspecial;
+  an->minseqlen = s->minseqlen; an->maxseqlen = s->maxseqlen;
+  an->equallength = s->equallength != 0;
+  an->equallength_value = an->equallength ? s->maxseqlen : 0;
+  for (int c = 0; c < 32; c++) an->chardist[c] = s->characterdistribution[c];
+  gtamd_choose_access_type(an, s->specialrangestab, s->wildcardrangestab);
 }
 
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,

@@ -39,7 +39,7 @@ static void put_word(outfile *o, uint64_t w) { put(o, &w, sizeof w); }
    the number of ranges that start up to its end */
 typedef struct {
   int kind;                 /* 0 uchar, 1 ushort, 2 uint32 */
-  uint64_t items, fill, maxv, numofpages, page, nextcheck, current;
+  uint64_t items, numofpages;
   void *positions, *rangelengths;
   uint64_t *endidxinpage;
 } swtable;
@@ -47,22 +47,10 @@ typedef struct {
 static const uint64_t sw_maxv[3] = {UCHAR_MAX, USHRT_MAX, UINT32_MAX};
 static const size_t sw_width[3] = {1, 2, 4};
 
-static int sw_init(swtable *t, int kind, uint64_t n, uint64_t items, int withlengths)
-{
-  memset(t, 0, sizeof *t);
-  t->kind = kind; t->items = items; t->maxv = sw_maxv[kind];
-  t->numofpages = n / t->maxv + 1;
-  t->nextcheck = t->maxv;
-  t->positions = malloc(sw_width[kind] * (items ? items : 1));
-  t->rangelengths = withlengths ? malloc(sw_width[kind] * (items ? items : 1)) : NULL;
-  t->endidxinpage = malloc(sizeof (uint64_t) * t->numofpages);
-  return t->positions != NULL && t->endidxinpage != NULL
-         && (!withlengths || t->rangelengths != NULL) ? 0 : -1;
-}
-
 static void sw_free(swtable *t)
 {
   free(t->positions); free(t->rangelengths); free(t->endidxinpage);
+  t->positions = t->rangelengths = NULL; t->endidxinpage = NULL;
 }
 
 static void sw_store(void *tab, int kind, uint64_t idx, uint64_t v)
@@ -72,47 +60,45 @@ static void sw_store(void *tab, int kind, uint64_t idx, uint64_t v)
   else ((uint32_t *) tab)[idx] = (uint32_t) v;
 }
 
-/* a member position of a range table (wildcard) */
-static void sw_member(swtable *t, uint64_t pos)
+/* The table of `runs` maximal runs (start, length; length NULL: single
+   positions) for a sequence of n symbols, `items` stored ranges expected: a
+   run longer than the length field holds is cut into pieces of maxv + 1
+   (src/core/accspecialrange.gen:136-161); endidxinpage[p] counts the ranges
+   that start at or before the last position of page p (:210-215, 247-251). */
+static int sw_build(swtable *t, int kind, uint64_t n, const uint64_t *start,
+                    const uint64_t *length, uint64_t runs, uint64_t items)
 {
-  if (t->current == 0) {
-    if (t->fill < t->items) sw_store(t->positions, t->kind, t->fill, pos & t->maxv);
-    t->fill++;
-    t->current = 1;
-  } else if (t->current == t->maxv) {
-    /* the range is full: close it, the next member opens a new one */
-    sw_store(t->rangelengths, t->kind, t->fill - 1, t->maxv);
-    t->current = 0;
-  } else t->current++;
-}
-
-static void sw_nonmember(swtable *t)
-{
-  if (t->current > 0) {
-    sw_store(t->rangelengths, t->kind, t->fill - 1, t->current - 1);
-    t->current = 0;
+  const uint64_t maxv = sw_maxv[kind];
+  uint64_t fill = 0, page = 0;
+  memset(t, 0, sizeof *t);
+  t->kind = kind; t->items = items;
+  t->numofpages = n / maxv + 1;
+  t->positions = malloc(sw_width[kind] * (items ? items : 1));
+  t->rangelengths = length != NULL ? malloc(sw_width[kind] * (items ? items : 1)) : NULL;
+  t->endidxinpage = malloc(sizeof (uint64_t) * t->numofpages);
+  if (t->positions == NULL || t->endidxinpage == NULL ||
+      (length != NULL && t->rangelengths == NULL)) {
+    sw_free(t);
+    return -1;
   }
-}
-
-/* a separator position (.ssp holds single positions, no lengths) */
-static void sw_point(swtable *t, uint64_t pos)
-{
-  if (t->fill < t->items) sw_store(t->positions, t->kind, t->fill, pos & t->maxv);
-  t->fill++;
-}
-
-static void sw_anyposition(swtable *t, uint64_t pos)
-{
-  if (pos == t->nextcheck) {
-    t->endidxinpage[t->page++] = t->fill;
-    t->nextcheck += t->maxv + 1;
+  for (uint64_t r = 0; r < runs; r++) {
+    uint64_t pos = start[r], left = length != NULL ? length[r] : 1;
+    while (left > 0) {
+      const uint64_t piece = left < maxv + 1 ? left : maxv + 1;
+      /* pages that end before this range starts are complete */
+      while (page < t->numofpages && page * (maxv + 1) + maxv < pos)
+        t->endidxinpage[page++] = fill;
+      if (fill < items) {
+        sw_store(t->positions, kind, fill, pos & maxv);
+        if (length != NULL) sw_store(t->rangelengths, kind, fill, piece - 1);
+      }
+      fill++;
+      pos += piece; left -= piece;
+    }
   }
-}
-
-static void sw_finish(swtable *t, int withlengths)
-{
-  if (withlengths) sw_nonmember(t);
-  while (t->page < t->numofpages) t->endidxinpage[t->page++] = t->fill;
+  while (page < t->numofpages) t->endidxinpage[page++] = fill;
+  if (fill != items) { sw_free(t); return -2; }
+  return 0;
 }
 
 static void sw_put(outfile *o, const swtable *t, int withlengths)
@@ -137,8 +123,7 @@ static int ssp_kind(uint64_t n, uint64_t numofseparators)
 }
 
 /* number of distinct original characters and the size of the largest class of
-   characters mapped to one code (src/core/encseq.c:5275-5358); protein != 0
-   selects the alphabet, as in the encoder */
+   characters mapped to one code (src/core/encseq.c:5275-5358) */
 static void original_classes(const uint64_t *dist, const uint8_t *enc_of_char,
                              uint64_t *numofallchars, uint8_t *maxsubalphasize)
 {
@@ -154,31 +139,55 @@ static void original_classes(const uint64_t *dist, const uint8_t *enc_of_char,
     if (classsize[k] > *maxsubalphasize) *maxsubalphasize = (uint8_t) classsize[k];
 }
 
-int gtamd_write_esq(const char *indexname, const char *const *paths,
-                    size_t numfiles, const uint8_t *enc, uint64_t n,
-                    int protein, const gtamd_encinfo *info, int write_ssp,
-                    char *err, size_t errlen)
+unsigned gtamd_least_probable(const gtamd_seqanalysis *an)
+{
+  unsigned least = 0;
+  for (unsigned k = 1; k < an->ss.numofchars; k++)
+    if (an->chardist[k] < an->chardist[least]) least = k;
+  return least;
+}
+
+void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
+                     int *specialbits, int *packed, int *wildcardruns,
+                     int *separators)
+{
+  const uint64_t numsep = an->ss.numofsequences - 1;
+  const int viatables = an->sat >= GTAMD_SAT_UCHARTABLES;
+  *packed = an->sat == GTAMD_SAT_BYTECOMPRESS;
+  *twobit = !*packed;
+  *specialbits = an->sat == GTAMD_SAT_BITACCESS && (an->sat_wildcardranges > 0 || numsep > 0);
+  *wildcardruns = viatables && an->sat_wildcardranges > 0;
+  /* the separator table exists for table access types and on request */
+  *separators = numsep > 0 && an->sat != GTAMD_SAT_EQUALLENGTH && (write_ssp || viatables);
+}
+
+int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
+                             size_t numfiles, int protein,
+                             const gtamd_seqanalysis *an, const gtamd_encinfo *info,
+                             int write_ssp, const gtamd_esq_sections *sec,
+                             char *err, size_t errlen)
 {
   const uint32_t numofchars = protein ? 20 : 4;
-  gtamd_seqanalysis an;
+  const uint64_t n = an->ss.totallength, numsep = an->ss.numofsequences - 1;
   outfile o = {NULL, 0, 0};
   char path[4096];
-  uint64_t lengthofdbfilenames = 0, numofallchars, *twobit = NULL, units = 0,
-           *specialbits = NULL, bitunits = 0, numsep;
-  uint8_t maxsubalphasize, enc_of_char[256], *packed = NULL, *names = NULL;
-  unsigned least = 0;
+  uint64_t lengthofdbfilenames = 0, numofallchars;
+  uint8_t maxsubalphasize, enc_of_char[256], *names = NULL;
   swtable wct, sspt;
-  int have_wct = 0, have_ssp = 0, rc = -1, viatables;
+  int have_wct = 0, have_ssp = 0, rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
+  memset(&wct, 0, sizeof wct); memset(&sspt, 0, sizeof sspt);
   if (info == NULL || info->numfiles != numfiles) {
     snprintf(err, errlen, "file information of the encoder is missing");
     return -1;
   }
-  gtamd_analyse_sequence(enc, n, numofchars, &an);
-  numsep = an.ss.numofsequences - 1;
-  viatables = an.sat >= GTAMD_SAT_UCHARTABLES;
-  for (unsigned k = 1; k < numofchars; k++)
-    if (an.chardist[k] < an.chardist[least]) least = k;
+  gtamd_esq_needs(an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
+  if ((need_tb && sec->twobit == NULL) || (need_sb && sec->specialbits == NULL) ||
+      (need_pk && sec->packed == NULL) || (need_wc && sec->wc_start == NULL) ||
+      (need_sep && sec->seppos == NULL)) {
+    snprintf(err, errlen, "sequence sections of the encoded sequence are missing");
+    return -1;
+  }
   gtamd_symbolmap(enc_of_char, protein);
   original_classes(info->originaldistribution, enc_of_char, &numofallchars,
                    &maxsubalphasize);
@@ -189,65 +198,19 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
     memcpy(names + off, paths[f], strlen(paths[f]) + 1);
     off += strlen(paths[f]) + 1;
   }
-
-  /* the separator table exists for table access types and on request */
-  if (numsep > 0 && an.sat != GTAMD_SAT_EQUALLENGTH && (write_ssp || viatables)) {
-    if (sw_init(&sspt, ssp_kind(n, numsep), n, numsep, 0) != 0) goto nomem;
+  if (need_sep) {
+    const int brc = sw_build(&sspt, ssp_kind(n, numsep), n, sec->seppos, NULL, numsep, numsep);
+    if (brc == -1) goto nomem;
+    if (brc != 0) goto inconsistent;
     have_ssp = 1;
   }
-  if (viatables) {
-    if (sw_init(&wct, an.sat - GTAMD_SAT_UCHARTABLES, n, an.sat_wildcardranges, 1) != 0)
-      goto nomem;
+  if (an->sat >= GTAMD_SAT_UCHARTABLES) {
+    const int brc = sw_build(&wct, an->sat - GTAMD_SAT_UCHARTABLES, n, sec->wc_start,
+                             sec->wc_len, need_wc ? sec->wc_runs : 0, an->sat_wildcardranges);
+    if (brc == -1) goto nomem;
+    if (brc != 0) goto inconsistent;
     have_wct = 1;
   }
-  if (an.sat == GTAMD_SAT_BYTECOMPRESS) {
-    const uint64_t bytes = (5 * n + 7) / 8;
-    packed = calloc(bytes ? bytes : 1, 1);
-    if (packed == NULL) goto nomem;
-  } else {
-    units = n < 32 ? 2 : 2 + (n - 1) / 32;
-    twobit = calloc(units, sizeof *twobit);
-    if (twobit == NULL) goto nomem;
-    if (an.sat == GTAMD_SAT_BITACCESS) {
-      bitunits = 1 + (n + 63) / 64;
-      specialbits = calloc(bitunits, sizeof *specialbits);
-      if (specialbits == NULL) goto nomem;
-      for (uint64_t p = n; p < n + 64; p++)
-        specialbits[p / 64] |= (uint64_t) 1 << (63 - p % 64);
-    }
-  }
-
-  for (uint64_t pos = 0; pos < n; pos++) {
-    const uint8_t c = enc[pos];
-    if (have_wct) {
-      if (c == GTAMD_WILDCARD) sw_member(&wct, pos); else sw_nonmember(&wct);
-      sw_anyposition(&wct, pos);
-    }
-    if (have_ssp) {
-      if (c == GTAMD_SEPARATOR) sw_point(&sspt, pos);
-      sw_anyposition(&sspt, pos);
-    }
-    if (packed != NULL) {
-      /* 5 bits per symbol, most significant bit first; wildcard and separator
-         are the two codes behind the alphabet */
-      const unsigned v = c == GTAMD_WILDCARD ? numofchars
-                       : c == GTAMD_SEPARATOR ? numofchars + 1 : c;
-      const uint64_t bit = 5 * pos;
-      const unsigned shift = 16 - 5 - (unsigned) (bit % 8);
-      packed[bit / 8] |= (uint8_t) ((v << shift) >> 8);
-      if (shift < 8) packed[bit / 8 + 1] |= (uint8_t) (v << shift);
-    } else {
-      uint64_t code;
-      if (c < GTAMD_WILDCARD) code = c;
-      else if (an.sat == GTAMD_SAT_BITACCESS) {
-        code = c == GTAMD_SEPARATOR ? 1 : 0;
-        specialbits[pos / 64] |= (uint64_t) 1 << (63 - pos % 64);
-      } else code = least;
-      twobit[pos / 32] |= code << (62 - 2 * (pos % 32));
-    }
-  }
-  if (have_wct) sw_finish(&wct, 1);
-  if (have_ssp) sw_finish(&sspt, 0);
 
   snprintf(path, sizeof path, "%s.esq", indexname);
   if ((o.fp = fopen(path, "wb")) == NULL) {
@@ -257,34 +220,33 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
   {
     const uint8_t is64bit = 1;
     const uint64_t sci[14] = {
-      an.ss.specialcharacters, an.ss.specialranges, an.ss.realspecialranges,
-      an.ss.lengthofspecialprefix, an.ss.lengthofspecialsuffix, an.ss.wildcards,
-      an.ss.wildcardranges, an.ss.realwildcardranges,
-      an.ss.lengthofwildcardprefix, an.ss.lengthofwildcardsuffix,
-      an.lengthoflongestnonspecial, 0, 0, 0 };
+      an->ss.specialcharacters, an->ss.specialranges, an->ss.realspecialranges,
+      an->ss.lengthofspecialprefix, an->ss.lengthofspecialsuffix, an->ss.wildcards,
+      an->ss.wildcardranges, an->ss.realwildcardranges,
+      an->ss.lengthofwildcardprefix, an->ss.lengthofwildcardsuffix,
+      an->lengthoflongestnonspecial, 0, 0, 0 };
     put(&o, &is64bit, 1);
     put_word(&o, 3);                           /* format version */
-    put_word(&o, (uint64_t) an.sat);
+    put_word(&o, (uint64_t) an->sat);
     put_word(&o, n);
-    put_word(&o, an.ss.numofsequences);
+    put_word(&o, an->ss.numofsequences);
     put_word(&o, numfiles);
     put_word(&o, lengthofdbfilenames);
     put(&o, sci, sizeof sci);
-    put_word(&o, an.minseqlen);
-    put_word(&o, an.maxseqlen);
+    put_word(&o, an->minseqlen);
+    put_word(&o, an->maxseqlen);
     put_word(&o, protein ? 1 : 0);             /* alphabet type */
     put_word(&o, 0);                           /* no alphabet definition */
     put(&o, names, lengthofdbfilenames);
     put(&o, &maxsubalphasize, 1);
     put_word(&o, numofallchars);
     put(&o, info->filelengthtab, sizeof (gtamd_filelength) * numfiles);
-    put(&o, an.chardist, sizeof (uint64_t) * numofchars);
+    put(&o, an->chardist, sizeof (uint64_t) * numofchars);
   }
-  if (packed != NULL) put(&o, packed, (5 * n + 7) / 8);
+  if (need_pk) put(&o, sec->packed, (5 * n + 7) / 8);
   else {
-    put(&o, twobit, sizeof (uint64_t) * units);
-    if (an.sat == GTAMD_SAT_BITACCESS && (an.sat_wildcardranges > 0 || numsep > 0))
-      put(&o, specialbits, sizeof (uint64_t) * bitunits);
+    put(&o, sec->twobit, sizeof (uint64_t) * (n < 32 ? 2 : 2 + (n - 1) / 32));
+    if (need_sb) put(&o, sec->specialbits, sizeof (uint64_t) * (1 + (n + 63) / 64));
     if (have_wct) sw_put(&o, &wct, 1);
   }
   if (fclose(o.fp) != 0 || o.failed) {
@@ -310,12 +272,85 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
   }
   rc = 0;
   goto done;
+inconsistent:
+  snprintf(err, errlen, "range lists do not match the sequence statistics");
+  goto done;
 nomem:
   snprintf(err, errlen, "out of memory while writing the encoded sequence");
 done:
-  if (have_wct) sw_free(&wct);
-  if (have_ssp) sw_free(&sspt);
-  free(twobit); free(specialbits); free(packed); free(names);
+  sw_free(&wct); sw_free(&sspt);
+  free(names);
+  return rc;
+}
+
+/* the sequence sections by host loops over the symbols */
+int gtamd_write_esq(const char *indexname, const char *const *paths,
+                    size_t numfiles, const uint8_t *enc, uint64_t n,
+                    int protein, const gtamd_encinfo *info, int write_ssp,
+                    char *err, size_t errlen)
+{
+  const uint32_t numofchars = protein ? 20 : 4;
+  gtamd_seqanalysis an;
+  gtamd_esq_sections sec;
+  uint64_t *twobit = NULL, *specialbits = NULL, *wc_start = NULL, *wc_len = NULL,
+           *seppos = NULL, nwc = 0, nsep = 0;
+  uint8_t *packed = NULL;
+  unsigned least;
+  int rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
+
+  gtamd_analyse_sequence(enc, n, numofchars, &an);
+  gtamd_esq_needs(&an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
+  least = gtamd_least_probable(&an);
+  memset(&sec, 0, sizeof sec);
+  if (need_pk && (packed = calloc((5 * n + 7) / 8 + 1, 1)) == NULL) goto nomem;
+  if (need_tb && (twobit = calloc(n < 32 ? 2 : 2 + (n - 1) / 32, 8)) == NULL) goto nomem;
+  if (need_sb) {
+    if ((specialbits = calloc(1 + (n + 63) / 64, 8)) == NULL) goto nomem;
+    for (uint64_t p = n; p < n + 64; p++)
+      specialbits[p / 64] |= (uint64_t) 1 << (63 - p % 64);
+  }
+  if (need_wc) {
+    wc_start = malloc(8 * (an.ss.realwildcardranges + 1));
+    wc_len = malloc(8 * (an.ss.realwildcardranges + 1));
+    if (wc_start == NULL || wc_len == NULL) goto nomem;
+  }
+  if (need_sep && (seppos = malloc(8 * an.ss.numofsequences)) == NULL) goto nomem;
+  for (uint64_t pos = 0; pos < n; pos++) {
+    const uint8_t c = enc[pos];
+    if (need_wc && c == GTAMD_WILDCARD) {
+      if (pos > 0 && enc[pos - 1] == GTAMD_WILDCARD) wc_len[nwc - 1]++;
+      else { wc_start[nwc] = pos; wc_len[nwc++] = 1; }
+    }
+    if (need_sep && c == GTAMD_SEPARATOR) seppos[nsep++] = pos;
+    if (packed != NULL) {
+      /* 5 bits per symbol, most significant bit first; wildcard and separator
+         are the two codes behind the alphabet */
+      const unsigned v = c == GTAMD_WILDCARD ? numofchars
+                       : c == GTAMD_SEPARATOR ? numofchars + 1 : c;
+      const uint64_t bit = 5 * pos;
+      const unsigned shift = 16 - 5 - (unsigned) (bit % 8);
+      packed[bit / 8] |= (uint8_t) ((v << shift) >> 8);
+      if (shift < 8) packed[bit / 8 + 1] |= (uint8_t) (v << shift);
+    } else {
+      uint64_t code;
+      if (c < GTAMD_WILDCARD) code = c;
+      else if (an.sat == GTAMD_SAT_BITACCESS) code = c == GTAMD_SEPARATOR ? 1 : 0;
+      else code = least;
+      if (specialbits != NULL && c >= GTAMD_WILDCARD)
+        specialbits[pos / 64] |= (uint64_t) 1 << (63 - pos % 64);
+      twobit[pos / 32] |= code << (62 - 2 * (pos % 32));
+    }
+  }
+  sec.twobit = twobit; sec.specialbits = specialbits; sec.packed = packed;
+  sec.wc_start = wc_start; sec.wc_len = wc_len; sec.wc_runs = nwc;
+  sec.seppos = seppos;
+  rc = gtamd_write_esq_sections(indexname, paths, numfiles, protein, &an, info,
+                                write_ssp, &sec, err, errlen);
+  goto done;
+nomem:
+  snprintf(err, errlen, "out of memory while writing the encoded sequence");
+done:
+  free(twobit); free(specialbits); free(packed); free(wc_start); free(wc_len); free(seppos);
   return rc;
 }
 

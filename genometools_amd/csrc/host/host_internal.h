@@ -3,6 +3,7 @@
 #ifndef GTAMD_HOST_INTERNAL_H
 #define GTAMD_HOST_INTERNAL_H
 #include "gtamd_host.h"
+#include "gtamd_encode.h"
 
 /* GtEncseqAccessType, src/core/encseq_access_type.h:24-34 */
 enum {
@@ -24,8 +25,39 @@ typedef struct {
 void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                             gtamd_seqanalysis *an);
 
+/* the sections of INDEX.esq / INDEX.ssp behind the header, whichever the access
+   type needs (gtamd_esq_needs): packed symbols, special bits, maximal
+   wildcard runs, separator positions */
+typedef struct {
+  const uint64_t *twobit, *specialbits;
+  const uint8_t *packed;
+  const uint64_t *wc_start, *wc_len;
+  uint64_t wc_runs;
+  const uint64_t *seppos;
+} gtamd_esq_sections;
+
+void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
+                     int *specialbits, int *packed, int *wildcardruns,
+                     int *separators);
+/* code that stands in for specials in the two-bit encoding of the equal-length
+   and table access types (src/core/encseq.c:4468-4485) */
+unsigned gtamd_least_probable(const gtamd_seqanalysis *an);
+int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
+                             size_t numfiles, int protein,
+                             const gtamd_seqanalysis *an, const gtamd_encinfo *info,
+                             int write_ssp, const gtamd_esq_sections *sec,
+                             char *err, size_t errlen);
+
 /* symbol map of the DNA / protein alphabet; 253 marks undefined characters */
 void gtamd_symbolmap(uint8_t map[256], int protein);
+
+/* stored-range counts and access type from the range counts per table width;
+   needs ss.totallength/numofsequences/numofchars and equallength set */
+void gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
+                              const uint64_t wc_tab[3]);
+/* the same analysis from the device encoder's summary */
+void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofchars,
+                                 gtamd_seqanalysis *an);
 
 /* bytes of a range table of the given width (0 uchar, 1 ushort, 2 uint32),
    src/core/encseq.c:924-949 */

@@ -74,7 +74,8 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_encinfo info;
   gtamd_esa_stats es;
   gtamd_esa_ctx *ctx;
-  int rc = -1;
+  gtamd_encoder *de = NULL;
+  int rc = -1, host_encoder = 0;
 
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i];
@@ -117,6 +118,12 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     else if (!strcmp(a, "-sds")) out_sds = yesno(argc, argv, &i);
     else if (!strcmp(a, "-md5")) out_md5 = yesno(argc, argv, &i);
     else if (!strcmp(a, "-ssp")) out_ssp = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-encoder")) {
+      /* not a reference option: read FASTA on the host instead of the device */
+      if (i + 1 >= argc || (strcmp(argv[i + 1], "host") && strcmp(argv[i + 1], "device")))
+        return fail(err, errlen, "argument to option -%s must be host or device", "encoder");
+      host_encoder = !strcmp(argv[++i], "host");
+    }
     else if (!strcmp(a, "-tis") || !strcmp(a, "-showprogress")) {
       (void) yesno(argc, argv, &i);
     } else
@@ -157,6 +164,36 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return fail(err, errlen, "option -%s only can be used for DNA alphabets",
                   mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
     }
+  } else if (want != 0 && !host_encoder && !gtamd_input_is_fastq(db, numdb)) {
+    /* FASTA, tables requested: read and encode on the device; the symbols stay
+       in HBM for the engine and come to the host only where a file needs them */
+    if (gtamd_device_encode_files(db, numdb, protein, &de, &desc, &desclen, &info, err, errlen) != 0)
+      return -1;
+    n = gtamd_encoder_length(de);
+    if (gtamd_write_esq_device(indexname, db, numdb, de, protein, &info, out_ssp, &ss, err, errlen) != 0) {
+      free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
+      return -1;
+    }
+    gtamd_encinfo_free(&info);
+    if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
+      free(desc); gtamd_encoder_destroy(de);
+      return fail(err, errlen, "cannot write description files of index '%s'", indexname);
+    }
+    free(desc);
+    if (out_md5 || mirrored || readmode != 0) {
+      /* MD5 sums and the -dir / -mirrored transforms work on host symbols */
+      if ((enc = malloc(n ? n : 1)) == NULL || gtamd_encoder_copy_symbols(de, enc, 0, n) != 0) {
+        free(enc); gtamd_encoder_destroy(de);
+        return fail(err, errlen, "cannot copy the encoded sequence from the device (%s)",
+                    gtamd_esa_last_error());
+      }
+      if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
+        free(enc); gtamd_encoder_destroy(de);
+        return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
+      }
+      if (mirrored || readmode != 0) { gtamd_encoder_destroy(de); de = NULL; }
+      else { free(enc); enc = NULL; }
+    }
   } else {
     if (gtamd_encode_files_info(db, numdb, protein, &enc, &n, &desc, &desclen, &info, err, errlen) != 0)
       return -1;
@@ -188,7 +225,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     enc = m;
     n = 2 * n + 1;
   }
-  gtamd_apply_readmode(enc, n, readmode);
+  if (enc != NULL) gtamd_apply_readmode(enc, n, readmode);
   if (verbose) {
     printf("# totallength=%llu\n# specialcharacters=%llu\n# numofsequences=%llu\n",
            (unsigned long long) ss.totallength, (unsigned long long) ss.specialcharacters,
@@ -211,11 +248,12 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   ctx = gtamd_esa_create(0, n, ss.numofchars);
   if (ctx == NULL) {
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
-    free(enc);
+    free(enc); gtamd_encoder_destroy(de);
     return -1;
   }
   if (gtamd_esa_set_prefixlength(ctx, userpl) != 0 ||
-      gtamd_esa_set_sequence_bytes(ctx, enc, n, 0) != 0 ||
+      (de != NULL ? gtamd_esa_set_sequence_bytes(ctx, gtamd_encoder_device_symbols(de), n, 1)
+                  : gtamd_esa_set_sequence_bytes(ctx, enc, n, 0)) != 0 ||
       gtamd_esa_run(ctx, want) != 0 || gtamd_esa_get_stats(ctx, &es) != 0) {
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
@@ -240,6 +278,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   rc = 0;
 done:
   gtamd_esa_destroy(ctx);
+  gtamd_encoder_destroy(de);
   free(enc);
   return rc;
 }

@@ -84,6 +84,27 @@ uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *enc);
 int gtamd_encoder_get_descriptions(const gtamd_encoder *enc, uint32_t *file,
                                    uint64_t *start, uint64_t *end);
 
+/* The sections of INDEX.esq behind its header, built from the symbols in HBM
+   and delivered to host memory (layouts: src/core/encseq.c:85-99, 2594-2607,
+   2771-2835 two-bit encoding and special bits; :2324-2447 bit packing):
+     pack_twobit        2 + (n-1)/32 words (2 if n < 32), 32 symbols per word,
+                        first symbol in the top bits; specials are stored as
+                        wildcard 0 / separator 1 (bitaccess != 0) or as
+                        fillcode (the least frequent letter)
+     pack_specialbits   1 + (n+63)/64 words, one bit per position, first in the
+                        top bit; the 64 positions behind the sequence are set
+     pack_bytecompress  (bits*n+7)/8 bytes, bits = 5 (protein) or 3 (DNA) per
+                        symbol, wildcard = sigma, separator = sigma + 1
+     wildcard_runs      the realwildcardranges maximal runs (start, length)
+     separators         the numofsequences - 1 separator positions */
+int gtamd_encoder_pack_twobit(const gtamd_encoder *enc, int bitaccess,
+                              unsigned fillcode, uint64_t *words);
+int gtamd_encoder_pack_specialbits(const gtamd_encoder *enc, uint64_t *words);
+int gtamd_encoder_pack_bytecompress(const gtamd_encoder *enc, uint8_t *bytes);
+int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *enc, uint64_t *start,
+                                    uint64_t *length);
+int gtamd_encoder_get_separators(const gtamd_encoder *enc, uint64_t *pos);
+
 /* device time of the last finish (ms, HIP events) and the bytes it read */
 int gtamd_encoder_get_timing(const gtamd_encoder *enc, float *total_ms,
                              float *parse_ms, float *stats_ms,

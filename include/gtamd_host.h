@@ -20,6 +20,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include "gtamd_esa.h"
+#include "gtamd_encode.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -79,6 +80,25 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
                     size_t numfiles, const uint8_t *enc, uint64_t n,
                     int protein, const gtamd_encinfo *info, int write_ssp,
                     char *err, size_t errlen);
+
+/* The same two steps with the device encoder (include/gtamd_encode.h) for
+   FASTA input: the files are read whole and encoded on the GPU; *enc (destroy
+   with gtamd_encoder_destroy) holds the symbols in HBM, ready for
+   gtamd_esa_set_sequence_bytes(ctx, gtamd_encoder_device_symbols(*enc), n, 1);
+   descriptions and file information come back as from gtamd_encode_files_info.
+   gtamd_write_esq_device writes INDEX.esq/.ssp from sections packed on the
+   device, byte-identical to gtamd_write_esq; *ss (may be NULL) receives the
+   sequence statistics.  gtamd_input_is_fastq: 1 if a file starts with '@'
+   (FASTQ stays with the host reader). */
+int gtamd_input_is_fastq(const char *const *paths, size_t numfiles);
+int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
+                              int protein, gtamd_encoder **enc,
+                              char **desc, uint64_t *desclen,
+                              gtamd_encinfo *info, char *err, size_t errlen);
+int gtamd_write_esq_device(const char *indexname, const char *const *paths,
+                           size_t numfiles, const gtamd_encoder *enc,
+                           int protein, const gtamd_encinfo *info, int write_ssp,
+                           gtamd_seqstats *ss, char *err, size_t errlen);
 
 /* The way back (option -ii, src/match/sfx-run.c:454-493 /
    gt_encseq_loader_load): the symbols of an existing INDEX.esq, written by

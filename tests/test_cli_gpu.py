@@ -128,3 +128,47 @@ def test_cli_readmodes_and_mirror(cli, key, tmp_path):
             assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
     with open(idx + ".prj") as f:
         assert f.read() == e["prj"]
+
+
+MULTI = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_multi.json")))
+
+
+@pytest.mark.parametrize("key", sorted(MULTI))
+@pytest.mark.parametrize("encoder", ["device", "host"])
+def test_cli_several_input_files(cli, key, encoder, tmp_path):
+    """-db with several files, read on the device (FASTA) or on the host
+    (FASTQ always): every file the reference writes, byte for byte"""
+    e = MULTI[key]
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-encoder", encoder, "-indexname", idx,
+                    "-db"] + e["files"], check=True, cwd=os.path.join(ou.GOLDEN_DIR, "multi"))
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    with open(idx + ".prj") as f:
+        assert f.read() == e["prj"]
+    for ext in ("des", "sds", "md5", "esq", "ssp"):
+        assert os.path.exists(idx + "." + ext) == (ext in e["seqfiles"]), ext
+        if ext in e["seqfiles"]:
+            with open(idx + "." + ext, "rb") as f:
+                assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
+
+
+@pytest.mark.parametrize("name", sorted(n for n in GOLDEN if not n.endswith(".fastq")))
+def test_cli_device_and_host_reader_write_the_same_index(cli, name, tmp_path):
+    """every FASTA fixture through both readers; the device path (default) is
+    the one compared with the reference's sequence-side files"""
+    e = GOLDEN[name]
+    src = ou.fixture_path(name)
+    out = {}
+    for encoder in ("device", "host"):
+        idx = str(tmp_path / encoder)
+        subprocess.run([cli, "-" + e["alphabet"], "-suf", "-encoder", encoder, "-indexname", idx,
+                        "-db", os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+        out[encoder] = {ext: hashlib.md5(open(idx + "." + ext, "rb").read()).hexdigest()
+                        for ext in ("suf", "prj", "des", "sds", "md5", "esq", "ssp")
+                        if os.path.exists(idx + "." + ext)}
+    assert out["device"] == out["host"]
+    for ext, v in e["seqfiles"].items():
+        assert out["device"][ext] == v["md5"], ext
+    assert out["device"]["suf"] == e["tables"]["suf"]["md5"]

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define MAXDB 1024
 
@@ -14,6 +15,13 @@ static int fail(char *err, size_t errlen, const char *msg, const char *arg)
 {
   snprintf(err, errlen, msg, arg);
   return -1;
+}
+
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
 }
 
 static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
@@ -76,6 +84,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_esa_ctx *ctx;
   gtamd_encoder *de = NULL;
   int rc = -1, host_encoder = 0;
+  double t0 = now_s(), t_seq, t_build, t_create;
 
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i];
@@ -226,6 +235,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     n = 2 * n + 1;
   }
   if (enc != NULL) gtamd_apply_readmode(enc, n, readmode);
+  t_seq = now_s() - t0;
   if (verbose) {
     printf("# totallength=%llu\n# specialcharacters=%llu\n# numofsequences=%llu\n",
            (unsigned long long) ss.totallength, (unsigned long long) ss.specialcharacters,
@@ -245,7 +255,9 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return fail(err, errlen, "cannot open file '%s' for writing", path);
     return 0;
   }
+  t_create = now_s();
   ctx = gtamd_esa_create(0, n, ss.numofchars);
+  t_create = now_s() - t_create;
   if (ctx == NULL) {
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     free(enc); gtamd_encoder_destroy(de);
@@ -258,6 +270,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
   }
+  t_build = now_s() - t0 - t_seq;
   if (verbose)
     printf("# prefixlength=%u\n# tied suffixes after the first sort=%llu, refinement rounds=%u\n",
            es.prefixlength, (unsigned long long) es.tied_suffixes, es.refine_rounds);
@@ -274,6 +287,22 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       fail(err, errlen, "cannot open file '%s' for writing", path);
       goto done;
     }
+  }
+  if (verbose && de != NULL) {
+    float total_ms = 0, parse_ms = 0, stats_ms = 0;
+    uint64_t bytes = 0;
+    (void) gtamd_encoder_get_timing(de, &total_ms, &parse_ms, &stats_ms, &bytes);
+    printf("# device encoder: %llu input bytes in %.2f ms (upload and parsing %.2f, "
+           "statistics %.2f)\n", (unsigned long long) bytes, total_ms, parse_ms, stats_ms);
+  }
+  if (verbose) {
+    gtamd_esa_timing tm;
+    memset(&tm, 0, sizeof tm);
+    (void) gtamd_esa_get_timing(ctx, &tm);
+    printf("# seconds: input, encoding and sequence files (%s reader) %.3f; tables on the "
+           "device %.3f (workspace %.3f, kernels %.3f); tables to files %.3f\n",
+           de != NULL ? "device" : "host", t_seq, t_build, t_create, tm.total_ms / 1e3,
+           now_s() - t0 - t_seq - t_build);
   }
   rc = 0;
 done:

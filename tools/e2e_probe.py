@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""End-to-end timing of gt-suffixerator-amd on a synthetic FASTA file (GPU box):
+FASTA on disk -> all index files, with the device reader and with the host
+reader; checks that both write the same files.
+
+  python tools/e2e_probe.py --symbols 1000000000 [--dir /dev/shm/e2e]
+"""
+import argparse
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from genometools_amd import _lib, synth  # noqa: E402
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--symbols", type=int, default=256_000_000)
+    ap.add_argument("--dir", default="/dev/shm/gtamd_e2e")
+    ap.add_argument("--encoders", default="device,host")
+    ap.add_argument("--tables", default="-suf -lcp -bwt")
+    a = ap.parse_args()
+    lib = _lib.load()
+    os.makedirs(a.dir, exist_ok=True)
+    try:
+        n = a.symbols
+        buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        _lib.check(lib.gtamd_synth_bytes(0, synth.MODEL_HUMANLIKE_DNA, 43, n, buf.data_ptr()))
+        enc = buf.cpu().numpy()
+        del buf
+        torch.cuda.empty_cache()
+        fa = os.path.join(a.dir, "genome.fna")
+        t = time.time()
+        synth.write_fasta(fa, enc)
+        del enc
+        print("FASTA: %d symbols, %.1f MB, written in %.1f s" % (n, os.path.getsize(fa) / 1e6,
+                                                                time.time() - t), flush=True)
+        cli = os.path.join(_lib.HERE, "gt-suffixerator-amd")
+        sums = {}
+        for encoder in a.encoders.split(","):
+            idx = os.path.join(a.dir, "idx_" + encoder)
+            t = time.time()
+            r = subprocess.run([cli, "-dna", *a.tables.split(), "-v", "-encoder", encoder,
+                                "-indexname", idx, "-db", "genome.fna"], cwd=a.dir,
+                               capture_output=True, text=True)
+            wall = time.time() - t
+            if r.returncode != 0:
+                print(encoder, "FAILED", r.stderr)
+                return 1
+            line = [l for l in r.stdout.splitlines()
+                    if l.startswith(("# seconds", "# device encoder"))]
+            print("%s reader: wall %.2f s\n  %s" % (encoder, wall, "\n  ".join(line)),
+                  flush=True)
+            sums[encoder] = {ext: md5(idx + "." + ext) for ext in
+                             ("esq", "ssp", "des", "sds", "md5", "prj", "suf", "lcp", "bwt")
+                             if os.path.exists(idx + "." + ext)}
+            for ext in ("suf", "lcp", "llv", "bwt", "esq"):
+                if os.path.exists(idx + "." + ext):
+                    os.unlink(idx + "." + ext)
+        if len(sums) == 2:
+            same = sums["device"] == sums["host"]
+            print("device and host reader wrote identical files:", same)
+            if not same:
+                return 1
+    finally:
+        shutil.rmtree(a.dir, ignore_errors=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

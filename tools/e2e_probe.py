@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/gtamd_e2e")
     ap.add_argument("--encoders", default="device,host")
     ap.add_argument("--tables", default="-suf -lcp -bwt")
+    ap.add_argument("--generate-only", action="store_true",
+                    help="write DIR/genome.fna and stop (input for a profiler run)")
     a = ap.parse_args()
     lib = _lib.load()
     os.makedirs(a.dir, exist_ok=True)
@@ -50,6 +52,9 @@ def main():
         del enc
         print("FASTA: %d symbols, %.1f MB, written in %.1f s" % (n, os.path.getsize(fa) / 1e6,
                                                                 time.time() - t), flush=True)
+        if a.generate_only:
+            a.dir = None
+            return 0
         cli = os.path.join(_lib.HERE, "gt-suffixerator-amd")
         sums = {}
         for encoder in a.encoders.split(","):
@@ -78,7 +83,8 @@ def main():
             if not same:
                 return 1
     finally:
-        shutil.rmtree(a.dir, ignore_errors=True)
+        if a.dir is not None:
+            shutil.rmtree(a.dir, ignore_errors=True)
     return 0
 
 

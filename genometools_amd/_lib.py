@@ -98,6 +98,8 @@ ABI = {
     "gtamd_esa_run": (_INT, [_P, _U32]),
     "gtamd_esa_table_entries": (_U64, [_P, _INT]),
     "gtamd_esa_table_offset": (_U64, [_P]),
+    "gtamd_esa_bck_layout": (_INT, [_P, ctypes.POINTER(_U64), ctypes.POINTER(_U64),
+                                    ctypes.POINTER(_U64)]),
     "gtamd_esa_table_device": (_P, [_P, _INT]),
     "gtamd_esa_table_copy": (_INT, [_P, _INT, _P, _U64, _U64]),
     "gtamd_esa_get_stats": (_INT, [_P, ctypes.POINTER(EsaStats)]),

@@ -412,6 +412,64 @@ __global__ __launch_bounds__(256) void k_k2_scatter(
 }
 
 // ---------------------------------------------------------------------------
+// bucket table (.bck): bcktab.c:55-81,519-577, sfx-suffixer.c:379-383,476-516
+// ---------------------------------------------------------------------------
+// code of the first k symbols in base sigma; a prefix shorter than k letters is
+// padded with the largest letter (the key pads with 1-bits)
+template <int BITS>
+__device__ __forceinline__ u64 bck_code(u64 key, u32 k, u32 sigma) {
+  if (BITS == 2) return k == 0 ? 0 : key >> (64 - 2 * k);
+  u64 code = 0;
+  for (u32 j = 0; j < k; j++) {
+    u32 d = (u32) (key >> (64 - BITS * (j + 1))) & ((1u << BITS) - 1u);
+    if (d >= sigma) d = sigma - 1;
+    code = code * sigma + d;
+  }
+  return code;
+}
+
+// hist[c] = entries whose padded k-code is c (suffixes that start with a
+// special are not in any bucket); the keys are sorted, so a wave adds one count
+// per run of equal codes.  Suffixes with fewer than k letters in front of a
+// special are counted per padded (k-1)-prefix and, for 1..k-2 letters, per
+// prefix of exactly that length.
+template <int BITS>
+__global__ __launch_bounds__(256) void k_bck_count(
+    const u64 *__restrict__ keys, u64 N, u32 k, u32 sigma, u32 *__restrict__ hist,
+    u32 *__restrict__ countspecial, u32 *__restrict__ distpfx) {
+  using K = Key<BITS>;
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool valid = i < N;
+  const u64 key = valid ? keys[i] : ~0ull;
+  const u32 dc = K::dcode(key);
+  const bool inbucket = valid && dc != K::DMAX;
+  const u64 code = inbucket ? bck_code<BITS>(key, k, sigma) : ~0ull;
+  const u64 prev = __shfl_up(code, 1, 64);
+  const bool head = inbucket && (lane == 0 || prev != code);
+  const u64 heads = __ballot(head), live = __ballot(inbucket);
+  if (head) {
+    // entries of this run inside the wave: up to the next head
+    const u64 above = lane == 63 ? 0 : (heads >> (lane + 1)) << (lane + 1);
+    const int end = above ? __ffsll((unsigned long long) above) - 1 : 64;
+    u64 mask = end == 64 ? ~0ull : ((1ull << end) - 1ull);
+    mask &= ~((1ull << lane) - 1ull);
+    atomicAdd(&hist[code], (u32) __popcll(live & mask));
+  }
+  if (inbucket && dc != 0) {
+    const u32 letters = K::letters(key);
+    if (letters < k) {
+      atomicAdd(&countspecial[bck_code<BITS>(key, k - 1, sigma)], 1u);
+      if (letters >= 1 && letters + 2 <= k) {
+        u64 off = 0, pw = sigma;
+        for (u32 l = 1; l < letters; l++) { off += pw; pw *= sigma; }
+        atomicAdd(&distpfx[off + bck_code<BITS>(key, letters, sigma)], 1u);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // finalize
 // ---------------------------------------------------------------------------
 struct Stats {          // device-side accumulators
@@ -1152,6 +1210,8 @@ struct gtamd_esa_ctx {
   u8 *lcp, *bwt;
   u64 *llv;
   u64 llv_pairs, llv_cap;
+  u32 *bck;                      // .bck sections, back to back
+  u64 bck_codes, bck_special, bck_dist;
   u64 *tiebits;
   Stats *d_stats, *h_stats;   // h_stats: pinned host mirror
   // refinement arena (grow-only)
@@ -1189,7 +1249,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
   free_dev(c->isa_tmp);
   free_dev(c->rws); free_dev(c->dig0); free_dev(c->dig1); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
-  free_dev(c->llv); free_dev(c->tiebits); free_dev(c->d_stats);
+  free_dev(c->llv); free_dev(c->bck); free_dev(c->tiebits); free_dev(c->d_stats);
   free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
   free_dev(c->xbuf);
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
@@ -1486,6 +1546,47 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   return 0;
 }
 
+// the three sections of the bucket table from the sorted keys
+template <int BITS>
+static int build_bcktab(gtamd_esa_ctx *c, const u64 *skey, u64 NL, u32 k,
+                        hipStream_t st) {
+  u64 codes = 1, special = 1, dist = 0, pw = 1;
+  for (u32 j = 0; j < k; j++) {
+    if (codes > (1ull << 31) / c->sigma) {
+      gtamd_set_error("bucket table for prefixlength %u over %u letters is too "
+                      "large", k, c->sigma);
+      return -1;
+    }
+    codes *= c->sigma;
+  }
+  for (u32 j = 0; j + 1 < k; j++) special *= c->sigma;
+  for (u32 j = 1; j + 1 < k; j++) { pw *= c->sigma; dist += pw; }
+  const u64 total = codes + 1 + special + dist;
+  free_dev(c->bck);
+  c->bck = nullptr;
+  HIP_TRY(hipMalloc(&c->bck, total * 4));
+  HIP_TRY(hipMemsetAsync(c->bck, 0, total * 4, st));
+  if (NL > 0) {
+    k_bck_count<BITS><<<(u32) div_up(NL, 256), 256, 0, st>>>(
+        skey, NL, k, c->sigma, c->bck, c->bck + codes + 1,
+        c->bck + codes + 1 + special);
+    HIP_TRY(hipGetLastError());
+  }
+  // left borders: exclusive prefix sums; the last entry becomes the number of
+  // suffixes that are in a bucket
+  u32 *ws = c->rws;
+  u32 *own = nullptr;
+  if (scan_workspace_words(codes + 1) > c->rws_words) {
+    HIP_TRY(hipMalloc(&own, scan_workspace_words(codes + 1) * 4));
+    ws = own;
+  }
+  const int rc = scan_u32(SCAN_SUM, c->bck, c->bck, codes + 1, false, ws, st);
+  if (own != nullptr) { (void) hipStreamSynchronize(st); free_dev(own); }
+  TRY(rc);
+  c->bck_codes = codes; c->bck_special = special; c->bck_dist = dist;
+  return 0;
+}
+
 template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   using K = Key<BITS>;
   const u64 N = c->N, n = c->n;
@@ -1500,6 +1601,12 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   if (prefixlength > (u32) K::SYMS) {
     gtamd_set_error("prefixlength %u exceeds the key width %d", prefixlength,
                     K::SYMS);
+    return -1;
+  }
+  if (parts && (want & GTAMD_WANT_BCK)) {
+    // as the reference: no bucket table from a run in parts
+    // (gt_Sfxiterator_bcktab2file, src/match/sfx-suffixer.c:2206-2217)
+    gtamd_set_error("the bucket table is not available from a part build");
     return -1;
   }
   if (parts && (c->comm_allgather == nullptr || c->comm_alltoallv == nullptr)) {
@@ -1599,6 +1706,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   u64 *fkey = (np & 1) ? c->k0 : c->k1;   // free key-sized buffer
   u32 *rank = (np & 1) ? c->v0 : c->v1;   // free value-sized buffer
   HIP_TRY(hipEventRecord(c->ev[2], st));
+
+  if (want & GTAMD_WANT_BCK) TRY(build_bcktab<BITS>(c, skey, NL, prefixlength, st));
 
   // ---- finalize; a part needs the last key of the preceding range
   u64 prev_key = 0;
@@ -1945,7 +2054,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
 extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   if (!c->have_text) { gtamd_set_error("no sequence set"); return -1; }
-  if ((want & 7u) == 0) { gtamd_set_error("nothing requested"); return -1; }
+  if ((want & 15u) == 0) { gtamd_set_error("nothing requested"); return -1; }
   HIP_TRY(hipSetDevice(c->device));
   return c->bits == 2 ? run_impl<2>(c, want) : run_impl<5>(c, want);
 }
@@ -1956,7 +2065,21 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
 extern "C" uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *c,
                                             gtamd_table which) {
   if (c == nullptr || !c->ran) return 0;
+  if (which == GTAMD_TAB_BCK)
+    return (c->want & GTAMD_WANT_BCK) ? c->bck_codes + 1 + c->bck_special + c->bck_dist : 0;
   return which == GTAMD_TAB_LLV ? c->llv_pairs : c->NL;
+}
+extern "C" int gtamd_esa_bck_layout(const gtamd_esa_ctx *c, uint64_t *numofallcodes,
+                                    uint64_t *numofspecialcodes,
+                                    uint64_t *numofdistpfxidxcounters) {
+  if (c == nullptr || !c->ran || !(c->want & GTAMD_WANT_BCK)) {
+    gtamd_set_error("no bucket table was requested");
+    return -1;
+  }
+  *numofallcodes = c->bck_codes;
+  *numofspecialcodes = c->bck_special;
+  *numofdistpfxidxcounters = c->bck_dist;
+  return 0;
 }
 extern "C" uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *c) {
   return (c == nullptr || !c->ran) ? 0 : c->index_offset;
@@ -1969,6 +2092,7 @@ extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
     case GTAMD_TAB_LCP: return (c->want & GTAMD_WANT_LCP) ? c->lcp : nullptr;
     case GTAMD_TAB_BWT: return (c->want & GTAMD_WANT_BWT) ? c->bwt : nullptr;
     case GTAMD_TAB_LLV: return (c->want & GTAMD_WANT_LCP) ? c->llv : nullptr;
+    case GTAMD_TAB_BCK: return (c->want & GTAMD_WANT_BCK) ? c->bck : nullptr;
   }
   return nullptr;
 }
@@ -1984,7 +2108,8 @@ extern "C" int gtamd_esa_table_copy(gtamd_esa_ctx *c, gtamd_table which,
                     (unsigned long long) count, (unsigned long long) entries);
     return -1;
   }
-  const u64 esz = which == GTAMD_TAB_SUF ? 8 : (which == GTAMD_TAB_LLV ? 16 : 1);
+  const u64 esz = which == GTAMD_TAB_SUF ? 8 : which == GTAMD_TAB_LLV ? 16
+                : which == GTAMD_TAB_BCK ? 4 : 1;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpy(dst, (const u8 *) src + first * esz, count * esz,
                     hipMemcpyDeviceToHost));

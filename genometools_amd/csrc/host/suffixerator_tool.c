@@ -24,13 +24,47 @@ static double now_s(void)
   return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
 }
 
+/* INDEX.bck: the three uint32 sections, each padded to 8 bytes
+   (src/match/bcktab.c:519-565, src/core/mapspec.c:350-457) */
+static int write_bcktab(gtamd_esa_ctx *ctx, const char *index, char *err, size_t errlen)
+{
+  static const uint8_t zero[8] = {0};
+  char path[4096];
+  uint64_t sec[3], first = 0;
+  FILE *fp;
+  if (gtamd_esa_bck_layout(ctx, &sec[0], &sec[1], &sec[2]) != 0) {
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+    return -1;
+  }
+  sec[0] += 1;
+  snprintf(path, sizeof path, "%s.bck", index);
+  if ((fp = fopen(path, "wb")) == NULL)
+    return fail(err, errlen, "cannot open file '%s' for writing", path);
+  for (int k = 0; k < 3; k++) {
+    uint32_t *buf;
+    if (sec[k] == 0) continue;
+    if ((buf = malloc(4 * sec[k])) == NULL ||
+        gtamd_esa_table_copy(ctx, GTAMD_TAB_BCK, buf, first, sec[k]) != 0 ||
+        fwrite(buf, 4, sec[k], fp) != sec[k] ||
+        ((4 * sec[k]) % 8 != 0 && fwrite(zero, 1, 4, fp) != 4)) {
+      free(buf); fclose(fp);
+      return fail(err, errlen, "cannot write file '%s'", path);
+    }
+    free(buf);
+    first += sec[k];
+  }
+  return fclose(fp) == 0 ? 0 : fail(err, errlen, "cannot close file '%s'", path);
+}
+
+/* entrysize 4 for the suffix table: -suftabuint, 32-bit entries */
 static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
                        const char *suffix, size_t entrysize, char *err, size_t errlen)
 {
+  const int narrow = which == GTAMD_TAB_SUF && entrysize == 4;
   char path[4096];
   const uint64_t entries = gtamd_esa_table_entries(ctx, which);
-  const uint64_t chunk = (64u << 20) / entrysize;   /* 64 MiB staging buffer */
-  void *buf = malloc(chunk * entrysize);
+  const uint64_t chunk = (64u << 20) / (narrow ? 8 : entrysize);   /* 64 MiB staging buffer */
+  void *buf = malloc(chunk * (narrow ? 8 : entrysize));
   FILE *fp;
   snprintf(path, sizeof path, "%s%s", index, suffix);
   fp = fopen(path, "wb");
@@ -45,6 +79,11 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
       snprintf(err, errlen, "%s", gtamd_esa_last_error());
       free(buf); fclose(fp);
       return -1;
+    }
+    if (narrow) {
+      const uint64_t *wide = buf;
+      uint32_t *out = buf;                  /* in place, front to back */
+      for (uint64_t k = 0; k < cnt; k++) out[k] = (uint32_t) wide[k];
     }
     if (fwrite(buf, entrysize, cnt, fp) != cnt) {
       snprintf(err, errlen, "cannot write to file '%s'", path);
@@ -83,7 +122,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_esa_stats es;
   gtamd_esa_ctx *ctx;
   gtamd_encoder *de = NULL;
-  int rc = -1, host_encoder = 0;
+  int rc = -1, host_encoder = 0, suftabuint = 0;
   double t0 = now_s(), t_seq, t_build, t_create;
 
   for (int i = 1; i < argc; i++) {
@@ -105,6 +144,8 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     else if (!strcmp(a, "-suf")) want |= GTAMD_WANT_SUF;
     else if (!strcmp(a, "-lcp")) want |= GTAMD_WANT_LCP;
     else if (!strcmp(a, "-bwt")) want |= GTAMD_WANT_BWT;
+    else if (!strcmp(a, "-bck")) want |= GTAMD_WANT_BCK;
+    else if (!strcmp(a, "-suftabuint")) suftabuint = 1;
     else if (!strcmp(a, "-v")) verbose = 1;
     else if (!strcmp(a, "-pl")) {
       if (i + 1 < argc && argv[i + 1][0] != '-') userpl = (uint32_t) strtoul(argv[++i], NULL, 10);
@@ -274,7 +315,9 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   if (verbose)
     printf("# prefixlength=%u\n# tied suffixes after the first sort=%llu, refinement rounds=%u\n",
            es.prefixlength, (unsigned long long) es.tied_suffixes, es.refine_rounds);
-  if ((want & GTAMD_WANT_SUF) && write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", 8, err, errlen) != 0) goto done;
+  if ((want & GTAMD_WANT_SUF) &&
+      write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", suftabuint ? 4 : 8, err, errlen) != 0) goto done;
+  if ((want & GTAMD_WANT_BCK) && write_bcktab(ctx, indexname, err, errlen) != 0) goto done;
   if (want & GTAMD_WANT_LCP) {
     if (write_table(ctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0) goto done;
     if (write_table(ctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0) goto done;

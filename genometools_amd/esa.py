@@ -17,11 +17,11 @@ import numpy as np
 from . import _lib
 from ._lib import EsaError, EsaStats, EsaTiming, check  # noqa: F401
 
-WANT_SUF, WANT_LCP, WANT_BWT = 1, 2, 4
-TAB_SUF, TAB_LCP, TAB_BWT, TAB_LLV = 0, 1, 2, 3
+WANT_SUF, WANT_LCP, WANT_BWT, WANT_BCK = 1, 2, 4, 8
+TAB_SUF, TAB_LCP, TAB_BWT, TAB_LLV, TAB_BCK = 0, 1, 2, 3, 4
 
 _TAB_DTYPE = {TAB_SUF: np.uint64, TAB_LCP: np.uint8, TAB_BWT: np.uint8,
-              TAB_LLV: np.uint64}
+              TAB_LLV: np.uint64, TAB_BCK: np.uint32}
 
 
 @dataclass
@@ -126,6 +126,20 @@ class EsaEngine:
                 self._ctx, which, out.ctypes.data_as(ctypes.c_void_p), first,
                 count))
         return out.reshape(-1, 2) if which == TAB_LLV else out
+
+    def set_prefixlength(self, k):
+        """prefix length of .prj and of the bucket table; 0: the recommended one"""
+        check(self._lib.gtamd_esa_set_prefixlength(self._ctx, k))
+
+    def bcktab(self):
+        """the sections of INDEX.bck (run with WANT_BCK): leftborder,
+        countspecialcodes, distpfxidx counters (src/match/bcktab.c:519-558)"""
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(self._lib.gtamd_esa_bck_layout(self._ctx, ctypes.byref(a), ctypes.byref(b),
+                                             ctypes.byref(c)))
+        raw = self.table(TAB_BCK)
+        na, nb = a.value + 1, b.value
+        return raw[:na], raw[na:na + nb], raw[na + nb:na + nb + c.value]
 
     def stats(self):
         s = EsaStats()

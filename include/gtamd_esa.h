@@ -45,13 +45,16 @@ extern "C" {
 #define GTAMD_WANT_SUF 1u
 #define GTAMD_WANT_LCP 2u
 #define GTAMD_WANT_BWT 4u
+#define GTAMD_WANT_BCK 8u  /* -bck, src/match/index_options.c */
 
 /* table selectors for gtamd_esa_table_* */
 typedef enum {
   GTAMD_TAB_SUF = 0,  /* (n+1) x uint64, native endian  (.suf) */
   GTAMD_TAB_LCP = 1,  /* (n+1) x uint8                  (.lcp) */
   GTAMD_TAB_BWT = 2,  /* (n+1) x uint8                  (.bwt) */
-  GTAMD_TAB_LLV = 3   /* numlargelcp x (uint64 index, uint64 value) (.llv) */
+  GTAMD_TAB_LLV = 3,  /* numlargelcp x (uint64 index, uint64 value) (.llv) */
+  GTAMD_TAB_BCK = 4   /* uint32: the sections of .bck back to back, see
+                         gtamd_esa_bck_layout */
 } gtamd_table;
 
 /* numbers the reference prints into .prj (src/match/sfx-outprj.c:38-83) that
@@ -166,6 +169,23 @@ int gtamd_esa_run(gtamd_esa_ctx *ctx, uint32_t want);
    the whole table */
 uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *ctx, gtamd_table which);
 uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *ctx);
+/* The bucket table of the run's prefixlength k (GTAMD_WANT_BCK; GtBcktab,
+   src/match/bcktab.c:55-81, file layout :519-558): GTAMD_TAB_BCK holds, as
+   uint32 and back to back,
+     leftborder[numofallcodes + 1]   first index of every bucket of k-mer codes
+                                     (base sigma, first symbol most significant);
+                                     suffixes with fewer than k letters before a
+                                     special sit at the end of the bucket of
+                                     their prefix padded with the largest letter;
+                                     the last entry is the number of suffixes
+                                     that do not start with a special
+     countspecialcodes[sigma^(k-1)]  such short suffixes per padded (k-1)-prefix
+     distpfxidx[sigma + ... + sigma^(k-2)]  suffixes with exactly l = 1..k-2
+                                     letters before a special, per l-letter code
+   (n + 1 <= UINT32_MAX here, so the reference writes uint32 too). */
+int gtamd_esa_bck_layout(const gtamd_esa_ctx *ctx, uint64_t *numofallcodes,
+                         uint64_t *numofspecialcodes,
+                         uint64_t *numofdistpfxidxcounters);
 /* device pointer of a table (valid until the next run / destroy) */
 const void *gtamd_esa_table_device(const gtamd_esa_ctx *ctx, gtamd_table which);
 /* copy entries [first, first+count) of a table to host memory */

@@ -142,7 +142,8 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
                     int mirrored);
 
 /* `gt suffixerator` for the option subset of this path:
-     -db FILE...  -indexname NAME  -dna | -protein  -suf -lcp -bwt
+     -db FILE... | -ii INDEX  -indexname NAME  -dna | -protein
+     -suf -lcp -bwt -bck  -suftabuint
      -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored   and, accepted without
      effect on the tables,
      -parts N  -memlimit X  -dc V  -tis [yes|no]

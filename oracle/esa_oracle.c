@@ -504,3 +504,48 @@ int ora_write_prj(const char *path, const ora_seqstats *ss,
   fclose(fp);
   return 0;
 }
+
+/* The three sections of the bucket table for prefix length k, restated from
+   what the reference's counting and insertion passes leave in GtBcktab
+   (src/match/bcktab.c:55-81,1274-1304; special suffixes
+   src/match/sfx-suffixer.c:476-516, sfx-enumcodes.c:100-222): every suffix that
+   does not start with a special belongs to the bucket of its first k symbols,
+   a suffix with fewer letters before a special to the bucket of its letters
+   padded with the largest letter. */
+void ora_bcktab(const uint8_t *enc, uint64_t n, uint32_t sigma, uint32_t k,
+                uint32_t *leftborder, uint32_t *countspecialcodes,
+                uint32_t *distpfxidx)
+{
+  uint64_t codes = 1, special = 1, dist = 0, pw = 1, sum = 0;
+  for (uint32_t j = 0; j < k; j++) codes *= sigma;
+  for (uint32_t j = 0; j + 1 < k; j++) special *= sigma;
+  for (uint32_t j = 1; j + 1 < k; j++) { pw *= sigma; dist += pw; }
+  memset(leftborder, 0, 4 * (codes + 1));
+  memset(countspecialcodes, 0, 4 * special);
+  if (dist > 0) memset(distpfxidx, 0, 4 * dist);
+  for (uint64_t p = 0; p < n; p++) {
+    uint64_t code = 0, prefix = 0;
+    uint32_t letters = 0;
+    while (letters < k && p + letters < n && enc[p + letters] < ORA_WILDCARD) {
+      code = code * sigma + enc[p + letters];
+      letters++;
+    }
+    if (letters == 0) continue;                  /* starts with a special */
+    prefix = code;
+    for (uint32_t j = letters; j < k; j++) code = code * sigma + (sigma - 1);
+    leftborder[code]++;
+    if (letters < k) {
+      countspecialcodes[code / sigma]++;
+      if (letters + 2 <= k) {
+        uint64_t off = 0, q = sigma;
+        for (uint32_t l = 1; l < letters; l++) { off += q; q *= sigma; }
+        distpfxidx[off + prefix]++;
+      }
+    }
+  }
+  for (uint64_t c = 0; c <= codes; c++) {        /* counts -> left borders */
+    const uint32_t cnt = leftborder[c];
+    leftborder[c] = (uint32_t) sum;
+    sum += cnt;
+  }
+}

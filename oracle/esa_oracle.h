@@ -97,6 +97,13 @@ void ora_esastats_compute(const uint8_t *enc, uint64_t n, const uint64_t *sa,
 int ora_check_suffix_array(const uint8_t *enc, uint64_t n, const uint64_t *sa,
                            uint64_t *where);
 
+/* sections of INDEX.bck (uint32 variant) for prefix length k: leftborder has
+   sigma^k + 1 entries, countspecialcodes sigma^(k-1), distpfxidx
+   sigma + ... + sigma^(k-2) (src/match/bcktab.c:519-558) */
+void ora_bcktab(const uint8_t *enc, uint64_t n, uint32_t sigma, uint32_t k,
+                uint32_t *leftborder, uint32_t *countspecialcodes,
+                uint32_t *distpfxidx);
+
 /* write NAME.prj exactly as sfx-outprj.c:38-83 does */
 int ora_write_prj(const char *path, const ora_seqstats *ss,
                   const ora_esastats *es, int with_lcp, int readmode,

@@ -19,7 +19,7 @@
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
   usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
-                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE]
+                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint]
                     -db FASTA... -indexname IDX [-time]
 */
 #include <stdio.h>
@@ -68,7 +68,8 @@ int main(int argc, char **argv)
   const char *db[64], *indexname = NULL, *sat = NULL;
   int numdb = 0;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
-       showtime = false, haserr = false, mirrored = false;
+       showtime = false, haserr = false, mirrored = false, want_bck = false,
+       suftabuint = false;
   GtReadmode readmode = GT_READMODE_FORWARD;
   unsigned int userpl = 0, dc = 0, prefixlength, numofchars;
   int i;
@@ -80,7 +81,7 @@ int main(int argc, char **argv)
   GtOutlcpinfo *outlcpinfo = NULL;
   Sfxstrategy strategy;
   Sfxiterator *sfi;
-  FILE *fpsuf = NULL, *fpbwt = NULL;
+  FILE *fpsuf = NULL, *fpbwt = NULL, *fpbck = NULL;
   GtUword numberofallsortedsuffixes = 0, totallength;
   Definedunsignedlong longest;
   double t0, t_encode, t_esa;
@@ -92,6 +93,8 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-lcp")) want_lcp = true;
     else if (!strcmp(argv[i], "-bwt")) want_bwt = true;
     else if (!strcmp(argv[i], "-time")) showtime = true;
+    else if (!strcmp(argv[i], "-bck")) want_bck = true;
+    else if (!strcmp(argv[i], "-suftabuint")) suftabuint = true;
     else if (!strcmp(argv[i], "-mirrored")) mirrored = true;
     else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
       const char *d = argv[++i];
@@ -170,6 +173,7 @@ int main(int argc, char **argv)
   defaultsfxstrategy(&strategy,
                      gt_encseq_bitwise_cmp_ok(encseq) ? false : true);
   strategy.differencecover = dc;
+  strategy.suftabuint = suftabuint;     /* -suftabuint, src/match/index_options.c:475 */
 
   t0 = now_s();
   if (want_lcp) {
@@ -179,12 +183,17 @@ int main(int argc, char **argv)
   }
   if (want_suf) fpsuf = open_tab(indexname, GT_SUFTABSUFFIX);
   if (want_bwt) fpbwt = open_tab(indexname, GT_BWTTABSUFFIX);
+  /* -bck, src/match/sfx-run.c:157-160: gt_fa_fopen, the iterator closes it */
+  if (want_bck) {
+    fpbck = gt_fa_fopen_with_suffix(indexname, GT_BCKTABSUFFIX, "wb", err);
+    if (fpbck == NULL) haserr = true;
+  }
   longest.defined = false;
   longest.valueunsignedlong = 0;
   sfi = haserr ? NULL
                : gt_Sfxiterator_new_withadditionalvalues(encseq,
                      readmode, prefixlength, 1U, 0UL, outlcpinfo,
-                     NULL, &strategy, NULL, false, NULL, err);
+                     fpbck, &strategy, NULL, false, NULL, err);
   if (sfi == NULL) haserr = true;
   while (!haserr) {
     GtUword numberofsuffixes, pos;
@@ -210,6 +219,9 @@ int main(int argc, char **argv)
   if (!haserr) {
     longest.defined = true;
     longest.valueunsignedlong = gt_Sfxiterator_longest(sfi);
+    /* src/match/sfx-run.c:303-310 */
+    if (fpbck != NULL && gt_Sfxiterator_bcktab2file(fpbck, sfi, err) != 0)
+      haserr = true;
   }
   if (sfi != NULL && gt_Sfxiterator_delete(sfi, err) != 0) haserr = true;
   if (fpsuf != NULL) fclose(fpsuf);

@@ -60,6 +60,13 @@ FORCED_SAT = [("Duplicate.fna", ALL_DNA_SAT), ("TTTN.fna", ALL_DNA_SAT),
               ("Reads1.fna", ["eqlen"]),
               ("extra/protein_specials.faa", ["direct", "bytecompress"]),
               ("extra/protein_long_x.faa", ["direct", "bytecompress"])]
+BCK_FILES = [("Atinsert.fna", [0, 1, 2, 3, 7]), ("Duplicate.fna", [0, 1, 2, 5]),
+             ("RandomN.fna", [0, 3, 6]), ("TTTN.fna", [0, 1, 2, 3]),
+             ("Verysmall.fna", [0, 2]), ("Reads1.fna", [0, 4]),
+             ("extra/starts_ends_special.fna", [0, 1, 2, 3, 4]),
+             ("extra/long_runs.fna", [0, 8]), ("extra/lowercase_iupac.fna", [0, 3]),
+             ("extra/protein_specials.faa", [0, 1, 2, 3]),
+             ("extra/protein_long_x.faa", [0, 2, 3]), ("sw100K1.fsa", [0, 2])]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -180,6 +187,26 @@ def main():
                     if os.path.exists(idx + "." + ext):
                         shutil.copyfile(idx + "." + ext, os.path.join(
                             esq_dir, "%s.%s.%s" % (os.path.basename(name), sat, ext)))
+    # bucket table (-bck) for several prefix lengths and the 32-bit suffix table
+    # (-suftabuint); keys "<name>|<pl>" (pl 0: the recommended prefixlength)
+    bck = {}
+    for name, pls in BCK_FILES:
+        src = (os.path.join(OUT, name) if name.startswith("extra/")
+               else os.path.join(REF, "testdata", name))
+        flag = "-protein" if name.endswith((".faa", ".fsa")) else "-dna"
+        for pl in pls:
+            with tempfile.TemporaryDirectory() as tmp:
+                idx = os.path.join(tmp, "idx")
+                run_ref(flag, [src], idx, extra=["-bck", "-suftabuint"] +
+                        (["-pl", str(pl)] if pl else []))
+                with open(idx + ".prj") as f:
+                    prj = f.read()
+                bck["%s|%d" % (name, pl)] = {
+                    "bck": {"md5": md5(idx + ".bck"), "bytes": os.path.getsize(idx + ".bck")},
+                    "suf32": {"md5": md5(idx + ".suf"), "bytes": os.path.getsize(idx + ".suf")},
+                    "prj": prj}
+    with open(os.path.join(OUT, "golden_bck.json"), "w") as f:
+        json.dump(bck, f, indent=1, sort_keys=True)
     variants = {}
     for name in VARIANT_FILES:
         src = os.path.join(REF, "testdata", name)

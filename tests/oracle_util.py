@@ -113,6 +113,37 @@ def esa(enc, numofchars=4, kasai=True):
             "lcpfull": lcpw, "stats": stats}
 
 
+def bck_sizes(numofchars, k):
+    """entries of the three sections of INDEX.bck (src/match/bcktab.c:240-287)"""
+    codes = numofchars ** k
+    special = numofchars ** (k - 1) if k >= 1 else 1
+    dist = sum(numofchars ** i for i in range(1, k - 1))
+    return codes, special, dist
+
+
+def bck_file_bytes(sections):
+    """uint32 sections -> file content: every section padded to 8 bytes
+    (src/core/mapspec.c:350-457)"""
+    out = b""
+    for sec in sections:
+        raw = np.ascontiguousarray(sec, dtype="<u4").tobytes()
+        if raw:
+            out += raw + b"\0" * (-len(raw) % 8)
+    return out
+
+
+def bcktab(enc, numofchars, k):
+    """the oracle's bucket table sections for prefix length k"""
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    codes, special, dist = bck_sizes(numofchars, k)
+    lb = np.zeros(codes + 1, dtype=np.uint32)
+    cs = np.zeros(special, dtype=np.uint32)
+    dp = np.zeros(max(dist, 1), dtype=np.uint32)
+    L.ora_bcktab(_p(enc), enc.size, numofchars, k, _p(lb), _p(cs), _p(dp))
+    return lb, cs, dp[:dist]
+
+
 def tables_given_sa(enc, sa):
     """LCP (Kasai) and BWT of the oracle for an externally supplied suffix
     array -- used at sizes where the oracle's comparison sort is too slow"""

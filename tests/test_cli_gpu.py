@@ -172,3 +172,26 @@ def test_cli_device_and_host_reader_write_the_same_index(cli, name, tmp_path):
     for ext, v in e["seqfiles"].items():
         assert out["device"][ext] == v["md5"], ext
     assert out["device"]["suf"] == e["tables"]["suf"]["md5"]
+
+
+BCK = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_bck.json")))
+
+
+@pytest.mark.parametrize("key", sorted(BCK))
+def test_cli_bucket_table_and_32bit_suffix_table(cli, key, tmp_path):
+    """-bck [-pl K] and -suftabuint: INDEX.bck and the narrow INDEX.suf as the
+    reference writes them"""
+    name, pl = key.split("|")
+    e = BCK[key]
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-" + GOLDEN[name]["alphabet"], "-suf", "-lcp", "-bwt", "-bck",
+                    "-suftabuint", "-indexname", idx, "-db", os.path.basename(src)] +
+                   (["-pl", pl] if pl != "0" else []), check=True, cwd=os.path.dirname(src))
+    for ext, key2 in (("bck", "bck"), ("suf", "suf32")):
+        with open(idx + "." + ext, "rb") as f:
+            raw = f.read()
+        assert len(raw) == e[key2]["bytes"], ext
+        assert hashlib.md5(raw).hexdigest() == e[key2]["md5"], ext
+    with open(idx + ".prj") as f:
+        assert f.read() == e["prj"]

@@ -214,3 +214,40 @@ def test_packed_device_input(gpu):
     with pytest.raises(esa.EsaError, match="2-bit DNA layout only"):
         with esa.EsaEngine(100, 20) as eng:
             eng.set_sequence_packed_device(d_tb.data_ptr(), d_sp.data_ptr(), 10)
+
+
+@pytest.mark.parametrize("model,n,ks", [
+    (synth.MODEL_HUMANLIKE_DNA, 1_000_003, [0, 1, 2, 5, 12]),
+    (synth.MODEL_UNIFORM_DNA, 300_000, [0, 3, 9]),
+    (synth.MODEL_PROTEIN, 400_000, [0, 1, 2, 3, 4]),
+])
+def test_bucket_table_matches_oracle(gpu, model, n, ks):
+    """GTAMD_WANT_BCK: the three sections of INDEX.bck from the sorted keys,
+    against the oracle's restatement (pinned to the reference's .bck files in
+    tests/test_oracle_golden.py)"""
+    sigma = synth.numofchars(model)
+    enc = synth.generate(model, 11, n)
+    with esa.EsaEngine(n, sigma) as eng:
+        eng.set_sequence(enc)
+        for k in ks:
+            eng.set_prefixlength(k)
+            eng.run(esa.WANT_SUF | esa.WANT_BCK)
+            kk = eng.stats()["prefixlength"]
+            assert k in (0, kk)
+            got = eng.bcktab()
+            want = ou.bcktab(enc, sigma, kk)
+            for name, g, w in zip(("leftborder", "countspecialcodes", "distpfxidx"), got, want):
+                assert np.array_equal(g, w), (name, kk)
+            # buckets are what they claim: the suffixes between two borders
+            # start with the bucket's k-mer
+            if kk <= 5:
+                suf = eng.table(esa.TAB_SUF)
+                lb = got[0]
+                for code in (0, len(lb) // 2, len(lb) - 2):
+                    for i in range(int(lb[code]), min(int(lb[code + 1]), int(lb[code]) + 50)):
+                        p = int(suf[i])
+                        digits = [(code // sigma ** (kk - 1 - j)) % sigma for j in range(kk)]
+                        seen = [int(x) for x in enc[p:p + kk]]
+                        letters = next((j for j, x in enumerate(seen) if x >= 254), len(seen))
+                        assert seen[:letters] == digits[:letters]
+                        assert all(d == sigma - 1 for d in digits[letters:])

@@ -6,44 +6,26 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-
-static int slurp_whole(const char *path, uint8_t **data, uint64_t *len)
-{
-  FILE *fp = fopen(path, "rb");
-  uint64_t cap = 1 << 20, n = 0;
-  size_t got;
-  uint8_t *buf;
-  if (fp == NULL) return -1;
-  if (fseek(fp, 0, SEEK_END) == 0) {
-    const long size = ftell(fp);
-    if (size > 0) cap = (uint64_t) size + 1;
-    rewind(fp);
-  }
-  buf = malloc(cap);
-  while (buf != NULL && (got = fread(buf + n, 1, cap - n, fp)) > 0) {
-    n += got;
-    if (n == cap) {
-      uint8_t *nb = realloc(buf, cap * 2);
-      if (nb == NULL) { free(buf); buf = NULL; break; }
-      buf = nb; cap *= 2;
-    }
-  }
-  fclose(fp);
-  if (buf == NULL) return -2;
-  *data = buf; *len = n;
-  return 0;
-}
+#include <zlib.h>
 
 int gtamd_input_is_fastq(const char *const *paths, size_t numfiles)
 {
   /* format by the first character (src/core/sequence_buffer.c guesses the
      type from the first file) */
   for (size_t f = 0; f < numfiles; f++) {
-    FILE *fp = fopen(paths[f], "rb");
+    const size_t plen = strlen(paths[f]);
     int c;
-    if (fp == NULL) continue;
-    c = fgetc(fp);
-    fclose(fp);
+    if (plen >= 4 && strcmp(paths[f] + plen - 3, ".gz") == 0) {
+      gzFile gz = gzopen(paths[f], "rb");
+      if (gz == NULL) continue;
+      c = gzgetc(gz);
+      gzclose(gz);
+    } else {
+      FILE *fp = fopen(paths[f], "rb");
+      if (fp == NULL) continue;
+      c = fgetc(fp);
+      fclose(fp);
+    }
     if (c == '@') return 1;
   }
   return 0;
@@ -68,10 +50,9 @@ int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
   if (raw == NULL || rawlen == NULL) goto nomem;
   if ((de = gtamd_encoder_create(0, protein)) == NULL) goto deverr;
   for (size_t f = 0; f < numfiles; f++) {
-    const int src = slurp_whole(paths[f], &raw[f], &rawlen[f]);
+    const int src = gtamd_read_input_file(paths[f], &raw[f], &rawlen[f]);
     if (src != 0) {
-      snprintf(err, errlen, src == -1 ? "cannot open file '%s'"
-                                      : "out of memory while reading '%s'", paths[f]);
+      gtamd_read_input_error(src, paths[f], err, errlen);
       goto done;
     }
     if (gtamd_encoder_add_file(de, paths[f], raw[f], rawlen[f]) != 0) goto deverr;

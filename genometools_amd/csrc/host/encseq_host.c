@@ -6,6 +6,7 @@
 #include <limits.h>
 #include <pthread.h>
 #include <unistd.h>
+#include <zlib.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,27 +50,64 @@ static int is_blank(int c)
   return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
 }
 
-/* whole file in memory (inputs of this layer are files the caller named; the
-   device path dominates for anything large) */
-static int slurp(const char *path, unsigned char **data, size_t *len)
+/* whole file in memory (the device encoder wants it whole, the host reader
+   walks it once).  The compression follows the file name, as in the reference
+   (gt_file_mode_determine, src/core/file.c:42-53): "*.gz" is read through
+   zlib; the file length the encoder reports is that of the decompressed text. */
+int gtamd_read_input_file(const char *path, uint8_t **data, uint64_t *len)
 {
-  FILE *fp = fopen(path, "rb");
-  size_t cap = 1 << 16, n = 0, got;
-  unsigned char *buf;
-  if (fp == NULL) return -1;
-  buf = malloc(cap);
-  while (buf != NULL && (got = fread(buf + n, 1, cap - n, fp)) > 0) {
-    n += got;
-    if (n == cap) {
-      unsigned char *nb = realloc(buf, cap * 2);
-      if (nb == NULL) { free(buf); buf = NULL; break; }
-      buf = nb; cap *= 2;
+  const size_t plen = strlen(path);
+  uint64_t cap = 1 << 20, n = 0;
+  uint8_t *buf;
+  if (plen >= 5 && strcmp(path + plen - 4, ".bz2") == 0) return -3;
+  if (plen >= 4 && strcmp(path + plen - 3, ".gz") == 0) {
+    gzFile gz = gzopen(path, "rb");
+    int got;
+    if (gz == NULL) return -1;
+    (void) gzbuffer(gz, 1 << 20);
+    buf = malloc(cap);
+    while (buf != NULL && (got = gzread(gz, buf + n, (unsigned) (cap - n < (1u << 30) ? cap - n : (1u << 30)))) > 0) {
+      n += (uint64_t) got;
+      if (n == cap) {
+        uint8_t *nb = realloc(buf, cap * 2);
+        if (nb == NULL) { free(buf); buf = NULL; break; }
+        buf = nb; cap *= 2;
+      }
     }
+    if (buf != NULL && !gzeof(gz)) { free(buf); gzclose(gz); return -4; }
+    gzclose(gz);
+  } else {
+    FILE *fp = fopen(path, "rb");
+    size_t got;
+    if (fp == NULL) return -1;
+    if (fseek(fp, 0, SEEK_END) == 0) {
+      const long size = ftell(fp);
+      if (size > 0) cap = (uint64_t) size + 1;
+      rewind(fp);
+    }
+    buf = malloc(cap);
+    while (buf != NULL && (got = fread(buf + n, 1, cap - n, fp)) > 0) {
+      n += got;
+      if (n == cap) {
+        uint8_t *nb = realloc(buf, cap * 2);
+        if (nb == NULL) { free(buf); buf = NULL; break; }
+        buf = nb; cap *= 2;
+      }
+    }
+    fclose(fp);
   }
-  fclose(fp);
   if (buf == NULL) return -2;
   *data = buf; *len = n;
   return 0;
+}
+
+void gtamd_read_input_error(int code, const char *path, char *err, size_t errlen)
+{
+  snprintf(err, errlen,
+           code == -1 ? "cannot open file '%s'"
+           : code == -3 ? "file '%s': bzip2-compressed input is not supported, use gzip or plain text"
+           : code == -4 ? "file '%s' is not a complete gzip stream"
+                        : "out of memory while reading '%s'", path);
 }
 
 typedef struct { uint64_t seqlen, desclen; size_t file; } fastq_record;
@@ -332,13 +370,12 @@ int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
     }
   }
   for (size_t f = 0; f < numfiles && rc == 0; f++) {
-    unsigned char *data = NULL;
-    size_t len = 0;
+    uint8_t *data = NULL;
+    uint64_t len = 0;
     st.file = f;
-    rc = slurp(paths[f], &data, &len);
+    rc = gtamd_read_input_file(paths[f], &data, &len);
     if (rc != 0) {
-      snprintf(err, errlen, rc == -1 ? "cannot open file '%s'"
-                                     : "out of memory while reading '%s'", paths[f]);
+      gtamd_read_input_error(rc, paths[f], err, errlen);
       break;
     }
     /* format by the first character, as the reference guesses it

@@ -48,6 +48,11 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
                              int write_ssp, const gtamd_esq_sections *sec,
                              char *err, size_t errlen);
 
+/* one input file, whole, decompressed when its name ends in ".gz"; 0 or a code
+   for gtamd_read_input_error */
+int gtamd_read_input_file(const char *path, uint8_t **data, uint64_t *len);
+void gtamd_read_input_error(int code, const char *path, char *err, size_t errlen);
+
 /* symbol map of the DNA / protein alphabet; 253 marks undefined characters */
 void gtamd_symbolmap(uint8_t map[256], int protein);
 

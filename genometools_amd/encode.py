@@ -53,7 +53,12 @@ class DeviceEncoder:
         """encode files (paths) or in-memory inputs ((name, bytes) pairs)"""
         inputs = []
         for p in paths or []:
-            inputs.append((p, np.fromfile(p, dtype=np.uint8)))
+            if str(p).endswith(".gz"):      # by name, src/core/file.c:42-53
+                import gzip
+                with gzip.open(p, "rb") as f:
+                    inputs.append((p, np.frombuffer(f.read(), dtype=np.uint8)))
+            else:
+                inputs.append((p, np.fromfile(p, dtype=np.uint8)))
         for name, raw in buffers or []:
             inputs.append((name, np.frombuffer(raw, dtype=np.uint8)
                            if not isinstance(raw, np.ndarray) else raw))

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <zlib.h>
 
 #define ISSPECIAL(c) ((c) >= 254u)   /* src/core/chardef.h:60 */
 
@@ -43,10 +44,30 @@ static void protein_symbolmap(uint8_t *map)
    '>' emits nothing, every later one emits SEPARATOR; white space is skipped;
    symbols go through the symbol map (sequence_buffer_inline.h:26-58).
    Empty sequences are rejected as in src/core/encseq_charproc.gen:112-117. */
+/* "*.gz" is read through zlib, chosen by the file name as in
+   src/core/file.c:42-53; the text is spooled to a temporary file so that the
+   reader below stays a plain stdio loop */
+static FILE *open_input(const char *path)
+{
+  const size_t len = strlen(path);
+  if (len >= 4 && strcmp(path + len - 3, ".gz") == 0) {
+    gzFile gz = gzopen(path, "rb");
+    FILE *tmp = gz != NULL ? tmpfile() : NULL;
+    char buf[1 << 15];
+    int got;
+    if (tmp == NULL) { if (gz != NULL) gzclose(gz); return NULL; }
+    while ((got = gzread(gz, buf, sizeof buf)) > 0) fwrite(buf, 1, (size_t) got, tmp);
+    gzclose(gz);
+    rewind(tmp);
+    return tmp;
+  }
+  return fopen(path, "rb");
+}
+
 int ora_encode_fasta(const char *path, int protein, uint8_t **encout,
                      uint64_t *nout, char *err, size_t errlen)
 {
-  FILE *fp = fopen(path, "rb");
+  FILE *fp = open_input(path);
   uint8_t map[256], *enc;
   uint64_t n = 0, cap = 1 << 16, line = 1, curlen = 0;
   int c, indesc = 0, first = 1;

@@ -31,6 +31,8 @@ REF = os.environ.get("GT_REFERENCE", "/root/reference")
 BIN = os.path.join(ROOT, "oracle", "_ref", "gt_ref_sfx")
 OUT = os.path.join(ROOT, "tests", "golden")
 
+# gzip-compressed input (read through zlib by name, src/core/file.c:42-53)
+GZ = ["ebola-genomes.fna.gz"]
 DNA = ["Arabidopsis-C99826.fna", "Atinsert.fna",
        "Atinsert_seqrange_13-17_rev.fna", "Atinsert_seqrange_3-7.fna",
        "Atinsert_single_3.fna", "Atinsert_single_3_rev.fna",
@@ -105,7 +107,7 @@ def main():
     os.makedirs(os.path.join(OUT, "fixtures"), exist_ok=True)
     os.makedirs(os.path.join(OUT, "tables"), exist_ok=True)
     golden = {}
-    for name, flag in [(f, "-dna") for f in DNA + FASTQ] + [(f, "-protein") for f in PROTEIN]:
+    for name, flag in [(f, "-dna") for f in DNA + FASTQ + GZ] + [(f, "-protein") for f in PROTEIN]:
         src = os.path.join(REF, "testdata", name)
         if not os.path.exists(src):
             print("missing", src)

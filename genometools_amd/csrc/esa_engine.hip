@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N, u64 stride,
 // adds the block's counts per part to partcnt (for the exact slice offsets).
 template <int BITS>
 __global__ __launch_bounds__(256) void k_part_count(
-    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner,
+    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner, u32 numparts,
     u64 *__restrict__ inrange, u32 *__restrict__ cnt,
     unsigned long long *__restrict__ partcnt) {
   __shared__ u32 s_cnt[4];
@@ -310,11 +310,21 @@ __global__ __launch_bounds__(256) void k_part_count(
   for (int j = 0; j < 4; j++) {
     const u64 p = (u64) blockIdx.x * 1024 + (u64) j * 256 + threadIdx.x;
     bool in = false;
+    u32 o = 0xFFFFFFFFu;
     if (p < N) {
       const u32 b = key_bin<BITS>(t, p);
       in = b >= lo && b < hi;
-      atomicAdd(&s_part[owner[b]], 1u);
+      o = owner[b];
     }
+    // suffixes per part: a few hot counters, so count with ballots (one LDS
+    // add per wave and part) rather than 256 contended atomics
+    if (numparts <= 16) {
+      for (u32 r = 0; r < numparts; r++) {
+        const u64 mr = __ballot(o == r);
+        if (lane == 0 && mr) atomicAdd(&s_part[r], (u32) __popcll(mr));
+      }
+    } else if (o != 0xFFFFFFFFu)
+      atomicAdd(&s_part[o], 1u);
     const u64 m = __ballot(in);
     if (lane == 0) {
       inrange[(u64) blockIdx.x * 16 + j * 4 + w] = m;
@@ -325,6 +335,75 @@ __global__ __launch_bounds__(256) void k_part_count(
   __syncthreads();
   if (threadIdx.x == 0) cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
   if (s_part[threadIdx.x])
+    atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
+}
+
+// The same for DNA and at most 16 parts, one thread per packed text word: the
+// bins of 32 consecutive suffixes are sliding 14-bit windows over two words,
+// specials come from one 64-position window of the bitmap.  Per-part counts
+// ride in byte-wide fields of two registers.  8 bitmask/count blocks of 1024
+// positions per thread block.
+__global__ __launch_bounds__(256) void k_part_count_dna(
+    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner,
+    u64 *__restrict__ inrange, u32 *__restrict__ cnt,
+    unsigned long long *__restrict__ partcnt) {
+  __shared__ u8 s_owner[PART_BINS];
+  __shared__ u32 s_part[16];
+  for (int i = threadIdx.x; i < PART_BINS / 4; i += 256)
+    reinterpret_cast<u32 *>(s_owner)[i] = reinterpret_cast<const u32 *>(owner)[i];
+  if (threadIdx.x < 16) s_part[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x, p0 = w * 32;
+  u32 mask = 0;
+  u64 clo = 0, chi = 0;          // 8 + 8 counters of 8 bits (at most 32 each)
+  if (p0 < N) {
+    const u64 W0 = tb_word(t, w), W1 = tb_word(t, w + 1);
+    const u64 S = sp_window(t, p0);
+    const int npos = N - p0 < 32 ? (int) (N - p0) : 32;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+      if (i < npos) {
+        const u64 x = i == 0 ? W0 : (W0 << (2 * i)) | (W1 >> (64 - 2 * i));
+        u32 b = (u32) (x >> (64 - PART_BITS));
+        const u32 s7 = (u32) (S >> i) & 0x7Fu;
+        if (s7) b |= (1u << (2 * (7 - (__ffs(s7) - 1)))) - 1u;   // pad behind d letters
+        mask |= (u32) (b >= lo && b < hi) << i;
+        const u32 o = s_owner[b];
+        if (o < 8) clo += 1ull << (8 * o); else chi += 1ull << (8 * (o - 8));
+      }
+    }
+  }
+  // bitmask words: two threads per 64 positions
+  const u32 other = __shfl_xor(mask, 1, 64);
+  // (every word of a started 1024-position block is written, also behind N)
+  const bool started = (w >> 5) < (N + 1023) / 1024;
+  if ((lane & 1) == 0 && started) inrange[w >> 1] = (u64) mask | ((u64) other << 32);
+  // suffixes in range per 1024 positions (32 threads)
+  u32 c = (u32) __popc(mask);
+#pragma unroll
+  for (int d = 1; d < 32; d <<= 1) c += __shfl_xor(c, d, 64);
+  if ((lane & 31) == 0 && started) cnt[w >> 5] = c;
+  // per-part counts: widen to 16-bit fields, add up the wave, then the block
+  u64 f[4] = {clo & 0x00FF00FF00FF00FFull, (clo >> 8) & 0x00FF00FF00FF00FFull,
+              chi & 0x00FF00FF00FF00FFull, (chi >> 8) & 0x00FF00FF00FF00FFull};
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] += __shfl_xor(f[k], d, 64);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        // f[0]: parts 0,2,4,6  f[1]: 1,3,5,7  f[2]: 8,10,12,14  f[3]: 9,11,13,15
+        const u32 part = (u32) (k >> 1) * 8 + 2 * q + (k & 1);
+        const u32 v = (u32) (f[k] >> (16 * q)) & 0xFFFFu;
+        if (v) atomicAdd(&s_part[part], v);
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16 && s_part[threadIdx.x])
     atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
 }
 
@@ -369,7 +448,7 @@ __global__ __launch_bounds__(256) void k_part_emit(
 template <int BITS>
 __global__ __launch_bounds__(256) void k_query_dest(
     Text t, const u32 *__restrict__ upos, u64 m, u64 h,
-    const u8 *__restrict__ owner, u64 *__restrict__ dkey,
+    const u8 *__restrict__ owner, u32 *__restrict__ dkey,
     u32 *__restrict__ dval, u32 *__restrict__ counts) {
   __shared__ u32 s_cnt[256];
   s_cnt[threadIdx.x] = 0;
@@ -1108,10 +1187,12 @@ __global__ __launch_bounds__(256) void k_lcp_pairs(
 }
 
 // LCP of the tied entries in TEXT order (the pairs are sorted by position):
-// for consecutive text positions lcp(p+1, pred(p+1)) >= lcp(p, pred(p)) - 1
-// (Kasai et al.; the reference's src/match/sfx-linlcp.c:74-129 walks the whole
-// text this way), so inside a repeat only the first position of a chunk pays
-// for the full extension.  One thread walks LCP_CHUNK consecutive pairs.
+// lcp(p+1, pred(p+1)) >= lcp(p, pred(p)) - 1 (Kasai et al.; the reference's
+// src/match/sfx-linlcp.c:74-129 walks the whole text this way), hence
+// lcp(p+d, pred(p+d)) >= lcp(p, pred(p)) - d for any distance d -- which is
+// what a part build needs, where a part sees only every R-th position of a
+// repeat.  Inside a repeat only the first position of a chunk pays for the
+// full extension.  One thread walks LCP_CHUNK consecutive pairs.
 constexpr int LCP_CHUNK = 32;
 template <int BITS>
 __global__ __launch_bounds__(256) void k_lcp_chunks(
@@ -1124,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, nlarge = 0;
   u32 mx = 0;
-  u64 prevp = ~0ull - 1, l = 0;
+  u64 prevp = 0, l = 0;
   for (int e = 0; e < LCP_CHUNK; e++) {
     const u64 s = c * LCP_CHUNK + e;
     if (s >= m1) break;
@@ -1133,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     const u64 i = uidx0[j];
     const u64 q = sa32[i - 1];
     u64 from = (u64) Key<BITS>::SYMS;
-    if (p == prevp + 1 && l > from + 1) from = l - 1;
+    if (e > 0 && l > from + (p - prevp)) from = l - (p - prevp);
     l = lcp_extend<BITS>(t, q, p, from);
     prevp = p;
     const u32 lv = (u32) l;
@@ -1495,7 +1576,7 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   HIP_TRY(hipMemsetAsync(d_counts, 0, 256 * 4, st));
   if (m > 0) {
     k_query_dest<BITS><<<(u32) div_up(m, 256), 256, 0, st>>>(
-        c->text, upos, m, h, c->d_owner, dkey_a, dval_a, d_counts);
+        c->text, upos, m, h, c->d_owner, reinterpret_cast<u32 *>(dkey_a), dval_a, d_counts);
     HIP_TRY(hipGetLastError());
   }
   u32 h_counts[256];
@@ -1515,8 +1596,10 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   const u32 *order = dval_a;
   if (m > 0) {
     const int shift0 = 0, width8 = 8;
-    TRY(radix_sort_pairs<u64, u32>(dkey_a, dval_a, dkey_b, dval_b, m, &shift0,
-                              &width8, 1, rws2, st, nullptr, nullptr));
+    // (the owner is the whole key: 32-bit keys in the 64-bit key buffers)
+    TRY(radix_sort_pairs<u32, u32>(reinterpret_cast<u32 *>(dkey_a), dval_a,
+                                   reinterpret_cast<u32 *>(dkey_b), dval_b, m, &shift0,
+                                   &width8, 1, rws2, st, nullptr, nullptr));
     order = dval_b;
     k_query_fill<<<(u32) div_up(m, 256), 256, 0, st>>>(upos, order, m, h, c->n, sendq);
     HIP_TRY(hipGetLastError());
@@ -1662,8 +1745,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     unsigned long long *d_partcnt =
         reinterpret_cast<unsigned long long *>(c->d_parthist);  // 256 x u64 fit
     HIP_TRY(hipMemsetAsync(d_partcnt, 0, 256 * 8, st));
-    k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, c->d_owner,
-                                                   inrange, cnt, d_partcnt);
+    if (BITS == 2 && R <= 16 && PART_BITS == 14)
+      k_part_count_dna<<<(u32) div_up(N, 8192), 256, 0, st>>>(c->text, N, lo, hi,
+                                                             c->d_owner, inrange, cnt,
+                                                             d_partcnt);
+    else
+      k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, c->d_owner, R,
+                                                     inrange, cnt, d_partcnt);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, cnt, off, nblk, false, sws, st));
     unsigned long long h_partcnt[256];

@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_part_count(
 __global__ __launch_bounds__(256) void k_part_count_dna(
     Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner,
     u64 *__restrict__ inrange, u32 *__restrict__ cnt,
-    unsigned long long *__restrict__ partcnt) {
+    unsigned long long *__restrict__ partcnt, u8 *__restrict__ pos_owner) {
   __shared__ u8 s_owner[PART_BINS];
   __shared__ u32 s_part[16];
   for (int i = threadIdx.x; i < PART_BINS / 4; i += 256)
@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256) void k_part_count_dna(
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x, p0 = w * 32;
   u32 mask = 0;
   u64 clo = 0, chi = 0;          // 8 + 8 counters of 8 bits (at most 32 each)
+  u64 ow[4] = {0, 0, 0, 0};
   if (p0 < N) {
     const u64 W0 = tb_word(t, w), W1 = tb_word(t, w + 1);
     const u64 S = sp_window(t, p0);
@@ -371,8 +372,17 @@ __global__ __launch_bounds__(256) void k_part_count_dna(
         mask |= (u32) (b >= lo && b < hi) << i;
         const u32 o = s_owner[b];
         if (o < 8) clo += 1ull << (8 * o); else chi += 1ull << (8 * (o - 8));
+        ow[i >> 3] |= (u64) o << (8 * (i & 7));
       }
     }
+    // owners of the 32 suffixes: four 8-byte stores
+    if (npos == 32) {
+      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(pos_owner + p0);
+      ulonglong2 a, b2;
+      a.x = ow[0]; a.y = ow[1]; b2.x = ow[2]; b2.y = ow[3];
+      dst[0] = a; dst[1] = b2;
+    } else
+      for (int i = 0; i < npos; i++) pos_owner[p0 + i] = (u8) (ow[i >> 3] >> (8 * (i & 7)));
   }
   // bitmask words: two threads per 64 positions
   const u32 other = __shfl_xor(mask, 1, 64);
@@ -473,6 +483,70 @@ __global__ __launch_bounds__(256) void k_query_fill(
   if (s >= m) return;
   u64 q = (u64) upos[order[s]] + h;
   sendq[s] = (u32) (q > n ? n : q);
+}
+
+// ---- the same bucketing for at most 16 parts, without a sort -----------------
+// pos_owner[p] = part that owns suffix p (written while the range membership of
+// all suffixes is computed), so a query's destination is one byte away.
+// k_q_count: destination of every query (kept as a byte) and, per block of 256
+// queries, how many go to each part -- laid out part-major, so that ONE
+// exclusive scan over numparts * blocks counters gives every block its write
+// offset inside every part's segment of the send buffer.
+__global__ __launch_bounds__(256) void k_q_count(
+    const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ pos_owner,
+    u32 numparts, u64 nblocks, u8 *__restrict__ dest, u32 *__restrict__ bcount) {
+  __shared__ u32 s_cnt[4][16];
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u32 d = 0xFFu;
+  if (j < m) {
+    u64 q = (u64) upos[j] + h;
+    if (q > n) q = n;
+    d = pos_owner[q];
+    dest[j] = (u8) d;
+  }
+  for (u32 r = 0; r < numparts; r++) {
+    const u64 mr = __ballot(d == r);
+    if (lane == 0) s_cnt[w][r] = (u32) __popcll(mr);
+  }
+  __syncthreads();
+  if (threadIdx.x < numparts)
+    bcount[(u64) threadIdx.x * nblocks + blockIdx.x] =
+        s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] +
+        s_cnt[3][threadIdx.x];
+}
+
+// k_q_place: queries and their slots to their place in the send buffer (stable)
+__global__ __launch_bounds__(256) void k_q_place(
+    const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ dest,
+    u32 numparts, u64 nblocks, const u32 *__restrict__ boff, u32 *__restrict__ sendq,
+    u32 *__restrict__ order) {
+  __shared__ u32 s_cnt[4][16];
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u32 d = j < m ? dest[j] : 0xFFu;
+  u32 before = 0;                 // queries of this wave's lower lanes to the same part
+  for (u32 r = 0; r < numparts; r++) {
+    const u64 mr = __ballot(d == r);
+    if (lane == 0) s_cnt[w][r] = (u32) __popcll(mr);
+    if (d == r) before = (u32) __popcll(mr & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  if (j >= m) return;
+  u32 at = boff[(u64) d * nblocks + blockIdx.x] + before;
+  for (int x = 0; x < w; x++) at += s_cnt[x][d];
+  u64 q = (u64) upos[j] + h;
+  sendq[at] = (u32) (q > n ? n : q);
+  order[at] = (u32) j;
+}
+
+// send counts per part from the scanned block counters: segment boundaries
+__global__ void k_q_totals(const u32 *__restrict__ boff, const u32 *__restrict__ bcount,
+                           u32 numparts, u64 nblocks, u32 *__restrict__ counts) {
+  const u32 r = threadIdx.x;
+  if (r >= numparts) return;
+  const u64 first = (u64) r * nblocks, last = first + nblocks - 1;
+  counts[r] = boff[last] + bcount[last] - boff[first];
 }
 
 __global__ __launch_bounds__(256) void k_answer(const u32 *__restrict__ q,
@@ -1307,6 +1381,8 @@ struct gtamd_esa_ctx {
   u64 NL, index_offset;    // entries and offset of this part's slice
   u32 *d_parthist;         // PART_BINS counters
   u8 *d_owner;             // bin -> owning part
+  u8 *pos_owner;           // part builds of DNA with <= 16 parts: suffix -> owning part
+  bool have_pos_owner;
   u32 *xbuf;               // exchange buffers (grow-only)
   u64 xbuf_words;
   // results
@@ -1332,6 +1408,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   free_dev(c->rws); free_dev(c->dig0); free_dev(c->dig1); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->tiebits); free_dev(c->d_stats);
   free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
+  free_dev(c->pos_owner);
   free_dev(c->xbuf);
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
   for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
@@ -1574,7 +1651,19 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   const u32 R = c->numparts;
   u32 *d_counts = c->d_parthist;   // idle after the split: reuse 256 counters
   HIP_TRY(hipMemsetAsync(d_counts, 0, 256 * 4, st));
-  if (m > 0) {
+  // few parts and an owner map: bucket without a sort (k_q_count / k_q_place)
+  const bool direct = c->have_pos_owner && R <= 16;
+  const u64 qb = div_up(m, 256);
+  u8 *dest = reinterpret_cast<u8 *>(dkey_b);          // m bytes
+  u32 *bcount = reinterpret_cast<u32 *>(dkey_a);      // R * qb counters, then their scan
+  u32 *boff = bcount + (u64) R * qb + 16;
+  if (m > 0 && direct) {
+    k_q_count<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, c->pos_owner, R, qb, dest, bcount);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, bcount, boff, (u64) R * qb, false, rws2, st));
+    k_q_totals<<<1, 64, 0, st>>>(boff, bcount, R, qb, d_counts);
+    HIP_TRY(hipGetLastError());
+  } else if (m > 0) {
     k_query_dest<BITS><<<(u32) div_up(m, 256), 256, 0, st>>>(
         c->text, upos, m, h, c->d_owner, reinterpret_cast<u32 *>(dkey_a), dval_a, d_counts);
     HIP_TRY(hipGetLastError());
@@ -1594,7 +1683,11 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   *all_queries = total;   // zero: no part has tied suffixes left
   if (total == 0) return 0;
   const u32 *order = dval_a;
-  if (m > 0) {
+  if (m > 0 && direct) {
+    k_q_place<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, dest, R, qb, boff, sendq, dval_b);
+    HIP_TRY(hipGetLastError());
+    order = dval_b;
+  } else if (m > 0) {
     const int shift0 = 0, width8 = 8;
     // (the owner is the whole key: 32-bit keys in the 64-bit key buffers)
     TRY(radix_sort_pairs<u32, u32>(reinterpret_cast<u32 *>(dkey_a), dval_a,
@@ -1745,10 +1838,15 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     unsigned long long *d_partcnt =
         reinterpret_cast<unsigned long long *>(c->d_parthist);  // 256 x u64 fit
     HIP_TRY(hipMemsetAsync(d_partcnt, 0, 256 * 8, st));
-    if (BITS == 2 && R <= 16 && PART_BITS == 14)
+    c->have_pos_owner = false;
+    if (BITS == 2 && R <= 16 && PART_BITS == 14) {
+      if (c->pos_owner == nullptr) HIP_TRY(hipMalloc(&c->pos_owner, N + 64));
+      c->have_pos_owner = true;
+    }
+    if (c->have_pos_owner)
       k_part_count_dna<<<(u32) div_up(N, 8192), 256, 0, st>>>(c->text, N, lo, hi,
                                                              c->d_owner, inrange, cnt,
-                                                             d_partcnt);
+                                                             d_partcnt, c->pos_owner);
     else
       k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, c->d_owner, R,
                                                      inrange, cnt, d_partcnt);

@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void k_query_fill(
 }
 
 // ---- the same bucketing for at most 16 parts, without a sort -----------------
+constexpr u32 Q_LOCAL = 0xFEu;   // destination code of a query this part answers itself
 // pos_owner[p] = part that owns suffix p (written while the range membership of
 // all suffixes is computed), so a query's destination is one byte away.
 // k_q_count: destination of every query (kept as a byte) and, per block of 256
@@ -494,7 +495,8 @@ __global__ __launch_bounds__(256) void k_query_fill(
 // offset inside every part's segment of the send buffer.
 __global__ __launch_bounds__(256) void k_q_count(
     const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ pos_owner,
-    u32 numparts, u64 nblocks, u8 *__restrict__ dest, u32 *__restrict__ bcount) {
+    u32 numparts, u32 self, u64 nblocks, u8 *__restrict__ dest,
+    u32 *__restrict__ bcount) {
   __shared__ u32 s_cnt[4][16];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(256) void k_q_count(
     u64 q = (u64) upos[j] + h;
     if (q > n) q = n;
     d = pos_owner[q];
+    if (d == self) d = Q_LOCAL;      // answered from the own table, not sent
     dest[j] = (u8) d;
   }
   for (u32 r = 0; r < numparts; r++) {
@@ -516,11 +519,12 @@ __global__ __launch_bounds__(256) void k_q_count(
         s_cnt[3][threadIdx.x];
 }
 
-// k_q_place: queries and their slots to their place in the send buffer (stable)
+// k_q_place: queries and their slots to their place in the send buffer (stable);
+// the ones this part owns itself are answered on the spot
 __global__ __launch_bounds__(256) void k_q_place(
     const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ dest,
     u32 numparts, u64 nblocks, const u32 *__restrict__ boff, u32 *__restrict__ sendq,
-    u32 *__restrict__ order) {
+    u32 *__restrict__ order, const u32 *__restrict__ rank, u32 *__restrict__ k2) {
   __shared__ u32 s_cnt[4][16];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -533,10 +537,12 @@ __global__ __launch_bounds__(256) void k_q_place(
   }
   __syncthreads();
   if (j >= m) return;
+  u64 q = (u64) upos[j] + h;
+  if (q > n) q = n;
+  if (d == Q_LOCAL) { k2[j] = rank[q]; return; }
   u32 at = boff[(u64) d * nblocks + blockIdx.x] + before;
   for (int x = 0; x < w; x++) at += s_cnt[x][d];
-  u64 q = (u64) upos[j] + h;
-  sendq[at] = (u32) (q > n ? n : q);
+  sendq[at] = (u32) q;
   order[at] = (u32) j;
 }
 
@@ -1658,7 +1664,8 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   u32 *bcount = reinterpret_cast<u32 *>(dkey_a);      // R * qb counters, then their scan
   u32 *boff = bcount + (u64) R * qb + 16;
   if (m > 0 && direct) {
-    k_q_count<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, c->pos_owner, R, qb, dest, bcount);
+    k_q_count<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, c->pos_owner, R, c->part, qb,
+                                        dest, bcount);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, bcount, boff, (u64) R * qb, false, rws2, st));
     k_q_totals<<<1, 64, 0, st>>>(boff, bcount, R, qb, d_counts);
@@ -1672,11 +1679,17 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 256 * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   std::vector<u64> sendcounts(R), matrix((size_t) R * R), recvcounts(R);
-  for (u32 r = 0; r < R; r++) sendcounts[r] = h_counts[r];
+  u64 msent = 0;
+  for (u32 r = 0; r < R; r++) { sendcounts[r] = h_counts[r]; msent += h_counts[r]; }
+  // queries this part answers itself are not sent; they still count in the
+  // matrix (its diagonal), which doubles as the termination test
+  const u64 mlocal = direct ? m - msent : 0;
+  if (direct) sendcounts[c->part] = mlocal;
   TRY(comm_allgather(c, sendcounts.data(), matrix.data(), R * 8));
+  if (direct) sendcounts[c->part] = 0;
   u64 nrecv = 0, total = 0;
   for (u32 r = 0; r < R; r++) {
-    recvcounts[r] = matrix[(size_t) r * R + c->part];
+    recvcounts[r] = (direct && r == c->part) ? 0 : matrix[(size_t) r * R + c->part];
     nrecv += recvcounts[r];
   }
   for (size_t i = 0; i < matrix.size(); i++) total += matrix[i];
@@ -1684,7 +1697,8 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
   if (total == 0) return 0;
   const u32 *order = dval_a;
   if (m > 0 && direct) {
-    k_q_place<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, dest, R, qb, boff, sendq, dval_b);
+    k_q_place<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, dest, R, qb, boff, sendq, dval_b,
+                                        rank, k2);
     HIP_TRY(hipGetLastError());
     order = dval_b;
   } else if (m > 0) {
@@ -1715,8 +1729,8 @@ static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
     gtamd_set_error("alltoallv callback failed (answers)");
     return -1;
   }
-  if (m > 0) {
-    k_k2_scatter<<<(u32) div_up(m, 256), 256, 0, st>>>(recvans, order, m, k2);
+  if (msent > 0) {
+    k_k2_scatter<<<(u32) div_up(msent, 256), 256, 0, st>>>(recvans, order, msent, k2);
     HIP_TRY(hipGetLastError());
   }
   return 0;

@@ -423,6 +423,23 @@ int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
   return 0;
 }
 
+void gtamd_clip_descriptions(char *desc, uint64_t *desclen)
+{
+  /* -clipdesc: every description ends at its first white space
+     (gt_desc_buffer_append_char, src/core/desc_buffer.c:69-80) */
+  uint64_t in = 0, out = 0;
+  while (in < *desclen) {
+    const uint64_t l = strlen(desc + in);
+    uint64_t keep = 0;
+    while (keep < l && !is_blank((unsigned char) desc[in + keep])) keep++;
+    memmove(desc + out, desc + in, keep);
+    desc[out + keep] = 0;
+    out += keep + 1;
+    in += l + 1;
+  }
+  *desclen = out;
+}
+
 int gtamd_write_des_sds(const char *indexname, const char *desc,
                         uint64_t desclen, int write_des, int write_sds)
 {

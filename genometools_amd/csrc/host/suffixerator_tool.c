@@ -122,7 +122,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_esa_stats es;
   gtamd_esa_ctx *ctx;
   gtamd_encoder *de = NULL;
-  int rc = -1, host_encoder = 0, suftabuint = 0;
+  int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0;
   double t0 = now_s(), t_seq, t_build, t_create;
 
   for (int i = 1; i < argc; i++) {
@@ -160,10 +160,27 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
         return fail(err, errlen, "argument to option -dir must be fwd or rev or cpl or rcl, not %s", argv[i]);
     } else if (!strcmp(a, "-mirrored")) {
       mirrored = 1;
-    } else if (!strcmp(a, "-parts") || !strcmp(a, "-memlimit") || !strcmp(a, "-dc")) {
+    } else if (!strcmp(a, "-parts") || !strcmp(a, "-memlimit") || !strcmp(a, "-dc") ||
+               !strcmp(a, "-maxwidthrealmedian")) {
       /* space/strategy knobs of the CPU algorithm: the tables do not depend on
          them, the device build ignores them */
       if (i + 1 < argc && argv[i + 1][0] != '-') i++;
+    } else if (!strcmp(a, "-algbds")) {
+      while (i + 1 < argc && argv[i + 1][0] != '-') i++;
+    } else if (!strcmp(a, "-cmpcharbychar") || !strcmp(a, "-dccheck") ||
+               !strcmp(a, "-iterscan") || !strcmp(a, "-kmerswithencseqreader") ||
+               !strcmp(a, "-noshortreadsort") || !strcmp(a, "-samplewithprefixlengthnull") ||
+               !strcmp(a, "-storespecialcodes") || !strcmp(a, "-withradixsort")) {
+      (void) yesno(argc, argv, &i);        /* more strategy switches, same tables */
+    } else if (!strcmp(a, "-clipdesc")) {
+      clipdesc = yesno(argc, argv, &i);
+    } else if (!strcmp(a, "-lossless") || !strcmp(a, "-smap") || !strcmp(a, "-sat") ||
+               !strcmp(a, "-plain") || !strcmp(a, "-kys") || !strcmp(a, "-lcpdist") ||
+               !strcmp(a, "-compressedoutput") || !strcmp(a, "-genomediff") ||
+               !strcmp(a, "-sortmaxdepth") || !strcmp(a, "-spmopt") ||
+               !strcmp(a, "-swallow-tail") || !strcmp(a, "-onlybucketinsertion")) {
+      /* these change what is written; not part of this path */
+      return fail(err, errlen, "option \"%s\" is not supported by the MI355X engine", a);
     } else if (!strcmp(a, "-des")) out_des = yesno(argc, argv, &i);
     else if (!strcmp(a, "-sds")) out_sds = yesno(argc, argv, &i);
     else if (!strcmp(a, "-md5")) out_md5 = yesno(argc, argv, &i);
@@ -225,6 +242,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return -1;
     }
     gtamd_encinfo_free(&info);
+    if (clipdesc) gtamd_clip_descriptions(desc, &desclen);
     if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
       free(desc); gtamd_encoder_destroy(de);
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);
@@ -255,6 +273,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     }
     gtamd_encinfo_free(&info);
     /* the sequence-side files describe the sequence as stored (before -dir) */
+    if (clipdesc) gtamd_clip_descriptions(desc, &desclen);
     if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
       free(enc); free(desc);
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);

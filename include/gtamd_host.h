@@ -118,6 +118,9 @@ void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
    every description but the last), src/core/encseq_charproc.gen:118-130,
    src/core/encseq.c:5613-5624.  INDEX.md5: per sequence the MD5 of its decoded
    upper-case symbols as 32 hex digits + NUL (encseq_charproc.gen:52-92). */
+/* -clipdesc (src/core/desc_buffer.c:63-80): cut every description of the
+   NUL-separated block at its first white space, in place */
+void gtamd_clip_descriptions(char *desc, uint64_t *desclen);
 int gtamd_write_des_sds(const char *indexname, const char *desc,
                         uint64_t desclen, int write_des, int write_sds);
 int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
@@ -144,9 +147,15 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
 /* `gt suffixerator` for the option subset of this path:
      -db FILE... | -ii INDEX  -indexname NAME  -dna | -protein
      -suf -lcp -bwt -bck  -suftabuint
-     -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored   and, accepted without
-     effect on the tables,
-     -parts N  -memlimit X  -dc V  -tis [yes|no]
+     -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored  -clipdesc  and, accepted
+     without effect on the tables (strategy knobs of the CPU algorithm),
+     -parts N  -memlimit X  -dc V  -algbds A B C  -maxwidthrealmedian W
+     -cmpcharbychar -dccheck -iterscan -kmerswithencseqreader -noshortreadsort
+     -samplewithprefixlengthnull -storespecialcodes -withradixsort
+     -showprogress -tis [yes|no];
+     -lossless -smap -sat -plain -kys -lcpdist -compressedoutput -genomediff
+     -sortmaxdepth -spmopt -swallow-tail -onlybucketinsertion change what is
+     written and are refused ("option \"-X\" is not supported ...").
    -des -sds -md5 -ssp [yes|no] select the sequence-side files; INDEX.esq is
    always written, as the reference does.
    argv[0] is the tool name.  Returns 0, or -1 with the message in err (the

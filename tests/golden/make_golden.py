@@ -69,6 +69,8 @@ BCK_FILES = [("Atinsert.fna", [0, 1, 2, 3, 7]), ("Duplicate.fna", [0, 1, 2, 5]),
              ("extra/long_runs.fna", [0, 8]), ("extra/lowercase_iupac.fna", [0, 3]),
              ("extra/protein_specials.faa", [0, 1, 2, 3]),
              ("extra/protein_long_x.faa", [0, 2, 3]), ("sw100K1.fsa", [0, 2])]
+CLIPDESC_FILES = ["Atinsert.fna", "Duplicate.fna", "extra/blanks.fna", "extra/crlf.fna",
+                  "test10_multiline.fastq", "Reads1.fna"]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -209,6 +211,20 @@ def main():
                     "prj": prj}
     with open(os.path.join(OUT, "golden_bck.json"), "w") as f:
         json.dump(bck, f, indent=1, sort_keys=True)
+    # -clipdesc: descriptions cut at the first white space
+    clip = {}
+    for name in CLIPDESC_FILES:
+        src = (os.path.join(OUT, name) if name.startswith("extra/")
+               else os.path.join(REF, "testdata", name))
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            subprocess.run([BIN, "-dna", "-clipdesc", "-indexname", idx, "-db",
+                            os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+            clip[name] = {ext: {"md5": md5(idx + "." + ext),
+                                "bytes": os.path.getsize(idx + "." + ext)}
+                          for ext in ("des", "sds")}
+    with open(os.path.join(OUT, "golden_clipdesc.json"), "w") as f:
+        json.dump(clip, f, indent=1, sort_keys=True)
     variants = {}
     for name in VARIANT_FILES:
         src = os.path.join(REF, "testdata", name)

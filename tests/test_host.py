@@ -436,3 +436,51 @@ def test_esq_reader_on_files_written_by_the_reference(host, stem, tmp_path):
     assert ss.totallength == enc.size
     assert ss.specialcharacters == int((enc >= 254).sum())
     assert ss.numofsequences == int((enc == 255).sum()) + 1
+
+
+CLIPDESC = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_clipdesc.json")))
+
+
+def _run_tool(host, *args, cwd=None):
+    argv = (ctypes.c_char_p * (len(args) + 1))(b"suffixerator", *[a.encode() for a in args])
+    err = ctypes.create_string_buffer(2048)
+    old = os.getcwd()
+    if cwd:
+        os.chdir(cwd)
+    try:
+        return host.gtamd_suffixerator(len(args) + 1, argv, err, 2048), err.value.decode()
+    finally:
+        os.chdir(old)
+
+
+@pytest.mark.parametrize("name", sorted(CLIPDESC))
+def test_tool_clipdesc_matches_reference(host, name, tmp_path):
+    """-clipdesc: INDEX.des/.sds with every description cut at its first
+    white space (src/core/desc_buffer.c:63-80)"""
+    import hashlib
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    assert _run_tool(host, "-dna", "-clipdesc", "-indexname", idx, "-db",
+                     os.path.basename(src), cwd=os.path.dirname(src)) == (0, "")
+    for ext in ("des", "sds"):
+        raw = open(idx + "." + ext, "rb").read()
+        assert len(raw) == CLIPDESC[name][ext]["bytes"], ext
+        assert hashlib.md5(raw).hexdigest() == CLIPDESC[name][ext]["md5"], ext
+
+
+def test_tool_strategy_switches_are_accepted_and_output_switches_refused(host, tmp_path):
+    """knobs of the reference's CPU algorithm do not change the files; options
+    that would change them and are not built fail loudly"""
+    src = ou.fixture_path("Atinsert.fna")
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    assert _run_tool(host, "-dna", "-indexname", a, "-db", src) == (0, "")
+    assert _run_tool(host, "-dna", "-indexname", b, "-db", src, "-cmpcharbychar", "-dc", "32",
+                     "-algbds", "3", "31", "80", "-maxwidthrealmedian", "1",
+                     "-noshortreadsort", "-storespecialcodes", "yes", "-withradixsort",
+                     "-iterscan", "no", "-parts", "2", "-memlimit", "1GB",
+                     "-showprogress", "no", "-dccheck") == (0, "")
+    assert open(a + ".prj").read() == open(b + ".prj").read()
+    for opt in ("-lossless", "-smap", "-sat", "-plain", "-kys", "-lcpdist",
+                "-compressedoutput", "-genomediff", "-sortmaxdepth", "-spmopt"):
+        rc, msg = _run_tool(host, "-dna", "-indexname", a, "-db", src, opt)
+        assert rc == -1 and msg == 'option "%s" is not supported by the MI355X engine' % opt

@@ -108,22 +108,27 @@ done:
 int gtamd_write_esq_device(const char *indexname, const char *const *paths,
                            size_t numfiles, const gtamd_encoder *enc,
                            int protein, const gtamd_encinfo *info, int write_ssp,
-                           gtamd_seqstats *ss, char *err, size_t errlen)
+                           const char *sat, gtamd_seqstats *ss, char *err, size_t errlen)
 {
   gtamd_encode_summary sum;
   gtamd_seqanalysis an;
   gtamd_esq_sections sec;
   uint64_t *twobit = NULL, *specialbits = NULL, *wc_start = NULL, *wc_len = NULL,
            *seppos = NULL, n;
-  uint8_t *packed = NULL;
+  uint8_t *packed = NULL, *plain = NULL;
   int rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
   if (gtamd_encoder_get_summary(enc, &sum) != 0) goto deverr;
   gtamd_analysis_from_summary(&sum, protein ? 20 : 4, &an);
+  if (gtamd_force_sat(&an, sat, protein, err, errlen) != 0) return -1;
   if (ss != NULL) *ss = an.ss;
   n = an.ss.totallength;
   gtamd_esq_needs(&an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
   memset(&sec, 0, sizeof sec);
+  if (an.sat == GTAMD_SAT_DIRECTACCESS) {
+    if ((plain = malloc(n ? n : 1)) == NULL) goto nomem;
+    if (gtamd_encoder_copy_symbols(enc, plain, 0, n) != 0) goto deverr;
+  }
   if (need_pk) {
     if ((packed = malloc((5 * n + 7) / 8 + 1)) == NULL) goto nomem;
     if (gtamd_encoder_pack_bytecompress(enc, packed) != 0) goto deverr;
@@ -148,6 +153,7 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
     if (gtamd_encoder_get_separators(enc, seppos) != 0) goto deverr;
   }
   sec.twobit = twobit; sec.specialbits = specialbits; sec.packed = packed;
+  sec.plain = plain;
   sec.wc_start = wc_start; sec.wc_len = wc_len; sec.wc_runs = sum.realwildcardranges;
   sec.seppos = seppos;
   rc = gtamd_write_esq_sections(indexname, paths, numfiles, protein, &an, info,
@@ -159,6 +165,7 @@ deverr:
 nomem:
   snprintf(err, errlen, "out of memory while writing the encoded sequence");
 done:
-  free(twobit); free(specialbits); free(packed); free(wc_start); free(wc_len); free(seppos);
+  free(twobit); free(specialbits); free(packed); free(plain); free(wc_start); free(wc_len);
+  free(seppos);
   return rc;
 }

@@ -630,23 +630,60 @@ void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
   st->lengthofspecialprefix = sp.prefix; st->lengthofspecialsuffix = sp.suffix;
   st->wildcards = wc.chars; st->realwildcardranges = wc.runs;
   st->lengthofwildcardprefix = wc.prefix; st->lengthofwildcardsuffix = wc.suffix;
-  gtamd_choose_access_type(an, sp.tab, wc.tab);
+  for (int k = 0; k < 3; k++) { an->sp_tab[k] = sp.tab[k]; an->wc_tab[k] = wc.tab[k]; }
+  (void) gtamd_choose_access_type(an, sp.tab, wc.tab, -1);
 }
 
-void gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
-                              const uint64_t wc_tab[3])
+int gtamd_parse_sat(const char *name, int protein, int *sat, char *err, size_t errlen)
+{
+  static const char *const names[7] = {"direct", "bytecompress", "eqlen", "bit", "uchar",
+                                       "ushort", "uint32"};
+  *sat = -1;
+  for (int k = 0; k < 7; k++) if (!strcmp(name, names[k])) *sat = k;
+  if (*sat < 0) {
+    /* src/core/encseq.c:797-807 */
+    snprintf(err, errlen, "Illegal argument \"%s\" to option -sat; must be one of the "
+             "following keywords: direct, bytecompress, eqlen, bit, uchar, ushort, uint32", name);
+    return -1;
+  }
+  /* src/core/encseq_access_type.c:163-221 */
+  if (!protein && *sat == GTAMD_SAT_BYTECOMPRESS) {
+    snprintf(err, errlen, "illegal argument \"%s\" to option -sat: cannot use bytecompress "
+             "on DNA sequences", name);
+    return -1;
+  }
+  if (protein && *sat != GTAMD_SAT_BYTECOMPRESS && *sat != GTAMD_SAT_DIRECTACCESS) {
+    snprintf(err, errlen, "illegal argument \"%s\" to option -sat: as the sequence is not "
+             "DNA, you can choose bytecompress or direct", name);
+    return -1;
+  }
+  return 0;
+}
+
+int gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
+                             const uint64_t wc_tab[3], int forced_sat)
 {
   gtamd_seqstats *st = &an->ss;
   const uint64_t n = st->totallength, nsep = st->numofsequences - 1;
   uint64_t best = 0;
   /* the "ranges" numbers are those of the smallest of the three table
-     representations, whatever access type is used in the end
-     (src/core/encseq.c:5215-5256, sizes encseq.c:924-949) */
+     representations, whatever access type is used in the end -- or of the
+     table type -sat asks for (src/core/encseq.c:5215-5256, :797-814; sizes
+     encseq.c:924-949) */
+  const int forcetable = forced_sat >= GTAMD_SAT_UCHARTABLES ? forced_sat - GTAMD_SAT_UCHARTABLES : 3;
   for (int k = 0; k < 3; k++) {
     const uint64_t size = gtamd_swtable_bytes(k, 1, n, wc_tab[k]);
-    if (k == 0 || size < best) {
+    if (forcetable != 3 && k != forcetable) continue;
+    if (k == 0 || forcetable == k || size < best) {
       best = size; st->specialranges = sp_tab[k]; st->wildcardranges = wc_tab[k];
     }
+  }
+  if (forced_sat >= 0) {
+    /* -sat: src/core/encseq_access_type.c:163-221 */
+    if (forced_sat == GTAMD_SAT_EQUALLENGTH && !an->equallength) return -1;
+    an->sat = forced_sat;
+    an->sat_wildcardranges = forcetable != 3 ? wc_tab[forcetable] : wc_tab[0];
+    return 0;
   }
   /* access type: non-DNA alphabets are bit-packed; DNA takes the smallest of
      bit access and the three table types, or "equal length" when all sequences
@@ -666,6 +703,7 @@ void gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
       }
     }
   }
+  return 0;
 }
 
 void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofchars,
@@ -686,7 +724,10 @@ void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofch
   an->equallength = s->equallength != 0;
   an->equallength_value = an->equallength ? s->maxseqlen : 0;
   for (int c = 0; c < 32; c++) an->chardist[c] = s->characterdistribution[c];
-  gtamd_choose_access_type(an, s->specialrangestab, s->wildcardrangestab);
+  for (int k = 0; k < 3; k++) {
+    an->sp_tab[k] = s->specialrangestab[k]; an->wc_tab[k] = s->wildcardrangestab[k];
+  }
+  (void) gtamd_choose_access_type(an, s->specialrangestab, s->wildcardrangestab, -1);
 }
 
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,

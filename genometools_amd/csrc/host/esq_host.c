@@ -147,6 +147,22 @@ unsigned gtamd_least_probable(const gtamd_seqanalysis *an)
   return least;
 }
 
+int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int protein, char *err,
+                    size_t errlen)
+{
+  int sat;
+  if (satname == NULL) return 0;
+  if (gtamd_parse_sat(satname, protein, &sat, err, errlen) != 0) return -1;
+  if (gtamd_choose_access_type(an, an->sp_tab, an->wc_tab, sat) != 0) {
+    /* src/core/encseq_access_type.c:185-193 */
+    snprintf(err, errlen, "illegal argument \"%s\" to option -sat: %s is only possible for "
+             "DNA sequences, if all sequences are of equal length and no sequence contains "
+             "a wildcard", satname, satname);
+    return -1;
+  }
+  return 0;
+}
+
 void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
                      int *specialbits, int *packed, int *wildcardruns,
                      int *separators)
@@ -154,7 +170,7 @@ void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
   const uint64_t numsep = an->ss.numofsequences - 1;
   const int viatables = an->sat >= GTAMD_SAT_UCHARTABLES;
   *packed = an->sat == GTAMD_SAT_BYTECOMPRESS;
-  *twobit = !*packed;
+  *twobit = an->sat >= GTAMD_SAT_EQUALLENGTH;
   *specialbits = an->sat == GTAMD_SAT_BITACCESS && (an->sat_wildcardranges > 0 || numsep > 0);
   *wildcardruns = viatables && an->sat_wildcardranges > 0;
   /* the separator table exists for table access types and on request */
@@ -182,7 +198,8 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
     return -1;
   }
   gtamd_esq_needs(an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
-  if ((need_tb && sec->twobit == NULL) || (need_sb && sec->specialbits == NULL) ||
+  if ((an->sat == GTAMD_SAT_DIRECTACCESS && sec->plain == NULL && n > 0) ||
+      (need_tb && sec->twobit == NULL) || (need_sb && sec->specialbits == NULL) ||
       (need_pk && sec->packed == NULL) || (need_wc && sec->wc_start == NULL) ||
       (need_sep && sec->seppos == NULL)) {
     snprintf(err, errlen, "sequence sections of the encoded sequence are missing");
@@ -243,7 +260,8 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
     put(&o, info->filelengthtab, sizeof (gtamd_filelength) * numfiles);
     put(&o, an->chardist, sizeof (uint64_t) * numofchars);
   }
-  if (need_pk) put(&o, sec->packed, (5 * n + 7) / 8);
+  if (an->sat == GTAMD_SAT_DIRECTACCESS) put(&o, sec->plain, n);
+  else if (need_pk) put(&o, sec->packed, (5 * n + 7) / 8);
   else {
     put(&o, sec->twobit, sizeof (uint64_t) * (n < 32 ? 2 : 2 + (n - 1) / 32));
     if (need_sb) put(&o, sec->specialbits, sizeof (uint64_t) * (1 + (n + 63) / 64));
@@ -283,11 +301,20 @@ done:
   return rc;
 }
 
-/* the sequence sections by host loops over the symbols */
 int gtamd_write_esq(const char *indexname, const char *const *paths,
                     size_t numfiles, const uint8_t *enc, uint64_t n,
                     int protein, const gtamd_encinfo *info, int write_ssp,
                     char *err, size_t errlen)
+{
+  return gtamd_write_esq_sat(indexname, paths, numfiles, enc, n, protein, info, write_ssp,
+                             NULL, NULL, err, errlen);
+}
+
+/* the sequence sections by host loops over the symbols */
+int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
+                        size_t numfiles, const uint8_t *enc, uint64_t n,
+                        int protein, const gtamd_encinfo *info, int write_ssp,
+                        const char *sat, gtamd_seqstats *ss, char *err, size_t errlen)
 {
   const uint32_t numofchars = protein ? 20 : 4;
   gtamd_seqanalysis an;
@@ -299,9 +326,12 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
   int rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
   gtamd_analyse_sequence(enc, n, numofchars, &an);
+  if (gtamd_force_sat(&an, sat, protein, err, errlen) != 0) return -1;
+  if (ss != NULL) *ss = an.ss;
   gtamd_esq_needs(&an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
   least = gtamd_least_probable(&an);
   memset(&sec, 0, sizeof sec);
+  sec.plain = enc;
   if (need_pk && (packed = calloc((5 * n + 7) / 8 + 1, 1)) == NULL) goto nomem;
   if (need_tb && (twobit = calloc(n < 32 ? 2 : 2 + (n - 1) / 32, 8)) == NULL) goto nomem;
   if (need_sb) {
@@ -322,6 +352,7 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
       else { wc_start[nwc] = pos; wc_len[nwc++] = 1; }
     }
     if (need_sep && c == GTAMD_SEPARATOR) seppos[nsep++] = pos;
+    if (twobit == NULL && packed == NULL) continue;      /* direct access */
     if (packed != NULL) {
       /* 5 bits per symbol, most significant bit first; wildcard and separator
          are the two codes behind the alphabet */

@@ -20,6 +20,7 @@ typedef struct {
   uint64_t equallength_value;
   int sat;                        /* access type the reference would choose */
   uint64_t sat_wildcardranges;    /* stored wildcard ranges for that type */
+  uint64_t sp_tab[3], wc_tab[3];  /* stored ranges per table width */
 } gtamd_seqanalysis;
 
 void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
@@ -31,6 +32,7 @@ void gtamd_analyse_sequence(const uint8_t *enc, uint64_t n, uint32_t numofchars,
 typedef struct {
   const uint64_t *twobit, *specialbits;
   const uint8_t *packed;
+  const uint8_t *plain;           /* direct access: the symbols themselves */
   const uint64_t *wc_start, *wc_len;
   uint64_t wc_runs;
   const uint64_t *seppos;
@@ -38,7 +40,7 @@ typedef struct {
 
 void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
                      int *specialbits, int *packed, int *wildcardruns,
-                     int *separators);
+                     int *separators);   /* direct access: none of the first three */
 /* code that stands in for specials in the two-bit encoding of the equal-length
    and table access types (src/core/encseq.c:4468-4485) */
 unsigned gtamd_least_probable(const gtamd_seqanalysis *an);
@@ -58,8 +60,15 @@ void gtamd_symbolmap(uint8_t map[256], int protein);
 
 /* stored-range counts and access type from the range counts per table width;
    needs ss.totallength/numofsequences/numofchars and equallength set */
-void gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
-                              const uint64_t wc_tab[3]);
+int gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
+                             const uint64_t wc_tab[3], int forced_sat);
+/* -sat NAME -> access type number; the alphabet-dependent checks and messages
+   of src/core/encseq.c:797-807, encseq_access_type.c:163-221 */
+int gtamd_parse_sat(const char *name, int protein, int *sat, char *err, size_t errlen);
+/* apply a forced access type (-sat) to a finished analysis; -1 with the
+   reference's message when "eqlen" does not fit the sequences */
+int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int protein, char *err,
+                    size_t errlen);
 /* the same analysis from the device encoder's summary */
 void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofchars,
                                  gtamd_seqanalysis *an);

@@ -107,7 +107,7 @@ static int yesno(int argc, const char **argv, int *i)
 
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
 {
-  const char *db[MAXDB], *indexname = NULL, *inputindex = NULL;
+  const char *db[MAXDB], *indexname = NULL, *inputindex = NULL, *sat = NULL;
   size_t numdb = 0;
   int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0,
       out_des = 1, out_sds = 1, out_md5 = 1, out_ssp = 1;   /* defaults of encseq_options.c */
@@ -174,7 +174,10 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       (void) yesno(argc, argv, &i);        /* more strategy switches, same tables */
     } else if (!strcmp(a, "-clipdesc")) {
       clipdesc = yesno(argc, argv, &i);
-    } else if (!strcmp(a, "-lossless") || !strcmp(a, "-smap") || !strcmp(a, "-sat") ||
+    } else if (!strcmp(a, "-sat")) {
+      if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "sat");
+      sat = argv[++i];
+    } else if (!strcmp(a, "-lossless") || !strcmp(a, "-smap") ||
                !strcmp(a, "-plain") || !strcmp(a, "-kys") || !strcmp(a, "-lcpdist") ||
                !strcmp(a, "-compressedoutput") || !strcmp(a, "-genomediff") ||
                !strcmp(a, "-sortmaxdepth") || !strcmp(a, "-spmopt") ||
@@ -201,9 +204,9 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     return fail(err, errlen, "either option \"-db\" or option \"-%s\" is mandatory", "ii");
   if (dna && protein)
     return fail(err, errlen, "option \"-dna\" and option \"-%s\" exclude each other", "protein");
-  if (inputindex != NULL && (numdb > 0 || dna || protein))
+  if (inputindex != NULL && (numdb > 0 || dna || protein || sat != NULL))
     return fail(err, errlen, "option \"-%s\" and option \"-ii\" exclude each other",
-                numdb > 0 ? "db" : dna ? "dna" : "protein");
+                numdb > 0 ? "db" : dna ? "dna" : protein ? "protein" : "sat");
   if (indexname == NULL && inputindex != NULL) {
     const char *base = strrchr(inputindex, '/');
     snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : inputindex);
@@ -237,7 +240,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     if (gtamd_device_encode_files(db, numdb, protein, &de, &desc, &desclen, &info, err, errlen) != 0)
       return -1;
     n = gtamd_encoder_length(de);
-    if (gtamd_write_esq_device(indexname, db, numdb, de, protein, &info, out_ssp, &ss, err, errlen) != 0) {
+    if (gtamd_write_esq_device(indexname, db, numdb, de, protein, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
       return -1;
     }
@@ -267,7 +270,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return -1;
     /* the encoded sequence itself, in the reference's format (always written:
        -tis is kept for backwards compatibility only, src/match/sfx-opt.c) */
-    if (gtamd_write_esq(indexname, db, numdb, enc, n, protein, &info, out_ssp, err, errlen) != 0) {
+    if (gtamd_write_esq_sat(indexname, db, numdb, enc, n, protein, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(enc); free(desc); gtamd_encinfo_free(&info);
       return -1;
     }
@@ -283,8 +286,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       free(enc);
       return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
     }
-    /* .prj describes the sequence as stored, the tables the sequence as read */
-    gtamd_sequence_stats(enc, n, protein ? 20 : 4, &ss);
+    /* (.prj describes the sequence as stored, the tables the sequence as read) */
   }
   if (mirrored) {
     uint8_t *m = gtamd_mirror(enc, n);

@@ -98,7 +98,7 @@ int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
 int gtamd_write_esq_device(const char *indexname, const char *const *paths,
                            size_t numfiles, const gtamd_encoder *enc,
                            int protein, const gtamd_encinfo *info, int write_ssp,
-                           gtamd_seqstats *ss, char *err, size_t errlen);
+                           const char *sat, gtamd_seqstats *ss, char *err, size_t errlen);
 
 /* The way back (option -ii, src/match/sfx-run.c:454-493 /
    gt_encseq_loader_load): the symbols of an existing INDEX.esq, written by
@@ -109,6 +109,16 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
    sequence statistics stored in the header. */
 int gtamd_read_esq(const char *indexname, uint8_t **enc, uint64_t *n,
                    int *protein, gtamd_seqstats *ss, char *err, size_t errlen);
+
+/* The same with the access type forced (-sat direct|bytecompress|eqlen|bit|
+   uchar|ushort|uint32; NULL: the reference's choice) and the sequence
+   statistics -- whose stored-range counts follow the forced table type --
+   returned in *ss (may be NULL).  Errors of src/core/encseq.c:797-807 and
+   src/core/encseq_access_type.c:163-221 with their wording. */
+int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
+                        size_t numfiles, const uint8_t *enc, uint64_t n,
+                        int protein, const gtamd_encinfo *info, int write_ssp,
+                        const char *sat, gtamd_seqstats *ss, char *err, size_t errlen);
 
 void gtamd_sequence_stats(const uint8_t *enc, uint64_t n, uint32_t numofchars,
                           gtamd_seqstats *st);
@@ -146,14 +156,14 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
 
 /* `gt suffixerator` for the option subset of this path:
      -db FILE... | -ii INDEX  -indexname NAME  -dna | -protein
-     -suf -lcp -bwt -bck  -suftabuint
+     -suf -lcp -bwt -bck  -suftabuint  -sat TYPE
      -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored  -clipdesc  and, accepted
      without effect on the tables (strategy knobs of the CPU algorithm),
      -parts N  -memlimit X  -dc V  -algbds A B C  -maxwidthrealmedian W
      -cmpcharbychar -dccheck -iterscan -kmerswithencseqreader -noshortreadsort
      -samplewithprefixlengthnull -storespecialcodes -withradixsort
      -showprogress -tis [yes|no];
-     -lossless -smap -sat -plain -kys -lcpdist -compressedoutput -genomediff
+     -lossless -smap -plain -kys -lcpdist -compressedoutput -genomediff
      -sortmaxdepth -spmopt -swallow-tail -onlybucketinsertion change what is
      written and are refused ("option \"-X\" is not supported ...").
    -des -sds -md5 -ssp [yes|no] select the sequence-side files; INDEX.esq is

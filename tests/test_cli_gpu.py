@@ -195,3 +195,25 @@ def test_cli_bucket_table_and_32bit_suffix_table(cli, key, tmp_path):
         assert hashlib.md5(raw).hexdigest() == e[key2]["md5"], ext
     with open(idx + ".prj") as f:
         assert f.read() == e["prj"]
+
+
+ESQ_DIR = os.path.join(ou.GOLDEN_DIR, "esq")
+
+
+@pytest.mark.parametrize("stem", sorted(f[:-4] for f in os.listdir(ESQ_DIR) if f.endswith(".esq")))
+def test_cli_forced_access_type(cli, stem, tmp_path):
+    """-sat TYPE through the device reader: INDEX.esq/.ssp as the reference
+    writes them with that access type (tests/golden/esq/), same tables"""
+    name, sat = stem.rsplit(".", 1)
+    key = name if name in GOLDEN else "extra/" + name
+    src = ou.fixture_path(key)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-" + GOLDEN[key]["alphabet"], "-suf", "-sat", sat, "-indexname", idx,
+                    "-db", os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+    for ext in ("esq", "ssp"):
+        ref = os.path.join(ESQ_DIR, "%s.%s" % (stem, ext))
+        assert os.path.exists(ref) == os.path.exists(idx + "." + ext), ext
+        if os.path.exists(ref):
+            assert open(idx + "." + ext, "rb").read() == open(ref, "rb").read(), ext
+    with open(idx + ".suf", "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == GOLDEN[key]["tables"]["suf"]["md5"]

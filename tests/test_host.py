@@ -56,6 +56,11 @@ def host():
                                   ctypes.c_size_t, P, ctypes.c_uint64, ctypes.c_int,
                                   ctypes.POINTER(EncInfo), ctypes.c_int, ctypes.c_char_p,
                                   ctypes.c_size_t]
+    L.gtamd_write_esq_sat.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p),
+                                      ctypes.c_size_t, P, ctypes.c_uint64, ctypes.c_int,
+                                      ctypes.POINTER(EncInfo), ctypes.c_int, ctypes.c_char_p,
+                                      ctypes.POINTER(SeqStats), ctypes.c_char_p,
+                                      ctypes.c_size_t]
     L.gtamd_read_esq.argtypes = [ctypes.c_char_p, ctypes.POINTER(P),
                                  ctypes.POINTER(ctypes.c_uint64),
                                  ctypes.POINTER(ctypes.c_int), ctypes.POINTER(SeqStats),
@@ -480,7 +485,64 @@ def test_tool_strategy_switches_are_accepted_and_output_switches_refused(host, t
                      "-iterscan", "no", "-parts", "2", "-memlimit", "1GB",
                      "-showprogress", "no", "-dccheck") == (0, "")
     assert open(a + ".prj").read() == open(b + ".prj").read()
-    for opt in ("-lossless", "-smap", "-sat", "-plain", "-kys", "-lcpdist",
+    for opt in ("-lossless", "-smap", "-plain", "-kys", "-lcpdist",
                 "-compressedoutput", "-genomediff", "-sortmaxdepth", "-spmopt"):
         rc, msg = _run_tool(host, "-dna", "-indexname", a, "-db", src, opt)
         assert rc == -1 and msg == 'option "%s" is not supported by the MI355X engine' % opt
+
+
+def _write_esq_forced(host, path, protein, idx, sat):
+    arr = (ctypes.c_char_p * 1)(path.encode())
+    names = (ctypes.c_char_p * 1)(os.path.basename(path).encode())
+    ptr, n = ctypes.c_void_p(), ctypes.c_uint64()
+    dptr, dlen = ctypes.c_void_p(), ctypes.c_uint64()
+    info, ss = EncInfo(), SeqStats()
+    err = ctypes.create_string_buffer(2048)
+    assert host.gtamd_encode_files_info(arr, 1, int(protein), ctypes.byref(ptr), ctypes.byref(n),
+                                        ctypes.byref(dptr), ctypes.byref(dlen),
+                                        ctypes.byref(info), err, 2048) == 0, err.value
+    rc = host.gtamd_write_esq_sat(idx.encode(), names, 1, ptr, n.value, int(protein),
+                                  ctypes.byref(info), 1, sat.encode(), ctypes.byref(ss),
+                                  err, 2048)
+    host.gtamd_encinfo_free(ctypes.byref(info))
+    libc = ctypes.CDLL(None)
+    libc.free(ptr)
+    libc.free(dptr)
+    return rc, err.value.decode(), ss
+
+
+@pytest.mark.parametrize("stem", REF_ESQ)
+def test_forced_access_type_matches_reference(host, stem, tmp_path):
+    """-sat TYPE: INDEX.esq / INDEX.ssp byte for byte as the reference writes
+    them with that access type forced (tests/golden/esq/)"""
+    name, sat = stem.rsplit(".", 1)
+    fixture = ou.fixture_path(name if name in GOLDEN else "extra/" + name)
+    idx = str(tmp_path / "idx")
+    rc, msg, ss = _write_esq_forced(host, fixture, name.endswith(".faa"), idx, sat)
+    assert rc == 0, msg
+    for ext in ("esq", "ssp"):
+        ref = os.path.join(ESQ_DIR, "%s.%s" % (stem, ext))
+        assert os.path.exists(ref) == os.path.exists(idx + "." + ext), ext
+        if os.path.exists(ref):
+            assert open(idx + "." + ext, "rb").read() == open(ref, "rb").read(), ext
+    # the statistics follow the forced table width (they are in the header too)
+    hdr = np.frombuffer(open(idx + ".esq", "rb").read(168), dtype="<u8")
+    assert (ss.specialranges, ss.wildcardranges) == (int(hdr[8]), int(hdr[13]))
+
+
+def test_forced_access_type_errors_use_the_reference_wording(host, tmp_path):
+    idx = str(tmp_path / "idx")
+    dna, prot = ou.fixture_path("Atinsert.fna"), ou.fixture_path("extra/protein_specials.faa")
+    rc, msg, _ = _write_esq_forced(host, dna, False, idx, "fast")
+    assert rc == -1 and msg == ('Illegal argument "fast" to option -sat; must be one of the '
+                                'following keywords: direct, bytecompress, eqlen, bit, uchar, '
+                                'ushort, uint32')
+    rc, msg, _ = _write_esq_forced(host, dna, False, idx, "bytecompress")
+    assert rc == -1 and msg == ('illegal argument "bytecompress" to option -sat: cannot use '
+                                'bytecompress on DNA sequences')
+    rc, msg, _ = _write_esq_forced(host, dna, False, idx, "eqlen")
+    assert rc == -1 and msg.startswith('illegal argument "eqlen" to option -sat: eqlen is only '
+                                       'possible for DNA sequences, if all sequences are of equal')
+    rc, msg, _ = _write_esq_forced(host, prot, True, idx, "bit")
+    assert rc == -1 and msg == ('illegal argument "bit" to option -sat: as the sequence is not '
+                                'DNA, you can choose bytecompress or direct')

@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Differential fuzzing on the GPU box: random structured sequences (repeats,
+tandem repeats, special runs, separators; DNA and protein) through
+  * the engine (all tables + bucket table, random prefix length),
+  * a part build with 2..5 parts (thread transport on one device),
+  * the device FASTA reader (random line widths, CRLF, blank lines),
+each compared with the CPU oracle / host reader.  Dev tool; stops at the first
+difference and prints the seed.
+
+  python tools/fuzz_gpu.py --seconds 300 [--seed 1]
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_util as ou  # noqa: E402
+import thread_comm  # noqa: E402
+from genometools_amd import encode, esa  # noqa: E402
+
+
+def random_sequence(rng, sigma):
+    n = int(rng.choice([1, 2, 3, 17, 64, 255, 256, 257, 1000, 4096, 4097, 9000, 20000]))
+    n = max(1, int(n * rng.uniform(0.5, 1.0)))
+    kind = rng.integers(0, 4)
+    if kind == 0:                       # low entropy: few letters
+        enc = rng.integers(0, min(sigma, rng.integers(1, 3) + 1), size=n).astype(np.uint8)
+    else:
+        enc = rng.integers(0, sigma, size=n).astype(np.uint8)
+    # copies of earlier stretches (long LCPs, big tie groups)
+    for _ in range(int(rng.integers(0, 8))):
+        if n < 8:
+            break
+        length = int(rng.integers(2, max(3, min(n // 2, 4000))))
+        src = int(rng.integers(0, n - length + 1))
+        dst = int(rng.integers(0, n - length + 1))
+        enc[dst:dst + length] = enc[src:src + length].copy()
+    # tandem repeats
+    for _ in range(int(rng.integers(0, 4))):
+        period = int(rng.integers(1, 7))
+        length = int(rng.integers(period, max(period + 1, min(n, 3000))))
+        at = int(rng.integers(0, max(1, n - length)))
+        unit = rng.integers(0, sigma, size=period).astype(np.uint8)
+        enc[at:at + length] = np.resize(unit, length)[:len(enc[at:at + length])]
+    # wildcard runs and separators (never an empty sequence)
+    for _ in range(int(rng.integers(0, 6))):
+        length = int(rng.choice([1, 1, 2, 5, 40, 300, 700]))
+        at = int(rng.integers(0, n))
+        enc[at:at + length] = 254
+    nsep = int(rng.integers(0, 6))
+    for at in rng.integers(1, max(2, n - 1), size=nsep):
+        at = int(at)
+        if 0 < at < n - 1 and enc[at - 1] != 255 and enc[at + 1] != 255:
+            enc[at] = 255
+    if enc[0] == 255:
+        enc[0] = 0
+    if enc[-1] == 255:
+        enc[-1] = 0
+    return enc
+
+
+def check_engine(rng, enc, sigma):
+    ora = ou.esa(enc, sigma)
+    with esa.EsaEngine(enc.size, sigma) as eng:
+        eng.set_sequence(enc)
+        kmax = 8 if sigma == 4 else 3
+        k = int(rng.integers(0, kmax + 1))
+        eng.set_prefixlength(k)
+        eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT | esa.WANT_BCK)
+        res = eng.result()
+        for name in ("suf", "lcp", "llv", "bwt"):
+            assert np.array_equal(getattr(res, name), ora[name]), name
+        kk = res.stats["prefixlength"]
+        for got, want in zip(eng.bcktab(), ou.bcktab(enc, sigma, kk)):
+            assert np.array_equal(got, want), "bck k=%d" % kk
+        assert res.stats["longest"] == ora["stats"]["longest"]
+        assert res.stats["largelcpvalues"] == ora["stats"]["largelcpvalues"]
+        assert res.stats["maxbranchdepth"] == ora["stats"]["maxbranchdepth"]
+    return ora
+
+
+def check_parts(rng, enc, sigma, ora):
+    parts = int(rng.integers(2, 6))
+    tabs = thread_comm.build_in_parts(enc, sigma, parts)[0]
+    for name in ("suf", "lcp", "llv", "bwt"):
+        assert np.array_equal(tabs[name], ora[name]), "parts=%d %s" % (parts, name)
+
+
+def check_encoder(rng, enc, sigma, tmp):
+    protein = sigma == 20
+    letters = b"LVIFKREDAGSTNQYWPHMC" if protein else b"ACGT"
+    wild = b"XUBZJO*-" if protein else b"NSYWRKVBDHM"
+    path = os.path.join(tmp, "f.fa")
+    eol = b"\r\n" if rng.integers(0, 4) == 0 else b"\n"
+    with open(path, "wb") as f:
+        start = 0
+        cuts = list(np.flatnonzero(enc == 255)) + [enc.size]
+        for i, end in enumerate(cuts):
+            f.write(b">seq%d some text\t%d" % (i, int(rng.integers(0, 1000))) + eol)
+            seq = enc[start:end]
+            txt = bytearray(len(seq))
+            for j, c in enumerate(seq):
+                ch = wild[int(rng.integers(0, len(wild)))] if c == 254 else letters[c]
+                if not protein and rng.integers(0, 3) == 0:
+                    ch = ord(chr(ch).lower())
+                txt[j] = ch
+            width = int(rng.choice([1, 7, 60, 70, 4095, 4096, 100000]))
+            for a in range(0, len(txt), width):
+                f.write(bytes(txt[a:a + width]) + eol)
+                if rng.integers(0, 20) == 0:
+                    f.write(eol)
+            start = end + 1
+    want = ou.encode_fasta(path, protein)
+    assert np.array_equal(want, enc), "fuzzer wrote a FASTA that does not decode back"
+    with encode.DeviceEncoder(protein=protein) as de:
+        de.encode([path])
+        assert np.array_equal(de.symbols(), enc), "device reader symbols"
+        s = de.summary()
+        st = ou.seqstats(enc, sigma)
+        for k in ("specialcharacters", "realspecialranges", "wildcards", "realwildcardranges",
+                  "lengthofspecialprefix", "lengthofspecialsuffix", "numofsequences"):
+            assert s[k] == st[k], k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    t0, case = time.time(), 0
+    with tempfile.TemporaryDirectory() as tmp:
+        while time.time() - t0 < a.seconds:
+            seed = a.seed * 1000003 + case
+            rng = np.random.default_rng(seed)
+            sigma = 20 if rng.integers(0, 4) == 0 else 4
+            enc = random_sequence(rng, sigma)
+            try:
+                ora = check_engine(rng, enc, sigma)
+                if case % 3 == 0:
+                    check_parts(rng, enc, sigma, ora)
+                if enc.size <= 20000 and case % 2 == 0:
+                    check_encoder(rng, enc, sigma, tmp)
+            except Exception:
+                print("FAILED: seed %d case %d sigma %d n %d" % (seed, case, sigma, enc.size),
+                      flush=True)
+                np.save(os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d.npy" % seed), enc)
+                raise
+            case += 1
+            if case % 50 == 0:
+                print("%d cases, %.0f s" % (case, time.time() - t0), flush=True)
+    print("fuzz ok: %d cases in %.0f s" % (case, time.time() - t0))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

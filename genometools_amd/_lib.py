@@ -109,6 +109,7 @@ ABI = {
     "gtamd_synth_bytes": (_INT, [_INT, _INT, _U64, _U64, _P]),
     # include/gtamd_encode.h
     "gtamd_encoder_create": (_P, [_INT, _INT]),
+    "gtamd_encoder_create_map": (_P, [_INT, _P, _U32, ctypes.c_uint]),
     "gtamd_encoder_destroy": (None, [_P]),
     "gtamd_encoder_add_file": (_INT, [_P, ctypes.c_char_p, _P, _U64]),
     "gtamd_encoder_finish": (_INT, [_P]),

@@ -445,7 +445,9 @@ template <typename T> int dev_alloc(T **p, u64 count) {
 
 struct gtamd_encoder {
   int device;
-  bool protein, finished;
+  bool finished;
+  u8 lut[256];             // code per input byte, LUT_UNDEF, LUT_BLANK
+  u32 sigma, packbits;     // alphabet size; bits per symbol of the bit packing
   std::vector<InputFile> files;
   hipStream_t st;
   hipEvent_t ev[4];
@@ -467,14 +469,36 @@ static void enc_free(gtamd_encoder *e) {
 }
 
 extern "C" gtamd_encoder *gtamd_encoder_create(int device, int protein) {
+  u8 lut[256];
+  build_lut(lut, protein != 0);
+  for (int c = 0; c < 256; c++) if (lut[c] == LUT_BLANK) lut[c] = LUT_UNDEF;
+  return gtamd_encoder_create_map(device, lut, protein ? 20 : 4, protein ? 5 : 3);
+}
+
+extern "C" gtamd_encoder *gtamd_encoder_create_map(int device, const uint8_t *symbolmap,
+                                                   uint32_t numofchars,
+                                                   unsigned bitspersymbol) {
   int count = 0;
+  if (symbolmap == nullptr || numofchars < 1 || numofchars > 32 || bitspersymbol < 1 ||
+      bitspersymbol > 8) {
+    gtamd_set_error("invalid alphabet for the device encoder (%u letters, %u bits)",
+                    numofchars, bitspersymbol);
+    return nullptr;
+  }
   if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) {
     gtamd_set_error("no HIP device %d available (this library has no CPU fallback)",
                     device);
     return nullptr;
   }
   gtamd_encoder *e = new gtamd_encoder();
-  e->device = device; e->protein = protein != 0; e->finished = false;
+  e->device = device; e->finished = false;
+  e->sigma = numofchars; e->packbits = bitspersymbol;
+  for (int c = 0; c < 256; c++) {
+    const u8 v = symbolmap[c];
+    e->lut[c] = v < numofchars || v == GTAMD_WILDCARD ? v : LUT_UNDEF;
+  }
+  // isspace() of the C locale is skipped between symbols
+  e->lut[' '] = e->lut['\t'] = e->lut['\n'] = e->lut['\r'] = e->lut['\v'] = e->lut['\f'] = LUT_BLANK;
   e->d_enc = nullptr; e->d_desc_start = e->d_desc_end = nullptr;
   e->n = e->cap_enc = e->ndesc = e->cap_desc = 0;
   e->total_ms = e->parse_ms = e->stats_ms = 0; e->input_bytes = 0;
@@ -711,10 +735,10 @@ extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
   memset(&e->sum, 0, sizeof e->sum);
   e->input_bytes = total;
   const u64 max_tiles = div_up(longest, EN_TILE) + 1;
-  u8 lut[256], *d_raw = nullptr, *d_lut = nullptr;
+  u8 *d_raw = nullptr, *d_lut = nullptr;
+  const u8 *lut = e->lut;
   u32 *d_tile = nullptr, *d_ws = nullptr;
   FaGlobals *d_glob = nullptr;
-  build_lut(lut, e->protein);
   int rc = -1;
   do {
     if (dev_alloc(&e->d_enc, total + EN_TILE) != 0) break;
@@ -890,8 +914,8 @@ extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *
 extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *bytes) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
-  const u32 sigma = e->protein ? 20 : 4, bits = e->protein ? 5 : 3;
-  const u64 nbytes = (bits * e->n + 7) / 8;
+  const u32 sigma = e->sigma, bits = e->packbits;
+  const u64 nbytes = ((u64) bits * e->n + 7) / 8;
   u8 *d;
   u32 blocks;
   TRY(dev_alloc(&d, nbytes));

@@ -36,6 +36,17 @@ int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
                               char **desc, uint64_t *desclen,
                               gtamd_encinfo *info, char *err, size_t errlen)
 {
+  gtamd_alphabet a;
+  gtamd_alphabet_standard(&a, protein);
+  return gtamd_device_encode_files_alpha(paths, numfiles, &a, enc_out, desc, desclen, info,
+                                         err, errlen);
+}
+
+int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
+                                    const gtamd_alphabet *a, gtamd_encoder **enc_out,
+                                    char **desc, uint64_t *desclen,
+                                    gtamd_encinfo *info, char *err, size_t errlen)
+{
   uint8_t **raw = calloc(numfiles ? numfiles : 1, sizeof *raw);
   uint64_t *rawlen = calloc(numfiles ? numfiles : 1, sizeof *rawlen);
   gtamd_encoder *de = NULL;
@@ -48,7 +59,8 @@ int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
   *enc_out = NULL;
   if (info != NULL) memset(info, 0, sizeof *info);
   if (raw == NULL || rawlen == NULL) goto nomem;
-  if ((de = gtamd_encoder_create(0, protein)) == NULL) goto deverr;
+  if ((de = gtamd_encoder_create_map(0, a->symbolmap, a->numofchars, a->bitspersymbol)) == NULL)
+    goto deverr;
   for (size_t f = 0; f < numfiles; f++) {
     const int src = gtamd_read_input_file(paths[f], &raw[f], &rawlen[f]);
     if (src != 0) {
@@ -110,6 +122,18 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
                            int protein, const gtamd_encinfo *info, int write_ssp,
                            const char *sat, gtamd_seqstats *ss, char *err, size_t errlen)
 {
+  gtamd_alphabet a;
+  gtamd_alphabet_standard(&a, protein);
+  return gtamd_write_esq_device_alpha(indexname, paths, numfiles, enc, &a, info, write_ssp,
+                                      sat, ss, err, errlen);
+}
+
+int gtamd_write_esq_device_alpha(const char *indexname, const char *const *paths,
+                                 size_t numfiles, const gtamd_encoder *enc,
+                                 const gtamd_alphabet *a, const gtamd_encinfo *info,
+                                 int write_ssp, const char *sat, gtamd_seqstats *ss,
+                                 char *err, size_t errlen)
+{
   gtamd_encode_summary sum;
   gtamd_seqanalysis an;
   gtamd_esq_sections sec;
@@ -119,8 +143,8 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
   int rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
   if (gtamd_encoder_get_summary(enc, &sum) != 0) goto deverr;
-  gtamd_analysis_from_summary(&sum, protein ? 20 : 4, &an);
-  if (gtamd_force_sat(&an, sat, protein, err, errlen) != 0) return -1;
+  gtamd_analysis_from_summary(&sum, a->numofchars, &an);
+  if (gtamd_force_sat(&an, sat, a->numofchars != 4, err, errlen) != 0) return -1;
   if (ss != NULL) *ss = an.ss;
   n = an.ss.totallength;
   gtamd_esq_needs(&an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
@@ -130,7 +154,7 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
     if (gtamd_encoder_copy_symbols(enc, plain, 0, n) != 0) goto deverr;
   }
   if (need_pk) {
-    if ((packed = malloc((5 * n + 7) / 8 + 1)) == NULL) goto nomem;
+    if ((packed = malloc((a->bitspersymbol * n + 7) / 8 + 1)) == NULL) goto nomem;
     if (gtamd_encoder_pack_bytecompress(enc, packed) != 0) goto deverr;
   }
   if (need_tb) {
@@ -156,7 +180,7 @@ int gtamd_write_esq_device(const char *indexname, const char *const *paths,
   sec.plain = plain;
   sec.wc_start = wc_start; sec.wc_len = wc_len; sec.wc_runs = sum.realwildcardranges;
   sec.seppos = seppos;
-  rc = gtamd_write_esq_sections(indexname, paths, numfiles, protein, &an, info,
+  rc = gtamd_write_esq_sections(indexname, paths, numfiles, a, &an, info,
                                 write_ssp, &sec, err, errlen);
   goto done;
 deverr:

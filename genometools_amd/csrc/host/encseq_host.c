@@ -3,6 +3,7 @@
 #include "gtamd_host.h"
 #include "gtamd_md5.h"
 #include "host_internal.h"
+#include <ctype.h>
 #include <limits.h>
 #include <pthread.h>
 #include <unistd.h>
@@ -353,13 +354,24 @@ int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
                             char **desc, uint64_t *desclen,
                             gtamd_encinfo *info, char *err, size_t errlen)
 {
+  gtamd_alphabet a;
+  gtamd_alphabet_standard(&a, protein);
+  return gtamd_encode_files_alpha(paths, numfiles, &a, enc, n, desc, desclen, info, err,
+                                  errlen);
+}
+
+int gtamd_encode_files_alpha(const char *const *paths, size_t numfiles,
+                             const gtamd_alphabet *a, uint8_t **enc, uint64_t *n,
+                             char **desc, uint64_t *desclen,
+                             gtamd_encinfo *info, char *err, size_t errlen)
+{
   uint8_t map[256];
   bytebuf out = {NULL, 0, 0};
   bytebuf dbuf = {NULL, 0, 0};
   encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0, info, 0, NULL, 0, 0};
   int last_was_fasta = 1, rc = 0;
 
-  build_symbolmap(map, protein);
+  memcpy(map, a->symbolmap, 256);
   if (info != NULL) {
     memset(info, 0, sizeof *info);
     info->numfiles = numfiles;
@@ -473,16 +485,15 @@ int gtamd_write_des_sds(const char *indexname, const char *desc,
 
 /* MD5 of one sequence: its decoded symbols in upper case, a wildcard decodes
    to the alphabet's wildcard character (N / X) */
-static void md5_of_sequence(const uint8_t *enc, uint64_t len, int protein, char hex[33])
+static void md5_of_sequence(const uint8_t *enc, uint64_t len, const uint8_t *show,
+                            char hex[33])
 {
-  static const char dna[] = "ACGT", prot[] = "LVIFKREDAGSTNQYWPHMC";
   uint8_t block[4096];
   size_t fill = 0;
   gtamd_md5 st;
   gtamd_md5_init(&st);
   for (uint64_t i = 0; i < len; i++) {
-    block[fill++] = enc[i] == GTAMD_WILDCARD ? (uint8_t) (protein ? 'X' : 'N')
-                                             : (uint8_t) (protein ? prot[enc[i]] : dna[enc[i]]);
+    block[fill++] = show[enc[i]];
     if (fill == sizeof block) { gtamd_md5_update(&st, block, fill); fill = 0; }
   }
   gtamd_md5_update(&st, block, fill);
@@ -493,7 +504,7 @@ typedef struct {
   const uint8_t *enc;
   const uint64_t *start, *len;     /* of the sequences of this batch */
   uint64_t count;
-  int protein;
+  const uint8_t *show;             /* upper-case character per symbol */
   char *hex;                       /* 33 bytes per sequence */
   uint64_t next;                   /* work counter, handed out under the lock */
   pthread_mutex_t lock;
@@ -508,12 +519,20 @@ static void *md5_worker(void *arg)
     k = b->next++;
     pthread_mutex_unlock(&b->lock);
     if (k >= b->count) return NULL;
-    md5_of_sequence(b->enc + b->start[k], b->len[k], b->protein, b->hex + 33 * k);
+    md5_of_sequence(b->enc + b->start[k], b->len[k], b->show, b->hex + 33 * k);
   }
 }
 
 int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
                     int protein)
+{
+  gtamd_alphabet a;
+  gtamd_alphabet_standard(&a, protein);
+  return gtamd_write_md5_alpha(indexname, enc, n, &a);
+}
+
+int gtamd_write_md5_alpha(const char *indexname, const uint8_t *enc, uint64_t n,
+                          const gtamd_alphabet *a)
 {
   /* the sums of different sequences are independent: batches of sequences go
      to a few threads, longest-first order does not matter at this grain */
@@ -525,6 +544,13 @@ int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   int nthreads = ncpu < 1 ? 1 : ncpu > MAXTHREADS ? MAXTHREADS : (int) ncpu, rc = -1;
   FILE *fp = NULL;
+  uint8_t show[256];
+  /* decoded symbols in upper case; a wildcard decodes to the alphabet's
+     wildcard character (encseq_charproc.gen:27-36,55-66) */
+  memset(show, 0, sizeof show);
+  for (uint32_t c = 0; c < a->numofchars; c++)
+    show[c] = (uint8_t) toupper((unsigned char) a->characters[c]);
+  show[GTAMD_WILDCARD] = (uint8_t) toupper((unsigned char) a->wildcardshow);
   snprintf(path, sizeof path, "%s.md5", indexname);
   if (start == NULL || len == NULL || hex == NULL || (fp = fopen(path, "wb")) == NULL) goto done;
   while (pos <= n) {
@@ -538,7 +564,7 @@ int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
       start[count] = pos; len[count] = end - pos; count++;
       pos = end + 1;
     }
-    b.enc = enc; b.start = start; b.len = len; b.count = count; b.protein = protein;
+    b.enc = enc; b.start = start; b.len = len; b.count = count; b.show = show;
     b.hex = hex; b.next = 0;
     pthread_mutex_init(&b.lock, NULL);
     for (int t = 1; t < nthreads && (uint64_t) t < count; t++)

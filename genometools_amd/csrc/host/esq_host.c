@@ -147,12 +147,12 @@ unsigned gtamd_least_probable(const gtamd_seqanalysis *an)
   return least;
 }
 
-int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int protein, char *err,
+int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int notdna, char *err,
                     size_t errlen)
 {
   int sat;
   if (satname == NULL) return 0;
-  if (gtamd_parse_sat(satname, protein, &sat, err, errlen) != 0) return -1;
+  if (gtamd_parse_sat(satname, notdna, &sat, err, errlen) != 0) return -1;
   if (gtamd_choose_access_type(an, an->sp_tab, an->wc_tab, sat) != 0) {
     /* src/core/encseq_access_type.c:185-193 */
     snprintf(err, errlen, "illegal argument \"%s\" to option -sat: %s is only possible for "
@@ -178,17 +178,17 @@ void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
 }
 
 int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
-                             size_t numfiles, int protein,
+                             size_t numfiles, const gtamd_alphabet *a,
                              const gtamd_seqanalysis *an, const gtamd_encinfo *info,
                              int write_ssp, const gtamd_esq_sections *sec,
                              char *err, size_t errlen)
 {
-  const uint32_t numofchars = protein ? 20 : 4;
+  const uint32_t numofchars = a->numofchars;
   const uint64_t n = an->ss.totallength, numsep = an->ss.numofsequences - 1;
   outfile o = {NULL, 0, 0};
   char path[4096];
   uint64_t lengthofdbfilenames = 0, numofallchars;
-  uint8_t maxsubalphasize, enc_of_char[256], *names = NULL;
+  uint8_t maxsubalphasize, *names = NULL;
   swtable wct, sspt;
   int have_wct = 0, have_ssp = 0, rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
@@ -205,8 +205,7 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
     snprintf(err, errlen, "sequence sections of the encoded sequence are missing");
     return -1;
   }
-  gtamd_symbolmap(enc_of_char, protein);
-  original_classes(info->originaldistribution, enc_of_char, &numofallchars,
+  original_classes(info->originaldistribution, a->symbolmap, &numofallchars,
                    &maxsubalphasize);
   for (size_t f = 0; f < numfiles; f++) lengthofdbfilenames += strlen(paths[f]) + 1;
   names = malloc(lengthofdbfilenames ? lengthofdbfilenames : 1);
@@ -252,8 +251,9 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
     put(&o, sci, sizeof sci);
     put_word(&o, an->minseqlen);
     put_word(&o, an->maxseqlen);
-    put_word(&o, protein ? 1 : 0);             /* alphabet type */
-    put_word(&o, 0);                           /* no alphabet definition */
+    put_word(&o, (uint64_t) a->alphatype);     /* 0 DNA, 1 protein, 2 symbol map */
+    put_word(&o, a->lengthofalphadef);
+    put(&o, a->alphadef, a->lengthofalphadef);   /* the symbol map text, if any */
     put(&o, names, lengthofdbfilenames);
     put(&o, &maxsubalphasize, 1);
     put_word(&o, numofallchars);
@@ -261,7 +261,7 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
     put(&o, an->chardist, sizeof (uint64_t) * numofchars);
   }
   if (an->sat == GTAMD_SAT_DIRECTACCESS) put(&o, sec->plain, n);
-  else if (need_pk) put(&o, sec->packed, (5 * n + 7) / 8);
+  else if (need_pk) put(&o, sec->packed, (a->bitspersymbol * n + 7) / 8);
   else {
     put(&o, sec->twobit, sizeof (uint64_t) * (n < 32 ? 2 : 2 + (n - 1) / 32));
     if (need_sb) put(&o, sec->specialbits, sizeof (uint64_t) * (1 + (n + 63) / 64));
@@ -310,13 +310,25 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
                              NULL, NULL, err, errlen);
 }
 
-/* the sequence sections by host loops over the symbols */
 int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
                         size_t numfiles, const uint8_t *enc, uint64_t n,
                         int protein, const gtamd_encinfo *info, int write_ssp,
                         const char *sat, gtamd_seqstats *ss, char *err, size_t errlen)
 {
-  const uint32_t numofchars = protein ? 20 : 4;
+  gtamd_alphabet a;
+  gtamd_alphabet_standard(&a, protein);
+  return gtamd_write_esq_alpha(indexname, paths, numfiles, enc, n, &a, info, write_ssp, sat,
+                               ss, err, errlen);
+}
+
+/* the sequence sections by host loops over the symbols */
+int gtamd_write_esq_alpha(const char *indexname, const char *const *paths,
+                          size_t numfiles, const uint8_t *enc, uint64_t n,
+                          const gtamd_alphabet *a, const gtamd_encinfo *info,
+                          int write_ssp, const char *sat, gtamd_seqstats *ss,
+                          char *err, size_t errlen)
+{
+  const uint32_t numofchars = a->numofchars, bits = a->bitspersymbol;
   gtamd_seqanalysis an;
   gtamd_esq_sections sec;
   uint64_t *twobit = NULL, *specialbits = NULL, *wc_start = NULL, *wc_len = NULL,
@@ -326,13 +338,13 @@ int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
   int rc = -1, need_tb, need_sb, need_pk, need_wc, need_sep;
 
   gtamd_analyse_sequence(enc, n, numofchars, &an);
-  if (gtamd_force_sat(&an, sat, protein, err, errlen) != 0) return -1;
+  if (gtamd_force_sat(&an, sat, numofchars != 4, err, errlen) != 0) return -1;
   if (ss != NULL) *ss = an.ss;
   gtamd_esq_needs(&an, write_ssp, &need_tb, &need_sb, &need_pk, &need_wc, &need_sep);
   least = gtamd_least_probable(&an);
   memset(&sec, 0, sizeof sec);
   sec.plain = enc;
-  if (need_pk && (packed = calloc((5 * n + 7) / 8 + 1, 1)) == NULL) goto nomem;
+  if (need_pk && (packed = calloc((bits * n + 7) / 8 + 2, 1)) == NULL) goto nomem;
   if (need_tb && (twobit = calloc(n < 32 ? 2 : 2 + (n - 1) / 32, 8)) == NULL) goto nomem;
   if (need_sb) {
     if ((specialbits = calloc(1 + (n + 63) / 64, 8)) == NULL) goto nomem;
@@ -354,12 +366,12 @@ int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
     if (need_sep && c == GTAMD_SEPARATOR) seppos[nsep++] = pos;
     if (twobit == NULL && packed == NULL) continue;      /* direct access */
     if (packed != NULL) {
-      /* 5 bits per symbol, most significant bit first; wildcard and separator
-         are the two codes behind the alphabet */
+      /* `bits` per symbol (at most 8), most significant bit first; wildcard
+         and separator are the two codes behind the alphabet */
       const unsigned v = c == GTAMD_WILDCARD ? numofchars
                        : c == GTAMD_SEPARATOR ? numofchars + 1 : c;
-      const uint64_t bit = 5 * pos;
-      const unsigned shift = 16 - 5 - (unsigned) (bit % 8);
+      const uint64_t bit = (uint64_t) bits * pos;
+      const unsigned shift = 16 - bits - (unsigned) (bit % 8);
       packed[bit / 8] |= (uint8_t) ((v << shift) >> 8);
       if (shift < 8) packed[bit / 8 + 1] |= (uint8_t) (v << shift);
     } else {
@@ -375,7 +387,7 @@ int gtamd_write_esq_sat(const char *indexname, const char *const *paths,
   sec.twobit = twobit; sec.specialbits = specialbits; sec.packed = packed;
   sec.wc_start = wc_start; sec.wc_len = wc_len; sec.wc_runs = nwc;
   sec.seppos = seppos;
-  rc = gtamd_write_esq_sections(indexname, paths, numfiles, protein, &an, info,
+  rc = gtamd_write_esq_sections(indexname, paths, numfiles, a, &an, info,
                                 write_ssp, &sec, err, errlen);
   goto done;
 nomem:
@@ -459,6 +471,22 @@ static int sw_apply(infile *in, int kind, int withlengths, uint64_t n, uint64_t 
 int gtamd_read_esq(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
                    int *protein_out, gtamd_seqstats *ss, char *err, size_t errlen)
 {
+  gtamd_alphabet a;
+  if (gtamd_read_esq_alpha(indexname, enc_out, n_out, &a, ss, err, errlen) != 0) return -1;
+  if (a.alphatype > 1) {
+    free(*enc_out); *enc_out = NULL;
+    gtamd_alphabet_free(&a);
+    snprintf(err, errlen, "index '%s' uses a custom alphabet", indexname);
+    return -1;
+  }
+  *protein_out = a.alphatype == 1;
+  return 0;
+}
+
+int gtamd_read_esq_alpha(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
+                         gtamd_alphabet *alpha, gtamd_seqstats *ss, char *err,
+                         size_t errlen)
+{
   char path[4096];
   uint8_t *data = NULL, *sspdata = NULL, *enc = NULL;
   uint64_t len = 0, ssplen = 0, sat, n, numseq, numfiles, namelen, alphatype,
@@ -468,6 +496,7 @@ int gtamd_read_esq(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
   uint32_t numofchars;
   int rc = -1;
 
+  memset(alpha, 0, sizeof *alpha);
   snprintf(path, sizeof path, "%s.esq", indexname);
   if (slurp_file(path, &data, &len) != 0) {
     snprintf(err, errlen, "cannot open file '%s'", path);
@@ -495,12 +524,14 @@ int gtamd_read_esq(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
     snprintf(err, errlen, "index '%s' has an unsupported format version", indexname);
     goto done;
   }
-  if (alphatype > 1 || alphadeflen != 0) {
-    snprintf(err, errlen, "index '%s' uses a custom alphabet, only the DNA and protein "
-             "alphabets are supported", indexname);
-    goto done;
-  }
-  numofchars = alphatype == 1 ? 20 : 4;
+  memset(alpha, 0, sizeof *alpha);
+  if (alphatype <= 1 && alphadeflen == 0) gtamd_alphabet_standard(alpha, alphatype == 1);
+  else if (alphatype == 2 && alphadeflen > 0) {
+    const char *def = take(&in, alphadeflen);
+    if (in.bad) goto corrupt;
+    if (gtamd_alphabet_from_text(def, alphadeflen, path, alpha, err, errlen) != 0) goto done;
+  } else goto corrupt;
+  numofchars = alpha->numofchars;
   wildcardranges = sci[6];
   (void) take(&in, namelen);
   (void) take(&in, 1);                                 /* maxsubalphasize */
@@ -516,7 +547,7 @@ int gtamd_read_esq(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
     if (in.bad) goto corrupt;
     memcpy(enc, plain, n);
   } else if (sat == GTAMD_SAT_BYTECOMPRESS) {
-    const unsigned bits = numofchars == 4 ? 3 : 5;
+    const unsigned bits = alpha->bitspersymbol;
     const uint8_t *packed = take(&in, (bits * n + 7) / 8);
     if (in.bad) goto corrupt;
     for (uint64_t pos = 0; pos < n; pos++) {
@@ -568,7 +599,6 @@ int gtamd_read_esq(const char *indexname, uint8_t **enc_out, uint64_t *n_out,
   } else goto corrupt;
   *enc_out = enc; enc = NULL;
   *n_out = n;
-  *protein_out = numofchars == 20;
   if (ss != NULL) {
     /* GtSpecialcharinfo as stored (src/core/chardef.h:91-116) */
     memset(ss, 0, sizeof *ss);
@@ -585,5 +615,6 @@ corrupt:
   snprintf(err, errlen, "index file '%s.esq' is truncated or inconsistent", indexname);
 done:
   free(enc); free(data); free(sspdata);
+  if (rc != 0) gtamd_alphabet_free(alpha);
   return rc;
 }

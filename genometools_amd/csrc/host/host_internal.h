@@ -45,7 +45,7 @@ void gtamd_esq_needs(const gtamd_seqanalysis *an, int write_ssp, int *twobit,
    and table access types (src/core/encseq.c:4468-4485) */
 unsigned gtamd_least_probable(const gtamd_seqanalysis *an);
 int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
-                             size_t numfiles, int protein,
+                             size_t numfiles, const gtamd_alphabet *a,
                              const gtamd_seqanalysis *an, const gtamd_encinfo *info,
                              int write_ssp, const gtamd_esq_sections *sec,
                              char *err, size_t errlen);
@@ -64,10 +64,10 @@ int gtamd_choose_access_type(gtamd_seqanalysis *an, const uint64_t sp_tab[3],
                              const uint64_t wc_tab[3], int forced_sat);
 /* -sat NAME -> access type number; the alphabet-dependent checks and messages
    of src/core/encseq.c:797-807, encseq_access_type.c:163-221 */
-int gtamd_parse_sat(const char *name, int protein, int *sat, char *err, size_t errlen);
+int gtamd_parse_sat(const char *name, int notdna, int *sat, char *err, size_t errlen);
 /* apply a forced access type (-sat) to a finished analysis; -1 with the
    reference's message when "eqlen" does not fit the sequences */
-int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int protein, char *err,
+int gtamd_force_sat(gtamd_seqanalysis *an, const char *satname, int notdna, char *err,
                     size_t errlen);
 /* the same analysis from the device encoder's summary */
 void gtamd_analysis_from_summary(const gtamd_encode_summary *s, uint32_t numofchars,

@@ -107,7 +107,9 @@ static int yesno(int argc, const char **argv, int *i)
 
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
 {
-  const char *db[MAXDB], *indexname = NULL, *inputindex = NULL, *sat = NULL;
+  const char *db[MAXDB], *indexname = NULL, *inputindex = NULL, *sat = NULL, *smap = NULL;
+  gtamd_alphabet alpha;
+  int dnalike;
   size_t numdb = 0;
   int protein = 0, dna = 0, verbose = 0, readmode = 0, mirrored = 0,
       out_des = 1, out_sds = 1, out_md5 = 1, out_ssp = 1;   /* defaults of encseq_options.c */
@@ -141,6 +143,10 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       indexname = argv[++i];
     } else if (!strcmp(a, "-dna")) dna = 1;
     else if (!strcmp(a, "-protein")) protein = 1;
+    else if (!strcmp(a, "-smap")) {
+      if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "smap");
+      smap = argv[++i];
+    }
     else if (!strcmp(a, "-suf")) want |= GTAMD_WANT_SUF;
     else if (!strcmp(a, "-lcp")) want |= GTAMD_WANT_LCP;
     else if (!strcmp(a, "-bwt")) want |= GTAMD_WANT_BWT;
@@ -177,7 +183,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     } else if (!strcmp(a, "-sat")) {
       if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "sat");
       sat = argv[++i];
-    } else if (!strcmp(a, "-lossless") || !strcmp(a, "-smap") ||
+    } else if (!strcmp(a, "-lossless") ||
                !strcmp(a, "-plain") || !strcmp(a, "-kys") || !strcmp(a, "-lcpdist") ||
                !strcmp(a, "-compressedoutput") || !strcmp(a, "-genomediff") ||
                !strcmp(a, "-sortmaxdepth") || !strcmp(a, "-spmopt") ||
@@ -204,9 +210,13 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     return fail(err, errlen, "either option \"-db\" or option \"-%s\" is mandatory", "ii");
   if (dna && protein)
     return fail(err, errlen, "option \"-dna\" and option \"-%s\" exclude each other", "protein");
-  if (inputindex != NULL && (numdb > 0 || dna || protein || sat != NULL))
+  if (smap != NULL && (dna || protein))
+    /* src/core/encseq_options.c:271-272 */
+    return fail(err, errlen, "option \"-smap\" and option \"-%s\" exclude each other",
+                dna ? "dna" : "protein");
+  if (inputindex != NULL && (numdb > 0 || dna || protein || sat != NULL || smap != NULL))
     return fail(err, errlen, "option \"-%s\" and option \"-ii\" exclude each other",
-                numdb > 0 ? "db" : dna ? "dna" : protein ? "protein" : "sat");
+                numdb > 0 ? "db" : smap != NULL ? "smap" : dna ? "dna" : protein ? "protein" : "sat");
   if (indexname == NULL && inputindex != NULL) {
     const char *base = strrchr(inputindex, '/');
     snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : inputindex);
@@ -221,26 +231,37 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     snprintf(indexbuf, sizeof indexbuf, "%s", base ? base + 1 : db[0]);
     indexname = indexbuf;
   }
-  if (protein && (readmode >= 2 || mirrored))
-    /* wording of src/match/sfx-run.c:566-570 */
-    return fail(err, errlen, "option -%s only can be used for DNA alphabets",
-                mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
+  if (smap != NULL) {
+    if (gtamd_alphabet_from_file(smap, &alpha, err, errlen) != 0) return -1;
+    if (alpha.numofchars > 28) {
+      gtamd_alphabet_free(&alpha);
+      return fail(err, errlen, "symbol map '%s' defines more than 28 letters", smap);
+    }
+  } else gtamd_alphabet_standard(&alpha, protein);
   if (inputindex != NULL) {
     /* an existing encoded sequence: nothing on the sequence side is rewritten;
        .prj repeats the statistics stored with it (src/match/sfx-run.c:454-493) */
-    if (gtamd_read_esq(inputindex, &enc, &n, &protein, &ss, err, errlen) != 0) return -1;
-    if (protein && (readmode >= 2 || mirrored)) {
-      free(enc);
-      return fail(err, errlen, "option -%s only can be used for DNA alphabets",
-                  mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
-    }
+    gtamd_alphabet_free(&alpha);
+    if (gtamd_read_esq_alpha(inputindex, &enc, &n, &alpha, &ss, err, errlen) != 0) return -1;
+  }
+  /* complementing needs a=0 c=1 g=2 t=3 (gt_alphabet_is_dna) */
+  dnalike = alpha.numofchars == 4 && alpha.symbolmap['a'] == 0 && alpha.symbolmap['c'] == 1 &&
+            alpha.symbolmap['g'] == 2 && alpha.symbolmap['t'] == 3;
+  if (!dnalike && (readmode >= 2 || mirrored)) {
+    /* wording of src/match/sfx-run.c:566-570 */
+    free(enc); gtamd_alphabet_free(&alpha);
+    return fail(err, errlen, "option -%s only can be used for DNA alphabets",
+                mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
+  }
+  if (inputindex != NULL) {
+    /* (read above) */
   } else if (want != 0 && !host_encoder && !gtamd_input_is_fastq(db, numdb)) {
     /* FASTA, tables requested: read and encode on the device; the symbols stay
        in HBM for the engine and come to the host only where a file needs them */
-    if (gtamd_device_encode_files(db, numdb, protein, &de, &desc, &desclen, &info, err, errlen) != 0)
+    if (gtamd_device_encode_files_alpha(db, numdb, &alpha, &de, &desc, &desclen, &info, err, errlen) != 0)
       return -1;
     n = gtamd_encoder_length(de);
-    if (gtamd_write_esq_device(indexname, db, numdb, de, protein, &info, out_ssp, sat, &ss, err, errlen) != 0) {
+    if (gtamd_write_esq_device_alpha(indexname, db, numdb, de, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
       return -1;
     }
@@ -258,7 +279,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
         return fail(err, errlen, "cannot copy the encoded sequence from the device (%s)",
                     gtamd_esa_last_error());
       }
-      if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
+      if (out_md5 && gtamd_write_md5_alpha(indexname, enc, n, &alpha) != 0) {
         free(enc); gtamd_encoder_destroy(de);
         return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
       }
@@ -266,11 +287,11 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       else { free(enc); enc = NULL; }
     }
   } else {
-    if (gtamd_encode_files_info(db, numdb, protein, &enc, &n, &desc, &desclen, &info, err, errlen) != 0)
+    if (gtamd_encode_files_alpha(db, numdb, &alpha, &enc, &n, &desc, &desclen, &info, err, errlen) != 0)
       return -1;
     /* the encoded sequence itself, in the reference's format (always written:
        -tis is kept for backwards compatibility only, src/match/sfx-opt.c) */
-    if (gtamd_write_esq_sat(indexname, db, numdb, enc, n, protein, &info, out_ssp, sat, &ss, err, errlen) != 0) {
+    if (gtamd_write_esq_alpha(indexname, db, numdb, enc, n, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(enc); free(desc); gtamd_encinfo_free(&info);
       return -1;
     }
@@ -282,7 +303,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);
     }
     free(desc);
-    if (out_md5 && gtamd_write_md5(indexname, enc, n, protein) != 0) {
+    if (out_md5 && gtamd_write_md5_alpha(indexname, enc, n, &alpha) != 0) {
       free(enc);
       return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
     }
@@ -313,6 +334,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     char path[4096];
     free(enc);
     snprintf(path, sizeof path, "%s.prj", indexname);
+    gtamd_alphabet_free(&alpha);
     if (gtamd_write_prj(path, &ss, &es, 0, readmode, mirrored) != 0)
       return fail(err, errlen, "cannot open file '%s' for writing", path);
     return 0;
@@ -370,6 +392,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   }
   rc = 0;
 done:
+  gtamd_alphabet_free(&alpha);
   gtamd_esa_destroy(ctx);
   gtamd_encoder_destroy(de);
   free(enc);

@@ -54,6 +54,11 @@ typedef struct {
 } gtamd_encode_summary;
 
 gtamd_encoder *gtamd_encoder_create(int device, int protein);
+/* any alphabet (-smap): code 0..numofchars-1 or 254 (wildcard) per input byte,
+   everything else is an illegal character; bitspersymbol is that of the
+   bit-packed access type (src/core/alphabet.c:300-305) */
+gtamd_encoder *gtamd_encoder_create_map(int device, const uint8_t *symbolmap,
+                                        uint32_t numofchars, unsigned bitspersymbol);
 void gtamd_encoder_destroy(gtamd_encoder *enc);
 
 /* One input file, in -db order: its name (for messages) and its bytes in host
@@ -93,8 +98,9 @@ int gtamd_encoder_get_descriptions(const gtamd_encoder *enc, uint32_t *file,
                         fillcode (the least frequent letter)
      pack_specialbits   1 + (n+63)/64 words, one bit per position, first in the
                         top bit; the 64 positions behind the sequence are set
-     pack_bytecompress  (bits*n+7)/8 bytes, bits = 5 (protein) or 3 (DNA) per
-                        symbol, wildcard = sigma, separator = sigma + 1
+     pack_bytecompress  (bits*n+7)/8 bytes, bits per symbol as given at
+                        creation (5 protein, 3 DNA), wildcard = sigma,
+                        separator = sigma + 1
      wildcard_runs      the realwildcardranges maximal runs (start, length)
      separators         the numofsequences - 1 separator positions */
 int gtamd_encoder_pack_twobit(const gtamd_encoder *enc, int bitaccess,

@@ -34,6 +34,28 @@ typedef struct {
   uint32_t numofchars;
 } gtamd_seqstats;
 
+/* An alphabet: the built-in DNA and protein ones (src/core/alphabet.c:84-91,
+   345-356, 480-503) or one read from a symbol map file (-smap; format and
+   parser src/core/alphabet.c:118-330: one line per symbol class, optionally a
+   blank and the character shown for the class, leading '#' lines are comments,
+   the last line holds the wildcards).  numofchars <= 28 for the engine. */
+typedef struct {
+  uint8_t symbolmap[256];      /* code per input byte; 254 wildcard, 253 undefined */
+  uint32_t numofchars;
+  char characters[64];         /* character shown for every code */
+  char wildcardshow;
+  int alphatype;               /* 0 DNA, 1 protein, 2 from a symbol map */
+  unsigned bitspersymbol;      /* of the bit-packed access type */
+  char *alphadef;              /* symbol map text as INDEX.esq stores it, or NULL */
+  uint64_t lengthofalphadef;
+} gtamd_alphabet;
+
+void gtamd_alphabet_standard(gtamd_alphabet *a, int protein);
+int gtamd_alphabet_from_file(const char *path, gtamd_alphabet *a, char *err, size_t errlen);
+int gtamd_alphabet_from_text(const char *text, uint64_t len, const char *mapfile,
+                             gtamd_alphabet *a, char *err, size_t errlen);
+void gtamd_alphabet_free(gtamd_alphabet *a);
+
 /* Read one or more (multi-)FASTA files into one encoded sequence; consecutive
    sequences are joined by one separator, also across files.  protein != 0
    selects the protein alphabet.  *enc is malloc'ed.  Returns 0, or -1 with the
@@ -67,6 +89,32 @@ int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
                             char **desc, uint64_t *desclen,
                             gtamd_encinfo *info, char *err, size_t errlen);
 void gtamd_encinfo_free(gtamd_encinfo *info);
+
+/* The functions of this header that take `int protein` have a twin ending in
+   _alpha that takes any alphabet instead. */
+int gtamd_encode_files_alpha(const char *const *paths, size_t numfiles,
+                             const gtamd_alphabet *a, uint8_t **enc, uint64_t *n,
+                             char **desc, uint64_t *desclen,
+                             gtamd_encinfo *info, char *err, size_t errlen);
+int gtamd_write_md5_alpha(const char *indexname, const uint8_t *enc, uint64_t n,
+                          const gtamd_alphabet *a);
+int gtamd_write_esq_alpha(const char *indexname, const char *const *paths,
+                          size_t numfiles, const uint8_t *enc, uint64_t n,
+                          const gtamd_alphabet *a, const gtamd_encinfo *info,
+                          int write_ssp, const char *sat, gtamd_seqstats *ss,
+                          char *err, size_t errlen);
+int gtamd_read_esq_alpha(const char *indexname, uint8_t **enc, uint64_t *n,
+                         gtamd_alphabet *a, gtamd_seqstats *ss, char *err,
+                         size_t errlen);
+int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
+                                    const gtamd_alphabet *a, gtamd_encoder **enc,
+                                    char **desc, uint64_t *desclen,
+                                    gtamd_encinfo *info, char *err, size_t errlen);
+int gtamd_write_esq_device_alpha(const char *indexname, const char *const *paths,
+                                 size_t numfiles, const gtamd_encoder *enc,
+                                 const gtamd_alphabet *a, const gtamd_encinfo *info,
+                                 int write_ssp, const char *sat, gtamd_seqstats *ss,
+                                 char *err, size_t errlen);
 
 /* INDEX.esq -- the encoded sequence in the reference's own on-disk format, so
    that an index written here can be mapped by GenomeTools' tools
@@ -156,14 +204,14 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
 
 /* `gt suffixerator` for the option subset of this path:
      -db FILE... | -ii INDEX  -indexname NAME  -dna | -protein
-     -suf -lcp -bwt -bck  -suftabuint  -sat TYPE
+     -suf -lcp -bwt -bck  -suftabuint  -sat TYPE  -smap FILE
      -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored  -clipdesc  and, accepted
      without effect on the tables (strategy knobs of the CPU algorithm),
      -parts N  -memlimit X  -dc V  -algbds A B C  -maxwidthrealmedian W
      -cmpcharbychar -dccheck -iterscan -kmerswithencseqreader -noshortreadsort
      -samplewithprefixlengthnull -storespecialcodes -withradixsort
      -showprogress -tis [yes|no];
-     -lossless -smap -plain -kys -lcpdist -compressedoutput -genomediff
+     -lossless -plain -kys -lcpdist -compressedoutput -genomediff
      -sortmaxdepth -spmopt -swallow-tail -onlybucketinsertion change what is
      written and are refused ("option \"-X\" is not supported ...").
    -des -sds -md5 -ssp [yes|no] select the sequence-side files; INDEX.esq is

@@ -19,7 +19,7 @@
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
   usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
-                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint] [-clipdesc]
+                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint] [-clipdesc] [-smap FILE]
                     -db FASTA... -indexname IDX [-time]
 */
 #include <stdio.h>
@@ -65,7 +65,7 @@ static FILE *open_tab(const char *indexname, const char *suffix)
 
 int main(int argc, char **argv)
 {
-  const char *db[64], *indexname = NULL, *sat = NULL;
+  const char *db[64], *indexname = NULL, *sat = NULL, *smap = NULL;
   int numdb = 0;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
        showtime = false, haserr = false, mirrored = false, want_bck = false,
@@ -113,6 +113,7 @@ int main(int argc, char **argv)
         db[numdb++] = argv[++i];
     }
     else if (!strcmp(argv[i], "-sat") && i + 1 < argc) sat = argv[++i];
+    else if (!strcmp(argv[i], "-smap") && i + 1 < argc) smap = argv[++i];
     else if (!strcmp(argv[i], "-indexname") && i + 1 < argc)
       indexname = argv[++i];
     else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
@@ -135,7 +136,14 @@ int main(int argc, char **argv)
   err = gt_error_new();
   t0 = now_s();
   ee = gt_encseq_encoder_new();
-  if (dna) gt_encseq_encoder_set_input_dna(ee);
+  if (smap != NULL) {
+    /* -smap FILE (an existing file: no lookup in gtdata/trans) */
+    if (gt_encseq_encoder_use_symbolmap_file(ee, smap, err) != 0) {
+      fprintf(stderr, "gt suffixerator: error: %s\n", gt_error_get(err));
+      return EXIT_FAILURE;
+    }
+  }
+  else if (dna) gt_encseq_encoder_set_input_dna(ee);
   else gt_encseq_encoder_set_input_protein(ee);
   if (clipdesc) gt_encseq_encoder_clip_desc(ee);   /* -clipdesc, encseq_options.c */
   if (sat != NULL) {

@@ -71,6 +71,10 @@ BCK_FILES = [("Atinsert.fna", [0, 1, 2, 3, 7]), ("Duplicate.fna", [0, 1, 2, 5]),
              ("extra/protein_long_x.faa", [0, 2, 3]), ("sw100K1.fsa", [0, 2])]
 CLIPDESC_FILES = ["Atinsert.fna", "Duplicate.fna", "extra/blanks.fna", "extra/crlf.fna",
                   "test10_multiline.fastq", "Reads1.fna"]
+SMAP_CASES = [("trans_dna.map", "Atinsert.fna"), ("trans_dna.map", "Duplicate.fna"),
+              ("trans_dna.map", "extra/lowercase_iupac.fna"),
+              ("prot5.map", "sw100K1.fsa"), ("prot5.map", "extra/protein_specials.faa"),
+              ("prot5.map", "extra/protein_long_x.faa")]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -211,6 +215,26 @@ def main():
                     "prj": prj}
     with open(os.path.join(OUT, "golden_bck.json"), "w") as f:
         json.dump(bck, f, indent=1, sort_keys=True)
+    # -smap FILE: alphabets from a symbol map (tests/golden/extra/*.map)
+    smap = {}
+    for mapname, name in SMAP_CASES:
+        src = (os.path.join(OUT, name) if name.startswith("extra/")
+               else os.path.join(REF, "testdata", name))
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            subprocess.run([BIN, "-smap", os.path.join(OUT, "extra", mapname), "-suf", "-lcp",
+                            "-bwt", "-bck", "-indexname", idx, "-db", os.path.basename(src)],
+                           check=True, cwd=os.path.dirname(src))
+            entry = {"tables": {}}
+            for ext in ("suf", "lcp", "llv", "bwt", "bck"):
+                entry["tables"][ext] = {"md5": md5(idx + "." + ext),
+                                        "bytes": os.path.getsize(idx + "." + ext)}
+            with open(idx + ".prj") as f:
+                entry["prj"] = f.read()
+            entry["seqfiles"] = seqfiles(idx)
+        smap["%s|%s" % (mapname, name)] = entry
+    with open(os.path.join(OUT, "golden_smap.json"), "w") as f:
+        json.dump(smap, f, indent=1, sort_keys=True)
     # -clipdesc: descriptions cut at the first white space
     clip = {}
     for name in CLIPDESC_FILES:

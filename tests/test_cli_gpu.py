@@ -217,3 +217,28 @@ def test_cli_forced_access_type(cli, stem, tmp_path):
             assert open(idx + "." + ext, "rb").read() == open(ref, "rb").read(), ext
     with open(idx + ".suf", "rb") as f:
         assert hashlib.md5(f.read()).hexdigest() == GOLDEN[key]["tables"]["suf"]["md5"]
+
+
+SMAP = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_smap.json")))
+
+
+@pytest.mark.parametrize("key", sorted(SMAP))
+@pytest.mark.parametrize("encoder", ["device", "host"])
+def test_cli_symbol_map_alphabets(cli, key, encoder, tmp_path):
+    """-smap FILE (5- and 4-letter alphabets from tests/golden/extra/*.map): all
+    tables, the bucket table and the sequence-side files"""
+    mapname, name = key.split("|")
+    e = SMAP[key]
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-smap", os.path.join(ou.GOLDEN_DIR, "extra", mapname), "-suf", "-lcp",
+                    "-bwt", "-bck", "-encoder", encoder, "-indexname", idx, "-db",
+                    os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+    for ext in ("suf", "lcp", "llv", "bwt", "bck"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    with open(idx + ".prj") as f:
+        assert f.read() == e["prj"]
+    for ext, v in e["seqfiles"].items():
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == v["md5"], ext

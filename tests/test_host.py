@@ -485,7 +485,7 @@ def test_tool_strategy_switches_are_accepted_and_output_switches_refused(host, t
                      "-iterscan", "no", "-parts", "2", "-memlimit", "1GB",
                      "-showprogress", "no", "-dccheck") == (0, "")
     assert open(a + ".prj").read() == open(b + ".prj").read()
-    for opt in ("-lossless", "-smap", "-plain", "-kys", "-lcpdist",
+    for opt in ("-lossless", "-plain", "-kys", "-lcpdist",
                 "-compressedoutput", "-genomediff", "-sortmaxdepth", "-spmopt"):
         rc, msg = _run_tool(host, "-dna", "-indexname", a, "-db", src, opt)
         assert rc == -1 and msg == 'option "%s" is not supported by the MI355X engine' % opt
@@ -546,3 +546,49 @@ def test_forced_access_type_errors_use_the_reference_wording(host, tmp_path):
     rc, msg, _ = _write_esq_forced(host, prot, True, idx, "bit")
     assert rc == -1 and msg == ('illegal argument "bit" to option -sat: as the sequence is not '
                                 'DNA, you can choose bytecompress or direct')
+
+
+SMAP = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_smap.json")))
+
+
+@pytest.mark.parametrize("key", sorted(SMAP))
+def test_tool_symbol_map_alphabets(host, key, tmp_path):
+    """-smap FILE: alphabet from a symbol map; INDEX.esq carries the map text
+    and alphabet type 2, the bit packing uses the alphabet's own width; all
+    sequence-side files as the reference writes them"""
+    import hashlib
+    mapname, name = key.split("|")
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    assert _run_tool(host, "-smap", os.path.join(ou.GOLDEN_DIR, "extra", mapname), "-indexname",
+                     idx, "-db", os.path.basename(src), cwd=os.path.dirname(src)) == (0, "")
+    e = SMAP[key]
+    for ext in ("des", "sds", "md5", "esq", "ssp"):
+        assert os.path.exists(idx + "." + ext) == (ext in e["seqfiles"]), ext
+        if ext in e["seqfiles"]:
+            raw = open(idx + "." + ext, "rb").read()
+            assert hashlib.md5(raw).hexdigest() == e["seqfiles"][ext]["md5"], ext
+    # and back: -ii reads the alphabet from the index
+    assert _run_tool(host, "-ii", idx, "-indexname", str(tmp_path / "again")) == (0, "")
+    want = dict(l.split("=") for l in e["prj"].splitlines())
+    got = dict(l.split("=") for l in open(str(tmp_path / "again") + ".prj").read().splitlines())
+    for k in ("totallength", "specialcharacters", "specialranges", "wildcards", "numofsequences",
+              "prefixlength"):
+        assert got[k] == want[k], k
+
+
+def test_symbol_map_errors(host, tmp_path):
+    src = ou.fixture_path("Atinsert.fna")
+    idx = str(tmp_path / "idx")
+    rc, msg = _run_tool(host, "-smap", str(tmp_path / "nothing"), "-indexname", idx, "-db", src)
+    assert rc == -1 and "cannot open file" in msg
+    bad = tmp_path / "bad.map"
+    bad.write_text("aA\ncCa\nn\n")
+    rc, msg = _run_tool(host, "-smap", str(bad), "-indexname", idx, "-db", src)
+    assert rc == -1 and msg == "cannot map symbol 'a' to 1: it is already mapped to 0"
+    assert _run_tool(host, "-smap", str(bad), "-dna", "-db", src) == \
+        (-1, 'option "-smap" and option "-dna" exclude each other')
+    # a protein-like map cannot be complemented
+    rc, msg = _run_tool(host, "-smap", os.path.join(ou.GOLDEN_DIR, "extra", "prot5.map"), "-dir",
+                        "rcl", "-indexname", idx, "-db", ou.fixture_path("extra/protein_specials.faa"))
+    assert rc == -1 and msg == "option -rcl only can be used for DNA alphabets"

@@ -4,6 +4,7 @@
 #include "gtamd_md5.h"
 #include "host_internal.h"
 #include <ctype.h>
+#include <dlfcn.h>
 #include <limits.h>
 #include <pthread.h>
 #include <unistd.h>
@@ -54,13 +55,45 @@ static int is_blank(int c)
 /* whole file in memory (the device encoder wants it whole, the host reader
    walks it once).  The compression follows the file name, as in the reference
    (gt_file_mode_determine, src/core/file.c:42-53): "*.gz" is read through
-   zlib; the file length the encoder reports is that of the decompressed text. */
+   zlib, "*.bz2" through libbz2; the file length the encoder reports is that of
+   the decompressed text. */
 int gtamd_read_input_file(const char *path, uint8_t **data, uint64_t *len)
 {
   const size_t plen = strlen(path);
   uint64_t cap = 1 << 20, n = 0;
   uint8_t *buf;
-  if (plen >= 5 && strcmp(path + plen - 4, ".bz2") == 0) return -3;
+  if (plen >= 5 && strcmp(path + plen - 4, ".bz2") == 0) {
+    /* libbz2 has no header in this image: bind the three calls at run time */
+    typedef void *(*open_fn)(const char *, const char *);
+    typedef int (*read_fn)(void *, void *, int);
+    typedef void (*close_fn)(void *);
+    void *lib = dlopen("libbz2.so.1.0", RTLD_NOW);
+    open_fn bzopen;
+    read_fn bzread;
+    close_fn bzclose;
+    void *bz;
+    int got;
+    if (lib == NULL) lib = dlopen("libbz2.so.1", RTLD_NOW);
+    if (lib == NULL) return -3;
+    bzopen = (open_fn) dlsym(lib, "BZ2_bzopen");
+    bzread = (read_fn) dlsym(lib, "BZ2_bzread");
+    bzclose = (close_fn) dlsym(lib, "BZ2_bzclose");
+    if (bzopen == NULL || bzread == NULL || bzclose == NULL) return -3;
+    if ((bz = bzopen(path, "rb")) == NULL) return -1;
+    buf = malloc(cap);
+    while (buf != NULL && (got = bzread(bz, buf + n, (int) (cap - n < (1u << 30) ? cap - n : (1u << 30)))) > 0) {
+      n += (uint64_t) got;
+      if (n == cap) {
+        uint8_t *nb = realloc(buf, cap * 2);
+        if (nb == NULL) { free(buf); buf = NULL; break; }
+        buf = nb; cap *= 2;
+      }
+    }
+    bzclose(bz);
+    if (buf == NULL) return -2;
+    *data = buf; *len = n;
+    return 0;
+  }
   if (plen >= 4 && strcmp(path + plen - 3, ".gz") == 0) {
     gzFile gz = gzopen(path, "rb");
     int got;
@@ -106,7 +139,7 @@ void gtamd_read_input_error(int code, const char *path, char *err, size_t errlen
 {
   snprintf(err, errlen,
            code == -1 ? "cannot open file '%s'"
-           : code == -3 ? "file '%s': bzip2-compressed input is not supported, use gzip or plain text"
+           : code == -3 ? "file '%s': libbz2 is not available to read bzip2-compressed input"
            : code == -4 ? "file '%s' is not a complete gzip stream"
                         : "out of memory while reading '%s'", path);
 }

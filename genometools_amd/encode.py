@@ -53,9 +53,11 @@ class DeviceEncoder:
         """encode files (paths) or in-memory inputs ((name, bytes) pairs)"""
         inputs = []
         for p in paths or []:
-            if str(p).endswith(".gz"):      # by name, src/core/file.c:42-53
+            if str(p).endswith((".gz", ".bz2")):      # by name, src/core/file.c:42-53
+                import bz2
                 import gzip
-                with gzip.open(p, "rb") as f:
+                opener = gzip.open if str(p).endswith(".gz") else bz2.open
+                with opener(p, "rb") as f:
                     inputs.append((p, np.frombuffer(f.read(), dtype=np.uint8)))
             else:
                 inputs.append((p, np.fromfile(p, dtype=np.uint8)))

@@ -7,6 +7,7 @@
 */
 #include "esa_oracle.h"
 #include <ctype.h>
+#include <dlfcn.h>
 #include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -58,6 +59,25 @@ static FILE *open_input(const char *path)
     if (tmp == NULL) { if (gz != NULL) gzclose(gz); return NULL; }
     while ((got = gzread(gz, buf, sizeof buf)) > 0) fwrite(buf, 1, (size_t) got, tmp);
     gzclose(gz);
+    rewind(tmp);
+    return tmp;
+  }
+  if (len >= 5 && strcmp(path + len - 4, ".bz2") == 0) {
+    /* libbz2 without a header in this image: bound at run time */
+    typedef void *(*open_fn)(const char *, const char *);
+    typedef int (*read_fn)(void *, void *, int);
+    typedef void (*close_fn)(void *);
+    void *lib = dlopen("libbz2.so.1.0", RTLD_NOW);
+    open_fn bzopen = lib ? (open_fn) dlsym(lib, "BZ2_bzopen") : NULL;
+    read_fn bzread = lib ? (read_fn) dlsym(lib, "BZ2_bzread") : NULL;
+    close_fn bzclose = lib ? (close_fn) dlsym(lib, "BZ2_bzclose") : NULL;
+    void *bz = bzopen && bzread && bzclose ? bzopen(path, "rb") : NULL;
+    FILE *tmp = bz != NULL ? tmpfile() : NULL;
+    char buf[1 << 15];
+    int got;
+    if (tmp == NULL) { if (bz != NULL) bzclose(bz); return NULL; }
+    while ((got = bzread(bz, buf, (int) sizeof buf)) > 0) fwrite(buf, 1, (size_t) got, tmp);
+    bzclose(bz);
     rewind(tmp);
     return tmp;
   }

@@ -144,7 +144,8 @@ def main():
         print(name, entry["tables"]["suf"]["md5"])
     # our own edge-case inputs (tests/golden/extra/), reference output
     extra_dir = os.path.join(OUT, "extra")
-    for name in sorted(f for f in os.listdir(extra_dir) if f.endswith((".fna", ".faa"))):
+    for name in sorted(f for f in os.listdir(extra_dir)
+                       if f.endswith((".fna", ".faa", ".fna.gz", ".fna.bz2"))):
         src = os.path.join(extra_dir, name)
         flag = "-protein" if name.endswith(".faa") else "-dna"
         with tempfile.TemporaryDirectory() as tmp:

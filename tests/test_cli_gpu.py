@@ -242,3 +242,69 @@ def test_cli_symbol_map_alphabets(cli, key, encoder, tmp_path):
     for ext, v in e["seqfiles"].items():
         with open(idx + "." + ext, "rb") as f:
             assert hashlib.md5(f.read()).hexdigest() == v["md5"], ext
+
+
+REF_CHECK = os.path.join(os.path.dirname(_lib.HERE), "oracle", "_ref", "gt_ref_check")
+
+
+def _reference_accepts(idx):
+    """oracle/_ref/gt_ref_check (built from the reference's sources by
+    oracle/Makefile.ref): gt_mapsuffixarray maps every file of the index, then
+    gt_suftab_lightweightcheck, gt_lcptab_lightweightcheck (Manzini's lcp9 from
+    the mapped suffix table against .lcp/.llv) and a .bwt check run over it"""
+    assert os.path.exists(REF_CHECK), "build oracle/_ref first (python -c 'import __graft_entry__ as g; g.build()')"
+    return subprocess.run([REF_CHECK, idx], capture_output=True, text=True)
+
+
+@pytest.mark.parametrize("name,extra", [
+    ("Atinsert.fna", []), ("Duplicate.fna", []), ("RandomN.fna", []), ("Reads1.fna", []),
+    ("sw100K1.fsa", []), ("extra/uint32_tables.fna", []), ("extra/long_runs.fna", []),
+    ("Atinsert.fna", ["-dir", "rcl"]), ("Duplicate.fna", ["-mirrored"]),
+    ("Atinsert.fna", ["-sat", "direct"]), ("ebola-genomes.fna.gz", []),
+])
+def test_reference_loads_and_verifies_our_index(cli, name, extra, tmp_path):
+    """the other direction of the drop-in: an index written here is mapped and
+    checked by the reference's own code"""
+    e = GOLDEN[name]
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-" + e["alphabet"], "-suf", "-lcp", "-bwt", "-indexname", idx, "-db",
+                    os.path.basename(src)] + extra, check=True, cwd=os.path.dirname(src))
+    r = _reference_accepts(idx)
+    assert r.returncode == 0, r.stderr + r.stdout
+    prj = dict(l.split("=") for l in open(idx + ".prj").read().splitlines())
+    assert r.stdout.startswith("ok totallength=%s " % prj["totallength"])
+
+
+def test_reference_checker_rejects_a_damaged_index(cli, tmp_path):
+    """(the checker does check: one wrong LCP value, one swapped pair of suffixes)"""
+    src = ou.fixture_path("Atinsert.fna")
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-indexname", idx, "-db",
+                    os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+    assert _reference_accepts(idx).returncode == 0
+    lcp = bytearray(open(idx + ".lcp", "rb").read())
+    lcp[1000] ^= 1
+    open(idx + ".lcp", "wb").write(bytes(lcp))
+    assert _reference_accepts(idx).returncode != 0
+    lcp[1000] ^= 1
+    open(idx + ".lcp", "wb").write(bytes(lcp))
+    suf = bytearray(open(idx + ".suf", "rb").read())
+    suf[8 * 500:8 * 501], suf[8 * 501:8 * 502] = suf[8 * 501:8 * 502], suf[8 * 500:8 * 501]
+    open(idx + ".suf", "wb").write(bytes(suf))
+    assert _reference_accepts(idx).returncode != 0
+
+
+def test_reference_verifies_a_large_index_from_the_device_reader(cli, tmp_path):
+    """8 Mbp human-like genome (separators, wildcard runs, repeats with LCPs in
+    the thousands): FASTA read on the device, all tables, checked by the
+    reference's mappers and lightweight checkers"""
+    from genometools_amd import synth
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 43, 8_000_000)
+    fasta = str(tmp_path / "h8m.fna")
+    synth.write_fasta(fasta, enc)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-bck", "-indexname", idx, "-db",
+                    "h8m.fna"], check=True, cwd=str(tmp_path))
+    r = _reference_accepts(idx)
+    assert r.returncode == 0, r.stderr + r.stdout

@@ -156,6 +156,7 @@ typedef struct {
   size_t file;           /* index of the file being read */
   fastq_record *rec;     /* FASTQ records so far (for the file length table) */
   size_t nrec, caprec;
+  bytebuf *orig;         /* original character of every symbol (-lossless), or NULL */
 } encstate;
 
 /* (multi-)FASTA, src/core/sequence_buffer_fasta.c:44-170 */
@@ -183,6 +184,7 @@ static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
           return -1;
         }
         if (bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
+        if (st->orig != NULL && bb_push(st->orig, 0) != 0) goto nomem;
         st->seqlen = 0;
         /* the separator in front of a file's first sequence is not counted
            for that file (sequence_buffer_fasta.c:133-146) */
@@ -199,6 +201,7 @@ static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
       return -1;
     }
     if (bb_push(st->out, st->map[c]) != 0) goto nomem;
+    if (st->orig != NULL && bb_push(st->orig, (uint8_t) c) != 0) goto nomem;
     st->seqlen++;
     added++;
     if (st->info != NULL) st->info->originaldistribution[c]++;
@@ -240,6 +243,7 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
       if (bb_push(st->desc, 0) != 0) goto nomem;
     }
     if (st->seen_record && bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
+    if (st->seen_record && st->orig != NULL && bb_push(st->orig, 0) != 0) goto nomem;
     st->seen_record = 1;
     for (; i < len && d[i] != '+'; i++) {
       const int c = d[i];
@@ -254,6 +258,7 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
         return -1;
       }
       if (bb_push(st->out, st->map[c]) != 0) goto nomem;
+      if (st->orig != NULL && bb_push(st->orig, (uint8_t) c) != 0) goto nomem;
       if (st->info != NULL) st->info->originaldistribution[c]++;
       nsym++;
     }
@@ -398,10 +403,21 @@ int gtamd_encode_files_alpha(const char *const *paths, size_t numfiles,
                              char **desc, uint64_t *desclen,
                              gtamd_encinfo *info, char *err, size_t errlen)
 {
+  return gtamd_encode_files_orig(paths, numfiles, a, enc, n, NULL, desc, desclen, info, err,
+                                 errlen);
+}
+
+int gtamd_encode_files_orig(const char *const *paths, size_t numfiles,
+                            const gtamd_alphabet *a, uint8_t **enc, uint64_t *n,
+                            uint8_t **orig, char **desc, uint64_t *desclen,
+                            gtamd_encinfo *info, char *err, size_t errlen)
+{
   uint8_t map[256];
+  bytebuf obuf = {NULL, 0, 0};
   bytebuf out = {NULL, 0, 0};
   bytebuf dbuf = {NULL, 0, 0};
-  encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0, info, 0, NULL, 0, 0};
+  encstate st = {map, &out, desc != NULL ? &dbuf : NULL, 0, 0, info, 0, NULL, 0, 0,
+                 orig != NULL ? &obuf : NULL};
   int last_was_fasta = 1, rc = 0;
 
   memcpy(map, a->symbolmap, 256);
@@ -453,10 +469,11 @@ int gtamd_encode_files_alpha(const char *const *paths, size_t numfiles,
     rc = -1;
   }
   if (rc != 0) {
-    free(out.p); free(dbuf.p); free(st.rec);
+    free(out.p); free(dbuf.p); free(st.rec); free(obuf.p);
     gtamd_encinfo_free(info);
     return -1;
   }
+  if (orig != NULL) *orig = obuf.p;
   if (info != NULL && st.nrec > 0)
     fastq_filelengths(st.rec, st.nrec, numfiles - 1, info->filelengthtab);
   free(st.rec);
@@ -564,8 +581,42 @@ int gtamd_write_md5(const char *indexname, const uint8_t *enc, uint64_t n,
   return gtamd_write_md5_alpha(indexname, enc, n, &a);
 }
 
+static int write_md5_show(const char *indexname, const uint8_t *enc, uint64_t n,
+                          const uint8_t *show);
+
+int gtamd_write_md5_orig(const char *indexname, const uint8_t *enc,
+                         const uint8_t *orig, uint64_t n)
+{
+  /* the sums over the original characters in upper case: the batch code works
+     on "symbols", so hand it the upper-cased originals with an identity map
+     (separators keep their code) */
+  uint8_t show[256], *up = malloc(n ? n : 1);
+  int rc;
+  if (up == NULL) return -1;
+  for (int c = 0; c < 256; c++) show[c] = (uint8_t) c;
+  for (uint64_t i = 0; i < n; i++)
+    up[i] = enc[i] == GTAMD_SEPARATOR ? (uint8_t) GTAMD_SEPARATOR
+                                      : (uint8_t) toupper(orig[i]);
+  rc = write_md5_show(indexname, up, n, show);
+  free(up);
+  return rc;
+}
+
 int gtamd_write_md5_alpha(const char *indexname, const uint8_t *enc, uint64_t n,
                           const gtamd_alphabet *a)
+{
+  uint8_t show[256];
+  /* decoded symbols in upper case; a wildcard decodes to the alphabet's
+     wildcard character (encseq_charproc.gen:27-36,55-66) */
+  memset(show, 0, sizeof show);
+  for (uint32_t c = 0; c < a->numofchars; c++)
+    show[c] = (uint8_t) toupper((unsigned char) a->characters[c]);
+  show[GTAMD_WILDCARD] = (uint8_t) toupper((unsigned char) a->wildcardshow);
+  return write_md5_show(indexname, enc, n, show);
+}
+
+static int write_md5_show(const char *indexname, const uint8_t *enc, uint64_t n,
+                          const uint8_t *show)
 {
   /* the sums of different sequences are independent: batches of sequences go
      to a few threads, longest-first order does not matter at this grain */
@@ -577,13 +628,6 @@ int gtamd_write_md5_alpha(const char *indexname, const uint8_t *enc, uint64_t n,
   long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
   int nthreads = ncpu < 1 ? 1 : ncpu > MAXTHREADS ? MAXTHREADS : (int) ncpu, rc = -1;
   FILE *fp = NULL;
-  uint8_t show[256];
-  /* decoded symbols in upper case; a wildcard decodes to the alphabet's
-     wildcard character (encseq_charproc.gen:27-36,55-66) */
-  memset(show, 0, sizeof show);
-  for (uint32_t c = 0; c < a->numofchars; c++)
-    show[c] = (uint8_t) toupper((unsigned char) a->characters[c]);
-  show[GTAMD_WILDCARD] = (uint8_t) toupper((unsigned char) a->wildcardshow);
   snprintf(path, sizeof path, "%s.md5", indexname);
   if (start == NULL || len == NULL || hex == NULL || (fp = fopen(path, "wb")) == NULL) goto done;
   while (pos <= n) {

@@ -240,7 +240,8 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
       an->ss.lengthofspecialprefix, an->ss.lengthofspecialsuffix, an->ss.wildcards,
       an->ss.wildcardranges, an->ss.realwildcardranges,
       an->ss.lengthofwildcardprefix, an->ss.lengthofwildcardsuffix,
-      an->lengthoflongestnonspecial, 0, 0, 0 };
+      an->lengthoflongestnonspecial,
+      info->exceptioncharacters, 0, info->realexceptionranges };   /* -lossless */
     put(&o, &is64bit, 1);
     put_word(&o, 3);                           /* format version */
     put_word(&o, (uint64_t) an->sat);

@@ -124,7 +124,8 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_esa_stats es;
   gtamd_esa_ctx *ctx;
   gtamd_encoder *de = NULL;
-  int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0;
+  int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0, lossless = 0;
+  uint8_t *orig = NULL;
   double t0 = now_s(), t_seq, t_build, t_create;
 
   for (int i = 1; i < argc; i++) {
@@ -183,8 +184,9 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     } else if (!strcmp(a, "-sat")) {
       if (i + 1 >= argc) return fail(err, errlen, "missing argument to option \"-%s\"", "sat");
       sat = argv[++i];
-    } else if (!strcmp(a, "-lossless") ||
-               !strcmp(a, "-plain") || !strcmp(a, "-kys") || !strcmp(a, "-lcpdist") ||
+    } else if (!strcmp(a, "-lossless")) {
+      lossless = yesno(argc, argv, &i);
+    } else if (!strcmp(a, "-plain") || !strcmp(a, "-kys") || !strcmp(a, "-lcpdist") ||
                !strcmp(a, "-compressedoutput") || !strcmp(a, "-genomediff") ||
                !strcmp(a, "-sortmaxdepth") || !strcmp(a, "-spmopt") ||
                !strcmp(a, "-swallow-tail") || !strcmp(a, "-onlybucketinsertion")) {
@@ -255,7 +257,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   }
   if (inputindex != NULL) {
     /* (read above) */
-  } else if (want != 0 && !host_encoder && !gtamd_input_is_fastq(db, numdb)) {
+  } else if (want != 0 && !host_encoder && !lossless && !gtamd_input_is_fastq(db, numdb)) {
     /* FASTA, tables requested: read and encode on the device; the symbols stay
        in HBM for the engine and come to the host only where a file needs them */
     if (gtamd_device_encode_files_alpha(db, numdb, &alpha, &de, &desc, &desclen, &info, err, errlen) != 0)
@@ -287,8 +289,14 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       else { free(enc); enc = NULL; }
     }
   } else {
-    if (gtamd_encode_files_alpha(db, numdb, &alpha, &enc, &n, &desc, &desclen, &info, err, errlen) != 0)
+    if (gtamd_encode_files_orig(db, numdb, &alpha, &enc, &n, lossless ? &orig : NULL, &desc,
+                                &desclen, &info, err, errlen) != 0)
       return -1;
+    /* -lossless: the exception table first, its counts go into INDEX.esq */
+    if (lossless && gtamd_write_ois(indexname, enc, orig, n, &alpha, &info, err, errlen) != 0) {
+      free(enc); free(orig); free(desc); gtamd_encinfo_free(&info);
+      return -1;
+    }
     /* the encoded sequence itself, in the reference's format (always written:
        -tis is kept for backwards compatibility only, src/match/sfx-opt.c) */
     if (gtamd_write_esq_alpha(indexname, db, numdb, enc, n, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
@@ -303,10 +311,13 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);
     }
     free(desc);
-    if (out_md5 && gtamd_write_md5_alpha(indexname, enc, n, &alpha) != 0) {
-      free(enc);
+    if (out_md5 && (lossless ? gtamd_write_md5_orig(indexname, enc, orig, n)
+                             : gtamd_write_md5_alpha(indexname, enc, n, &alpha)) != 0) {
+      free(enc); free(orig);
       return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
     }
+    free(orig);
+    orig = NULL;
     /* (.prj describes the sequence as stored, the tables the sequence as read) */
   }
   if (mirrored) {

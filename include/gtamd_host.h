@@ -82,6 +82,8 @@ typedef struct {
   uint64_t originaldistribution[256];
   gtamd_filelength *filelengthtab;      /* numfiles entries, malloc'ed */
   size_t numfiles;
+  uint64_t exceptioncharacters,         /* -lossless: set by gtamd_write_ois, go */
+           realexceptionranges;         /* into the header of INDEX.esq          */
 } gtamd_encinfo;
 
 int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
@@ -89,6 +91,23 @@ int gtamd_encode_files_info(const char *const *paths, size_t numfiles,
                             char **desc, uint64_t *desclen,
                             gtamd_encinfo *info, char *err, size_t errlen);
 void gtamd_encinfo_free(gtamd_encinfo *info);
+
+/* -lossless (src/core/encseq_api.h:276-286): the reader also returns the
+   original character of every symbol (0 for separators; *orig malloc'ed);
+   gtamd_write_ois writes INDEX.ois -- most frequent original character per
+   symbol class, the classes' character lists, and the bit-packed list of
+   "exceptions" with their runs (src/core/encseq.c:1018-1078, 5275-5419) -- and
+   stores the exception counts in *info for INDEX.esq; the MD5 sums are taken
+   over the original characters (encseq_charproc.gen:30-36). */
+int gtamd_encode_files_orig(const char *const *paths, size_t numfiles,
+                            const gtamd_alphabet *a, uint8_t **enc, uint64_t *n,
+                            uint8_t **orig, char **desc, uint64_t *desclen,
+                            gtamd_encinfo *info, char *err, size_t errlen);
+int gtamd_write_ois(const char *indexname, const uint8_t *enc, const uint8_t *orig,
+                    uint64_t n, const gtamd_alphabet *a, gtamd_encinfo *info,
+                    char *err, size_t errlen);
+int gtamd_write_md5_orig(const char *indexname, const uint8_t *enc,
+                         const uint8_t *orig, uint64_t n);
 
 /* The functions of this header that take `int protein` have a twin ending in
    _alpha that takes any alphabet instead. */
@@ -204,14 +223,14 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
 
 /* `gt suffixerator` for the option subset of this path:
      -db FILE... | -ii INDEX  -indexname NAME  -dna | -protein
-     -suf -lcp -bwt -bck  -suftabuint  -sat TYPE  -smap FILE
+     -suf -lcp -bwt -bck  -suftabuint  -sat TYPE  -smap FILE  -lossless
      -pl [K]  -v  -dir fwd|rev|cpl|rcl  -mirrored  -clipdesc  and, accepted
      without effect on the tables (strategy knobs of the CPU algorithm),
      -parts N  -memlimit X  -dc V  -algbds A B C  -maxwidthrealmedian W
      -cmpcharbychar -dccheck -iterscan -kmerswithencseqreader -noshortreadsort
      -samplewithprefixlengthnull -storespecialcodes -withradixsort
      -showprogress -tis [yes|no];
-     -lossless -plain -kys -lcpdist -compressedoutput -genomediff
+     -plain -kys -lcpdist -compressedoutput -genomediff
      -sortmaxdepth -spmopt -swallow-tail -onlybucketinsertion change what is
      written and are refused ("option \"-X\" is not supported ...").
    -des -sds -md5 -ssp [yes|no] select the sequence-side files; INDEX.esq is

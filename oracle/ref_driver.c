@@ -19,7 +19,7 @@
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
   usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
-                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint] [-clipdesc] [-smap FILE]
+                    [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint] [-clipdesc] [-smap FILE] [-lossless]
                     -db FASTA... -indexname IDX [-time]
 */
 #include <stdio.h>
@@ -69,7 +69,7 @@ int main(int argc, char **argv)
   int numdb = 0;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
        showtime = false, haserr = false, mirrored = false, want_bck = false,
-       suftabuint = false, clipdesc = false;
+       suftabuint = false, clipdesc = false, lossless = false;
   GtReadmode readmode = GT_READMODE_FORWARD;
   unsigned int userpl = 0, dc = 0, prefixlength, numofchars;
   int i;
@@ -96,6 +96,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-bck")) want_bck = true;
     else if (!strcmp(argv[i], "-suftabuint")) suftabuint = true;
     else if (!strcmp(argv[i], "-clipdesc")) clipdesc = true;
+    else if (!strcmp(argv[i], "-lossless")) lossless = true;
     else if (!strcmp(argv[i], "-mirrored")) mirrored = true;
     else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
       const char *d = argv[++i];
@@ -146,6 +147,7 @@ int main(int argc, char **argv)
   else if (dna) gt_encseq_encoder_set_input_dna(ee);
   else gt_encseq_encoder_set_input_protein(ee);
   if (clipdesc) gt_encseq_encoder_clip_desc(ee);   /* -clipdesc, encseq_options.c */
+  if (lossless) gt_encseq_encoder_enable_lossless_support(ee);   /* -lossless */
   if (sat != NULL) {
     /* -sat of src/core/encseq_options.c: force an access type */
     if (gt_encseq_encoder_use_representation(ee, sat, err) != 0) {

@@ -75,6 +75,10 @@ SMAP_CASES = [("trans_dna.map", "Atinsert.fna"), ("trans_dna.map", "Duplicate.fn
               ("trans_dna.map", "extra/lowercase_iupac.fna"),
               ("prot5.map", "sw100K1.fsa"), ("prot5.map", "extra/protein_specials.faa"),
               ("prot5.map", "extra/protein_long_x.faa")]
+LOSSLESS_FILES = ["Atinsert.fna", "Duplicate.fna", "RandomN.fna", "TTTN.fna", "Reads1.fna",
+                  "extra/lowercase_iupac.fna", "extra/lowercase_across_records.fna",
+                  "extra/long_runs.fna", "extra/protein_specials.faa", "sw100K1.fsa",
+                  "test10_multiline.fastq", "ebola-genomes.fna.gz"]
 MAX_FIXTURE = 120 * 1024     # bigger inputs: md5 of tables only, no copy
 MAX_TABLES = 16 * 1024       # store full tables only for small inputs
 
@@ -236,6 +240,22 @@ def main():
         smap["%s|%s" % (mapname, name)] = entry
     with open(os.path.join(OUT, "golden_smap.json"), "w") as f:
         json.dump(smap, f, indent=1, sort_keys=True)
+    # -lossless: INDEX.ois, exception counts in INDEX.esq, MD5 over the originals
+    lossless = {}
+    for name in LOSSLESS_FILES:
+        src = (os.path.join(OUT, name) if name.startswith("extra/")
+               else os.path.join(REF, "testdata", name))
+        flag = "-protein" if name.endswith((".faa", ".fsa")) else "-dna"
+        with tempfile.TemporaryDirectory() as tmp:
+            idx = os.path.join(tmp, "idx")
+            subprocess.run([BIN, flag, "-lossless", "-indexname", idx, "-db",
+                            os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+            lossless[name] = {ext: {"md5": md5(idx + "." + ext),
+                                    "bytes": os.path.getsize(idx + "." + ext)}
+                              for ext in ("ois", "esq", "md5", "des", "sds", "ssp")
+                              if os.path.exists(idx + "." + ext)}
+    with open(os.path.join(OUT, "golden_lossless.json"), "w") as f:
+        json.dump(lossless, f, indent=1, sort_keys=True)
     # -clipdesc: descriptions cut at the first white space
     clip = {}
     for name in CLIPDESC_FILES:

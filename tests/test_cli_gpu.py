@@ -308,3 +308,26 @@ def test_reference_verifies_a_large_index_from_the_device_reader(cli, tmp_path):
                     "h8m.fna"], check=True, cwd=str(tmp_path))
     r = _reference_accepts(idx)
     assert r.returncode == 0, r.stderr + r.stdout
+
+
+LOSSLESS = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_lossless.json")))
+
+
+@pytest.mark.parametrize("name", ["Atinsert.fna", "extra/lowercase_across_records.fna",
+                                  "sw100K1.fsa"])
+def test_cli_lossless_with_tables(cli, name, tmp_path):
+    """-lossless (host reader) together with a table build: the exception table
+    and sequence files of the reference, the usual tables, and the reference's
+    loader still accepts the index"""
+    e = GOLDEN[name]
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-" + e["alphabet"], "-lossless", "-suf", "-lcp", "-bwt", "-indexname",
+                    idx, "-db", os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+    for ext, v in LOSSLESS[name].items():
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == v["md5"], ext
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    assert _reference_accepts(idx).returncode == 0

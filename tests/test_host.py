@@ -592,3 +592,23 @@ def test_symbol_map_errors(host, tmp_path):
     rc, msg = _run_tool(host, "-smap", os.path.join(ou.GOLDEN_DIR, "extra", "prot5.map"), "-dir",
                         "rcl", "-indexname", idx, "-db", ou.fixture_path("extra/protein_specials.faa"))
     assert rc == -1 and msg == "option -rcl only can be used for DNA alphabets"
+
+
+LOSSLESS = __import__("json").load(open(os.path.join(ou.GOLDEN_DIR, "golden_lossless.json")))
+
+
+@pytest.mark.parametrize("name", sorted(LOSSLESS))
+def test_tool_lossless_matches_reference(host, name, tmp_path):
+    """-lossless: INDEX.ois (exception table), the exception counts in the
+    header of INDEX.esq and INDEX.md5 over the original characters"""
+    import hashlib
+    src = ou.fixture_path(name)
+    idx = str(tmp_path / "idx")
+    flag = "-protein" if GOLDEN[name]["alphabet"] == "protein" else "-dna"
+    assert _run_tool(host, flag, "-lossless", "-indexname", idx, "-db", os.path.basename(src),
+                     cwd=os.path.dirname(src)) == (0, "")
+    for ext, v in LOSSLESS[name].items():
+        raw = open(idx + "." + ext, "rb").read()
+        assert len(raw) == v["bytes"], ext
+        assert hashlib.md5(raw).hexdigest() == v["md5"], ext
+    assert os.path.exists(idx + ".ois")

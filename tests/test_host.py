@@ -26,7 +26,9 @@ class SeqStats(ctypes.Structure):
 
 class EncInfo(ctypes.Structure):           # gtamd_encinfo, include/gtamd_host.h
     _fields_ = [("originaldistribution", ctypes.c_uint64 * 256),
-                ("filelengthtab", ctypes.c_void_p), ("numfiles", ctypes.c_size_t)]
+                ("filelengthtab", ctypes.c_void_p), ("numfiles", ctypes.c_size_t),
+                ("exceptioncharacters", ctypes.c_uint64),
+                ("realexceptionranges", ctypes.c_uint64)]
 
 
 @pytest.fixture(scope="module")
@@ -485,7 +487,7 @@ def test_tool_strategy_switches_are_accepted_and_output_switches_refused(host, t
                      "-iterscan", "no", "-parts", "2", "-memlimit", "1GB",
                      "-showprogress", "no", "-dccheck") == (0, "")
     assert open(a + ".prj").read() == open(b + ".prj").read()
-    for opt in ("-lossless", "-plain", "-kys", "-lcpdist",
+    for opt in ("-plain", "-kys", "-lcpdist",
                 "-compressedoutput", "-genomediff", "-sortmaxdepth", "-spmopt"):
         rc, msg = _run_tool(host, "-dna", "-indexname", a, "-db", src, opt)
         assert rc == -1 and msg == 'option "%s" is not supported by the MI355X engine' % opt

@@ -649,7 +649,8 @@ static int encode_files(gtamd_encoder *e, u8 *d_raw, u8 *d_lut, u32 *d_tile,
 static int summarise(gtamd_encoder *e) {
   const u64 n = e->n, ntiles = div_up(n, EN_TILE);
   if (n == 0) {
-    gtamd_set_error("file '%s' contains an empty sequence", e->files.back().name.c_str());
+    gtamd_set_error("file '%s' contains an empty sequence",
+                    e->files.empty() ? "(symbols)" : e->files.back().name.c_str());
     return -1;
   }
   RunSum<u32> *d_tiles;
@@ -676,6 +677,10 @@ static int summarise(gtamd_encoder *e) {
   if (rc != 0) { gtamd_set_error("device statistics of the encoded sequence failed"); return -1; }
   if (small[32] != NONE64) {
     // the file whose '>' produced the offending separator (or the last one)
+    if (e->files.empty()) {
+      gtamd_set_error("the sequence contains an empty sequence");
+      return -1;
+    }
     size_t fi = e->files.size() - 1;
     for (size_t k = 0; k < e->files.size(); k++)
       if (small[32] >= e->files[k].out_start &&
@@ -772,6 +777,39 @@ extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
   if (d_ws) (void) hipFree(d_ws);
   if (d_glob) (void) hipFree(d_glob);
   if (rc != 0) { enc_free(e); e->n = 0; e->ndesc = 0; return -1; }
+  e->finished = true;
+  return 0;
+}
+
+extern "C" int gtamd_encoder_set_symbols(gtamd_encoder *e, const uint8_t *symbols,
+                                         uint64_t n) {
+  if (e == nullptr || (symbols == nullptr && n > 0)) {
+    gtamd_set_error("invalid argument to gtamd_encoder_set_symbols");
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  enc_free(e);
+  e->finished = false;
+  e->files.clear();
+  memset(&e->sum, 0, sizeof e->sum);
+  e->input_bytes = n;
+  e->ndesc = 0;
+  if (dev_alloc(&e->d_enc, n + EN_TILE) != 0) return -1;
+  e->cap_enc = n + EN_TILE;
+  e->n = n;
+  (void) hipEventRecord(e->ev[0], e->st);
+  if (n > 0 && hipMemcpyAsync(e->d_enc, symbols, n, hipMemcpyHostToDevice, e->st) != hipSuccess) {
+    gtamd_set_error("cannot copy %llu symbols to the device", (unsigned long long) n);
+    enc_free(e);
+    return -1;
+  }
+  (void) hipEventRecord(e->ev[1], e->st);
+  if (summarise(e) != 0) { enc_free(e); e->n = 0; return -1; }
+  (void) hipEventRecord(e->ev[2], e->st);
+  HIP_TRY(hipStreamSynchronize(e->st));
+  (void) hipEventElapsedTime(&e->parse_ms, e->ev[0], e->ev[1]);
+  (void) hipEventElapsedTime(&e->stats_ms, e->ev[1], e->ev[2]);
+  (void) hipEventElapsedTime(&e->total_ms, e->ev[0], e->ev[2]);
   e->finished = true;
   return 0;
 }

@@ -125,6 +125,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   gtamd_esa_ctx *ctx;
   gtamd_encoder *de = NULL;
   int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0, lossless = 0;
+  const char *reader = "host";
   uint8_t *orig = NULL;
   double t0 = now_s(), t_seq, t_build, t_create;
 
@@ -256,10 +257,11 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
                 mirrored ? "mirrored" : (readmode == 2 ? "cpl" : "rcl"));
   }
   if (inputindex != NULL) {
-    /* (read above) */
+    reader = "index";   /* (read above) */
   } else if (want != 0 && !host_encoder && !lossless && !gtamd_input_is_fastq(db, numdb)) {
     /* FASTA, tables requested: read and encode on the device; the symbols stay
        in HBM for the engine and come to the host only where a file needs them */
+    reader = "device";
     if (gtamd_device_encode_files_alpha(db, numdb, &alpha, &de, &desc, &desclen, &info, err, errlen) != 0)
       return -1;
     n = gtamd_encoder_length(de);
@@ -298,27 +300,47 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
       return -1;
     }
     /* the encoded sequence itself, in the reference's format (always written:
-       -tis is kept for backwards compatibility only, src/match/sfx-opt.c) */
-    if (gtamd_write_esq_alpha(indexname, db, numdb, enc, n, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
-      free(enc); free(desc); gtamd_encinfo_free(&info);
+       -tis is kept for backwards compatibility only, src/match/sfx-opt.c).
+       With tables to build a device is needed anyway: then the symbols of the
+       host reader go there at once, and statistics and the sections of
+       INDEX.esq come from the device as with the device reader. */
+    if (want != 0) {
+      de = gtamd_encoder_create_map(0, alpha.symbolmap, alpha.numofchars, alpha.bitspersymbol);
+      if (de == NULL || gtamd_encoder_set_symbols(de, enc, n) != 0) {
+        snprintf(err, errlen, "%s", gtamd_esa_last_error());
+        free(enc); free(orig); free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
+        return -1;
+      }
+    }
+    if ((de != NULL ? gtamd_write_esq_device_alpha(indexname, db, numdb, de, &alpha, &info,
+                                                   out_ssp, sat, &ss, err, errlen)
+                    : gtamd_write_esq_alpha(indexname, db, numdb, enc, n, &alpha, &info, out_ssp,
+                                            sat, &ss, err, errlen)) != 0) {
+      free(enc); free(orig); free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
       return -1;
     }
     gtamd_encinfo_free(&info);
     /* the sequence-side files describe the sequence as stored (before -dir) */
     if (clipdesc) gtamd_clip_descriptions(desc, &desclen);
     if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
-      free(enc); free(desc);
+      free(enc); free(orig); free(desc); gtamd_encoder_destroy(de);
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);
     }
     free(desc);
     if (out_md5 && (lossless ? gtamd_write_md5_orig(indexname, enc, orig, n)
                              : gtamd_write_md5_alpha(indexname, enc, n, &alpha)) != 0) {
-      free(enc); free(orig);
+      free(enc); free(orig); gtamd_encoder_destroy(de);
       return fail(err, errlen, "cannot write md5 file of index '%s'", indexname);
     }
     free(orig);
     orig = NULL;
-    /* (.prj describes the sequence as stored, the tables the sequence as read) */
+    /* (.prj describes the sequence as stored, the tables the sequence as read)
+       -dir / -mirrored transform host symbols; otherwise the engine reads the
+       device copy */
+    if (de != NULL) {
+      if (mirrored || readmode != 0) { gtamd_encoder_destroy(de); de = NULL; }
+      else { free(enc); enc = NULL; }
+    }
   }
   if (mirrored) {
     uint8_t *m = gtamd_mirror(enc, n);
@@ -398,7 +420,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     (void) gtamd_esa_get_timing(ctx, &tm);
     printf("# seconds: input, encoding and sequence files (%s reader) %.3f; tables on the "
            "device %.3f (workspace %.3f, kernels %.3f); tables to files %.3f\n",
-           de != NULL ? "device" : "host", t_seq, t_build, t_create, tm.total_ms / 1e3,
+           reader, t_seq, t_build, t_create, tm.total_ms / 1e3,
            now_s() - t0 - t_seq - t_build);
   }
   rc = 0;

@@ -69,6 +69,12 @@ int gtamd_encoder_add_file(gtamd_encoder *enc, const char *name,
 /* Encode all files added so far into one sequence. */
 int gtamd_encoder_finish(gtamd_encoder *enc);
 
+/* Instead of add_file/finish: n already encoded symbols from host memory (the
+   host reader's output, e.g. of FASTQ input) become the encoder's sequence;
+   summary (without the original-character histogram) and the INDEX.esq
+   sections are then available as after gtamd_encoder_finish. */
+int gtamd_encoder_set_symbols(gtamd_encoder *enc, const uint8_t *symbols, uint64_t n);
+
 uint64_t gtamd_encoder_length(const gtamd_encoder *enc);
 /* the symbols in device memory (valid until destroy), e.g. for
    gtamd_esa_set_sequence_bytes(ctx, ptr, n, 1) */

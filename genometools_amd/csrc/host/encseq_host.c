@@ -47,6 +47,18 @@ static int bb_push(bytebuf *b, uint8_t c)
   return 0;
 }
 
+/* room for `more` further bytes, so that a hot loop can store without checks */
+static int bb_reserve(bytebuf *b, uint64_t more)
+{
+  if (b->cap - b->len < more) {
+    uint64_t ncap = b->len + more + (more >> 3) + 64;
+    uint8_t *np = realloc(b->p, ncap);
+    if (np == NULL) return -1;
+    b->p = np; b->cap = ncap;
+  }
+  return 0;
+}
+
 static int is_blank(int c)
 {
   return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f';
@@ -160,58 +172,90 @@ typedef struct {
 } encstate;
 
 /* (multi-)FASTA, src/core/sequence_buffer_fasta.c:44-170 */
+static uint64_t line_of(const unsigned char *d, size_t upto)
+{
+  uint64_t line = 1;
+  for (const unsigned char *p = d, *end = d + upto;
+       (p = memchr(p, '\n', (size_t) (end - p))) != NULL; p++)
+    line++;
+  return line;
+}
+
 static int parse_fasta(encstate *st, const char *path, const unsigned char *d,
                        size_t len, char *err, size_t errlen)
 {
-  uint64_t line = 1, added = 0;
-  int in_header = 0, first_in_file = 1;
-  for (size_t i = 0; i < len; i++) {
+  /* byte classes of the sequence state: symbol, blank, '>', anything else */
+  enum { C_SYMBOL = 0, C_BLANK, C_HEADER, C_ILLEGAL };
+  uint8_t cls[256];
+  uint64_t hist[4][256], separators_counted = 0;
+  const uint64_t out0 = st->out->len;
+  uint64_t seqstart = st->out->len - st->seqlen;     /* first symbol of the open sequence */
+  int first_in_file = 1;
+  size_t i = 0;
+  /* a file contributes at most one symbol per byte */
+  if (bb_reserve(st->out, len + 1) != 0 || (st->orig != NULL && bb_reserve(st->orig, len + 1) != 0))
+    goto nomem;
+  memset(hist, 0, sizeof hist);
+  for (int c = 0; c < 256; c++)
+    cls[c] = is_blank(c) ? C_BLANK : c == '>' ? C_HEADER
+           : st->map[c] == SYM_UNDEF ? C_ILLEGAL : C_SYMBOL;
+  while (i < len) {
     const int c = d[i];
-    if (in_header) {
-      if (c == '\n') {
-        line++; in_header = 0;
-        if (st->desc != NULL && bb_push(st->desc, 0) != 0) goto nomem;
-      } else if (c != '\r' && st->desc != NULL && bb_push(st->desc, (uint8_t) c) != 0)
-        goto nomem;
-      continue;
-    }
-    if (c == '\n') line++;
-    if (is_blank(c)) continue;
-    if (c == '>') {
+    const uint8_t k = cls[c];
+    if (k == C_SYMBOL) {
+      st->out->p[st->out->len++] = st->map[c];
+      if (st->orig != NULL) st->orig->p[st->orig->len++] = (uint8_t) c;
+      hist[i & 3][c]++;     /* four tables: no store-to-load chain on one counter */
+      i++;
+    } else if (k == C_BLANK) i++;
+    else if (k == C_HEADER) {
+      const unsigned char *nl;
       if (st->seen_record) {
-        if (st->seqlen == 0) {
+        if (st->out->len == seqstart) {
           snprintf(err, errlen, "file '%s' contains an empty sequence", path);
           return -1;
         }
-        if (bb_push(st->out, GTAMD_SEPARATOR) != 0) goto nomem;
-        if (st->orig != NULL && bb_push(st->orig, 0) != 0) goto nomem;
-        st->seqlen = 0;
+        st->out->p[st->out->len++] = GTAMD_SEPARATOR;
+        if (st->orig != NULL) st->orig->p[st->orig->len++] = 0;
+        seqstart = st->out->len;
         /* the separator in front of a file's first sequence is not counted
            for that file (sequence_buffer_fasta.c:133-146) */
-        if (!first_in_file) added++;
+        if (!first_in_file) separators_counted++;
       }
       st->seen_record = 1;
       first_in_file = 0;
-      in_header = 1;
-      continue;
-    }
-    if (st->map[c] == SYM_UNDEF) {
+      /* the description runs to the end of the line (or of the file) */
+      i++;
+      nl = memchr(d + i, '\n', len - i);
+      {
+        const size_t end = nl != NULL ? (size_t) (nl - d) : len;
+        if (st->desc != NULL) {
+          for (size_t q = i; q < end; q++)
+            if (d[q] != '\r' && bb_push(st->desc, d[q]) != 0) goto nomem;
+          if (nl != NULL && bb_push(st->desc, 0) != 0) goto nomem;
+        }
+        i = nl != NULL ? end + 1 : len;
+      }
+    } else {
       snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu", c,
-               path, (unsigned long long) line);
+               path, (unsigned long long) line_of(d, i));
       return -1;
     }
-    if (bb_push(st->out, st->map[c]) != 0) goto nomem;
-    if (st->orig != NULL && bb_push(st->orig, (uint8_t) c) != 0) goto nomem;
-    st->seqlen++;
-    added++;
-    if (st->info != NULL) st->info->originaldistribution[c]++;
   }
+  st->seqlen = st->out->len - seqstart;
   if (st->info != NULL) {
+    uint64_t symbols = 0;
+    for (int c = 0; c < 256; c++) {
+      const uint64_t h = hist[0][c] + hist[1][c] + hist[2][c] + hist[3][c];
+      st->info->originaldistribution[c] += h;
+      symbols += h;
+    }
     /* bytes read / symbols and separators contributed by this file
        (sequence_buffer_fasta.c:86-94,104,144,156) */
     st->info->filelengthtab[st->file].length = len;
-    st->info->filelengthtab[st->file].effectivelength = added;
+    st->info->filelengthtab[st->file].effectivelength = symbols + separators_counted;
   }
+  (void) out0;
   return 0;
 nomem:
   snprintf(err, errlen, "out of memory while reading '%s'", path);
@@ -225,7 +269,13 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
                        size_t len, char *err, size_t errlen)
 {
   size_t i = 0;
-  uint64_t line = 1;
+  uint64_t line = 1, hist[4][256];
+  uint8_t cls[256];                /* 0 symbol, 1 skipped ('\n', ' '), 2 illegal */
+  if (bb_reserve(st->out, len + 1) != 0 || (st->orig != NULL && bb_reserve(st->orig, len + 1) != 0))
+    goto nomem;
+  memset(hist, 0, sizeof hist);
+  for (int c = 0; c < 256; c++)
+    cls[c] = c == '\n' || c == ' ' ? 1 : st->map[c] == SYM_UNDEF ? 2 : 0;
   while (i < len) {
     size_t name0, name1, nsym = 0, nq = 0, q0, q1;
     if (d[i] != '@') {
@@ -247,20 +297,22 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
     st->seen_record = 1;
     for (; i < len && d[i] != '+'; i++) {
       const int c = d[i];
-      if (c == '\n') { line++; continue; }
-      if (c == ' ') continue;
-      if (st->map[c] == SYM_UNDEF) {
+      const uint8_t k = cls[c];
+      if (k == 0) {                          /* a symbol */
+        st->out->p[st->out->len++] = st->map[c];
+        if (st->orig != NULL) st->orig->p[st->orig->len++] = (uint8_t) c;
+        hist[i & 3][c]++;
+        nsym++;
+      } else if (k == 1) {                   /* line end or blank */
+        if (c == '\n') line++;
+      } else {
         /* the reference maps the sequence after it has read it completely */
         uint64_t l2 = line;
-        for (size_t k = i; k < len && d[k] != '+'; k++) l2 += d[k] == '\n';
+        for (size_t q = i; q < len && d[q] != '+'; q++) l2 += d[q] == '\n';
         snprintf(err, errlen, "illegal character '%c': file \"%s\", line %llu", c,
                  path, (unsigned long long) l2);
         return -1;
       }
-      if (bb_push(st->out, st->map[c]) != 0) goto nomem;
-      if (st->orig != NULL && bb_push(st->orig, (uint8_t) c) != 0) goto nomem;
-      if (st->info != NULL) st->info->originaldistribution[c]++;
-      nsym++;
     }
     if (i >= len) goto premature;
     if (nsym == 0) {
@@ -277,6 +329,12 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
                "description '%.*s' in line %llu", (int) (name1 - name0), d + name0,
                (int) (q1 - q0), d + q0, (unsigned long long) (line - 1));
       return -1;
+    }
+    /* the usual layout: all qualities on one line */
+    if (i + nsym < len && d[i + nsym] == '\n' && memchr(d + i, '\n', nsym) == NULL &&
+        memchr(d + i, ' ', nsym) == NULL) {
+      i += nsym;
+      nq = nsym;
     }
     while (nq < nsym) {
       if (i >= len) {
@@ -313,6 +371,9 @@ static int parse_fastq(encstate *st, const char *path, const unsigned char *d,
       st->nrec++;
     }
   }
+  if (st->info != NULL)
+    for (int c = 0; c < 256; c++)
+      st->info->originaldistribution[c] += hist[0][c] + hist[1][c] + hist[2][c] + hist[3][c];
   return 0;
 premature:
   snprintf(err, errlen, "premature end of file '%s' in line %llu: file ended before "

@@ -144,6 +144,16 @@ def load():
             raise RuntimeError(
                 "%s is missing: run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (needs hipcc); there is no CPU fallback" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP/HSA runtime next to the system one
+        # this library links.  Both work in one process only when torch's
+        # copy is mapped first (measured on the MI355X box: the other order
+        # leaves torch with "No HIP GPUs are available"), so a Python process
+        # that may use torch for device buffers or torch.distributed gets
+        # torch imported here, before the library.  C callers are unaffected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in ABI.items():
             fn = getattr(lib, name)

@@ -901,12 +901,16 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     Stats *stats, const u32 *__restrict__ rank, u64 h, u64 n) {
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
   // of reading a k2 array (which a part build fills through the exchange)
+  // 28 KB of LDS, so that five workgroups share a CU (the rank lookups below
+  // are latency-bound random reads: more waves in flight hide more of it).
+  // The group numbers and second keys are only needed until the sort keys are
+  // built, so they are staged in the memory of the keys themselves.
   __shared__ u64 s_key[RT_TILE];
-  __shared__ u32 s_k2[RT_TILE];
-  __shared__ u32 s_grp[RT_TILE + 1];
   __shared__ u32 s_pos[RT_TILE];
   __shared__ u16 s_start[RT_TILE + 2];   // first slot of each local group
   __shared__ u32 s_scan[4];
+  u32 *s_grp = reinterpret_cast<u32 *>(s_key);
+  u32 *s_k2 = s_grp + RT_TILE;
   const int tid = threadIdx.x;
   const u64 base = (u64) blockIdx.x * RT_TILE;
   const u32 cnt = (u32) ((m - base) < (u64) RT_TILE ? (m - base) : (u64) RT_TILE);
@@ -934,36 +938,48 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     }
   }
   __syncthreads();
-  // local group numbers: inclusive count of group starts, thread owns 8
-  // consecutive slots
+  // from here on a thread owns 8 consecutive slots; it takes their group
+  // numbers and second keys into registers before the keys overwrite them
+  u32 gr[RT_PER], kr[RT_PER];
+  u32 kprev = tid > 0 ? s_k2[(u32) tid * RT_PER - 1] : 0u;
+  u32 gprev = tid > 0 ? s_grp[(u32) tid * RT_PER - 1] : 0u;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    gr[c] = s_grp[(u32) tid * RT_PER + c];
+    kr[c] = s_k2[(u32) tid * RT_PER + c];
+  }
+  // local group numbers: inclusive count of group starts
   u32 startflags = 0, nstart = 0;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) tid * RT_PER + c;
-    const bool st = e == 0 || s_grp[e] != s_grp[e - 1];
+    const bool st = e == 0 || gr[c] != gprev;
+    gprev = gr[c];
     startflags |= (u32) st << c;
     nstart += st;
   }
   u32 tot;
+  // (the barriers inside the scan also end the staging area's first life)
   u32 lg = block_scan_excl_sum(nstart, &tot, s_scan);
   u32 nflag = 0;
   // does any group of this tile split in this round?  (inside a long repeat
   // most rounds leave a group as it is: every member's k2 is the same)
   int splits = 0;
-  u32 kprev = tid > 0 ? s_k2[(u32) tid * RT_PER - 1] : 0u;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) tid * RT_PER + c;
     const bool start = (startflags >> c) & 1u;
     lg += start;
-    const u32 g = s_grp[e];
+    const u32 g = gr[c];
     const bool open = e < cnt && ((first_open && g == g_first) ||
                                   (last_open && g == g_last));
-    const u32 kraw = s_k2[e];
+    const u32 kraw = kr[c];
     const u32 kk = open ? 0u : kraw;
     splits |= (e < cnt && !open && !start && kraw != kprev);
     kprev = kraw;
-    s_key[e] = ((u64) lg << 43) | ((u64) kk << 11) | (u64) e;
+    // local group | deferred | k2 | slot: a group is deferred as a whole, so
+    // the flag bit never reorders anything
+    s_key[e] = ((u64) lg << 44) | ((u64) open << 43) | ((u64) kk << 11) | (u64) e;
     if (e < cnt) flg[base + e] = open;
     if (open && rank != nullptr) k2[base + e] = kraw;   // for the global path
     nflag += open;
@@ -990,8 +1006,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       for (int c = RT_PER - 1; c >= 0; c--) {
         const u32 e = (u32) tid * RT_PER + c;
         if ((startflags >> c) & 1u) {
-          const u32 g = s_grp[e];
-          const bool open = (first_open && g == g_first) || (last_open && g == g_last);
+          const bool open = (s_key[e] >> 43) & 1u;
           if (e < cnt && !open) {
             const u32 size = (u32) s_start[lgw + 1] - e;
             gmax = size > gmax ? size : gmax;
@@ -1062,8 +1077,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     if (e < cnt) {
       const u64 key = s_key[e];
       const u32 src = (u32) (key & 2047u);
-      const u32 g = s_grp[src];
-      const bool open = (first_open && g == g_first) || (last_open && g == g_last);
+      const bool open = (key >> 43) & 1u;
       if (!open) {
         cv[base + e] = s_pos[src];
         hv[base + e] = carry;
@@ -2064,7 +2078,11 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       // (Measured at 3 Gbp: direct scatter 120 ms; 256 windows 61 ms + 23 ms
       // for the pass; 4096 windows 53 ms + 38 ms; 4096 windows pinned to XCDs
       // (each window written inside one L2) no better -- the gain is TLB
-      // reach, not L2 residency, so the single pass wins.)
+      // reach, not L2 residency, so the single pass wins.  Two 8-bit passes
+      // (65 536 windows of 256 KB, each written by neighbouring workgroups):
+      // scatter 59 instead of 68 ms, but the second pass costs 17 -- the
+      // scatter is bound by the number of 4-byte store transactions, which
+      // only an LDS-staged window would remove.)
       const int nbp = bits_for(N - 1);
       const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
       TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,

@@ -257,93 +257,98 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-template <typename K, typename V, int XCD>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
+// The kernel is VALU-bound (a wave64 instruction occupies its 16-lane SIMD for
+// four cycles; ISA count x 4 cycles accounts for the measured time), so the
+// ranking is written for instruction count:
+//  * the lanes with the same digit are  m &= ~(ballot(bit b) ^ (own bit b spread
+//    over the word))  -- one sign-extending bit-field extract, one compare and
+//    one v_bitop3 per half and bit, against the nine instructions the compiler
+//    makes of the select form  m &= bit ? bal : ~bal;
+//  * v_mbcnt counts the matching lanes below this one without a lane mask;
+//  * every lane reads the wave's running counter itself (same-address LDS
+//    reads broadcast), then the first lane of the group adds the group size:
+//    no leader search and no cross-lane shuffle.  LDS operations of one wave
+//    execute in order, so the next item's read sees this item's update.
+//  * full tiles (all but the last) run without per-item range checks.
+typedef __attribute__((address_space(3))) volatile u16 lds_vu16;
+
+template <bool FULL, bool DIG, typename K, typename V>
+__device__ __forceinline__ void rs_scatter_tile(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
-    K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
-    u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles,
-    u8 *__restrict__ dig_out, int next_shift, u32 next_mask) {
-  __shared__ K s_key[RS_TILE];
-  __shared__ V s_val[RS_TILE];
-  __shared__ u32 s_cnt[RS_WAVES][RADIX];   // running counters, then wave prefix
-  __shared__ u32 s_dbase[RADIX];           // tile-local start of each digit run
-  __shared__ u32 s_obase[RADIX];           // global base minus local start
-  __shared__ u32 s_scan[RS_WAVES];
-
+    K *__restrict__ keys_out, V *__restrict__ vals_out, const u32 valid, int shift,
+    u32 mask, u32 gbase, u8 *__restrict__ dig_out, int next_shift, u32 next_mask,
+    K *s_key, V *s_val, u16 *s_cnt_generic /* [RS_WAVES][RADIX] */, u32 *s_obase) {
+  // volatile: lanes read counters that other lanes of the wave have updated
+  lds_vu16 *s_cnt = (lds_vu16 *) s_cnt_generic;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const u32 tile = XCD == 2 ? os_tile(blockIdx.x)
-                            : (XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x);
-  if (tile >= ntiles) return;   // whole block leaves together
-  const u64 tile_base = (u64) tile * RS_TILE;
-  const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
-                                                            : (u64) RS_TILE);
-  for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS)
-    (&s_cnt[0][0])[i] = 0;
-  // this tile's global write base per digit: strided, latency-bound load,
-  // issued first so that it is back long before it is needed
-  u32 gbase = 0;
-  if (tid < RADIX) gbase = hist_scanned[(u64) tile * RADIX + tid];
-
+  u32 *s_scan = reinterpret_cast<u32 *>(s_key);
   K key[RS_ITEMS];
   V val[RS_ITEMS];
   u32 rk[RS_ITEMS];   // rank inside the wave's stream << 8 | digit
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
-    if (e < valid) {
-      key[j] = keys_in[tile_base + e];
-      val[j] = vals_in[tile_base + e];
+    if (FULL || e < valid) {
+      key[j] = keys_in[e];
+      val[j] = vals_in[e];
     } else {
       key[j] = (K) ~(K) 0;
       val[j] = 0;
     }
   }
-  __syncthreads();
-  const u64 lt = (1ull << lane) - 1ull;
-  {
+  __syncthreads();   // counters are zero
+  lds_vu16 *cnt_w = s_cnt + w * RADIX;
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; j++) {
-      const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
-      // out-of-range pairs go to the last digit; being the last pairs of the
-      // tile they end up behind all valid ones and are never written
-      const u32 d = e < valid ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
-      const u64 m = match_digit(d);
-      const u32 intra = (u32) __popcll(m & lt);
-      const int leader = __ffsll((unsigned long long) m) - 1;
-      u32 old = 0;
-      if (lane == leader) {
-        old = s_cnt[w][d];
-        s_cnt[w][d] = old + (u32) __popcll(m);
-      }
-      old = __shfl(old, leader, 64);
-      rk[j] = ((old + intra) << 8) | d;
+  for (int j = 0; j < RS_ITEMS; j++) {
+    const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    // out-of-range pairs go to the last digit; being the last pairs of the
+    // tile they end up behind all valid ones and are never written
+    const u32 d = (FULL || e < valid) ? ((u32) (key[j] >> shift) & mask) : (RADIX - 1);
+    u32 mlo = ~0u, mhi = ~0u;   // lanes holding the same digit
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      u32 sx = (u32) ((int) (d << (31 - b)) >> 31);   // bit b of d, spread
+      asm volatile("" : "+v"(sx));   // compare THIS register, not a shifted copy of d
+      const u64 bal = __ballot(sx != 0);
+      // m & ~(bal ^ sx) as ONE three-input bit operation (truth table 0x90)
+      mlo = __builtin_amdgcn_bitop3_b32(mlo, (u32) bal, sx, 0x90);
+      mhi = __builtin_amdgcn_bitop3_b32(mhi, (u32) (bal >> 32), sx, 0x90);
     }
+    const u32 intra = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    const u32 old = cnt_w[d];
+    if (intra == 0) cnt_w[d] = (u16) (old + (u32) __popc(mlo) + (u32) __popc(mhi));
+    rk[j] = ((old + intra) << 8) | d;
   }
   __syncthreads();
-  // digit totals over the waves, wave-exclusive prefixes, tile-local bases
+  // digit totals over the waves; every (wave, digit) counter becomes the
+  // tile-local position where that wave's pairs of that digit start
   // (threads 0..255 own one digit each; the scan needs all threads)
   {
+    u32 c[RS_WAVES];
     u32 tot = 0;
     if (tid < RADIX) {
 #pragma unroll
       for (int i = 0; i < RS_WAVES; i++) {
-        const u32 c = s_cnt[i][tid];
-        s_cnt[i][tid] = tot;
-        tot += c;
+        c[i] = s_cnt[i * RADIX + tid];
+        tot += c[i];
       }
     }
     u32 blocktot;
     u32 dbase = block_scan_excl<SCAN_SUM, RS_THREADS>(tot, &blocktot, s_scan);
     if (tid < RADIX) {
-      s_dbase[tid] = dbase;
       s_obase[tid] = gbase - dbase;
+#pragma unroll
+      for (int i = 0; i < RS_WAVES; i++) {
+        s_cnt[i * RADIX + tid] = (u16) dbase;
+        dbase += c[i];
+      }
     }
   }
-  __syncthreads();
+  __syncthreads();   // also: the scan scratch inside s_key is free again
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 d = rk[j] & 255u;
-    const u32 pos = s_dbase[d] + s_cnt[w][d] + (rk[j] >> 8);
+    const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
     s_key[pos] = key[j];
     s_val[pos] = val[j];
   }
@@ -351,15 +356,61 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) j * RS_THREADS + tid;
-    if (e < valid) {
+    if (FULL || e < valid) {
       const K k = s_key[e];
       const u32 d = (u32) (k >> shift) & mask;
       const u32 g = s_obase[d] + e;
       keys_out[g] = k;
       vals_out[g] = s_val[e];
-      if (dig_out != nullptr) dig_out[g] = (u8) ((u32) (k >> next_shift) & next_mask);
+      if (DIG) dig_out[g] = (u8) ((u32) (k >> next_shift) & next_mask);
     }
   }
+}
+
+template <typename K, typename V, int XCD>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
+    const K *__restrict__ keys_in, const V *__restrict__ vals_in,
+    K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
+    u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles,
+    u8 *__restrict__ dig_out, int next_shift, u32 next_mask) {
+  // 53 KB of LDS in all, so that three workgroups (24 waves) share a CU:
+  // 16-bit counters (a tile has 4096 pairs) and the scan scratch laid over
+  // the key staging area, which is not written before the scan is done
+  __shared__ K s_key[RS_TILE];
+  __shared__ V s_val[RS_TILE];
+  __shared__ u16 s_cnt[RS_WAVES * RADIX];  // running counters, then staging base
+  __shared__ u32 s_obase[RADIX];           // global base minus local start
+  static_assert(sizeof(K) * RS_TILE + sizeof(V) * RS_TILE + sizeof(u16) * RS_WAVES * RADIX
+                + sizeof(u32) * RADIX <= 53 * 1024 || sizeof(K) + sizeof(V) > 12,
+                "three workgroups per CU");
+
+  const int tid = threadIdx.x;
+  const u32 tile = XCD == 2 ? os_tile(blockIdx.x)
+                            : (XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x);
+  if (tile >= ntiles) return;   // whole block leaves together
+  const u64 tile_base = (u64) tile * RS_TILE;
+  const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
+                                                            : (u64) RS_TILE);
+  for (int i = tid; i < RS_WAVES * RADIX / 2; i += RS_THREADS)
+    reinterpret_cast<u32 *>(s_cnt)[i] = 0;
+  // this tile's global write base per digit: strided, latency-bound load,
+  // issued first so that it is back long before it is needed
+  u32 gbase = 0;
+  if (tid < RADIX) gbase = hist_scanned[(u64) tile * RADIX + tid];
+  // (the digit-byte side output is an experiment switch, off by default: it
+  // takes the checked variant so that the two hot variants stay branch-free)
+  if (dig_out != nullptr)
+    rs_scatter_tile<false, true, K, V>(keys_in + tile_base, vals_in + tile_base, keys_out,
+                                       vals_out, valid, shift, mask, gbase, dig_out,
+                                       next_shift, next_mask, s_key, s_val, s_cnt, s_obase);
+  else if (valid == (u32) RS_TILE)
+    rs_scatter_tile<true, false, K, V>(keys_in + tile_base, vals_in + tile_base, keys_out,
+                                       vals_out, valid, shift, mask, gbase, dig_out,
+                                       next_shift, next_mask, s_key, s_val, s_cnt, s_obase);
+  else
+    rs_scatter_tile<false, false, K, V>(keys_in + tile_base, vals_in + tile_base, keys_out,
+                                        vals_out, valid, shift, mask, gbase, dig_out,
+                                        next_shift, next_mask, s_key, s_val, s_cnt, s_obase);
 }
 
 // ---------------------------------------------------------------------------

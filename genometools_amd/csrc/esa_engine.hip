@@ -885,6 +885,62 @@ __global__ __launch_bounds__(256) void k_rank_scatter(
   }
 }
 
+// The same through LDS, for a build that owns ALL positions: after the pairs
+// are partitioned on their leading position bits, bucket b holds exactly the
+// positions [b << wb, (b + 1) << wb) -- and, every position occurring once,
+// exactly the pairs with these indices.  A workgroup scatters one window of
+// heads inside LDS (4-byte LDS stores cost nothing against 4-byte global
+// stores, each of which is a memory transaction of its own: 47 G/s measured)
+// and writes the window out in whole lines.  With wb = 16 (N >= 2^31) a
+// window is twice the LDS; two workgroups then read the bucket and keep one
+// half each (they are eight workgroups apart, i.e. on the same XCD, so that
+// the second read of the pairs can hit that L2).
+constexpr int RW_BITS = 15;
+constexpr int RW_THREADS = 1024;
+
+__global__ __launch_bounds__(RW_THREADS) void k_rank_window(
+    const u32 *__restrict__ pos, const u32 *__restrict__ heads, u64 N, int wb,
+    int split, u32 nbuckets, u32 *__restrict__ rank) {
+  __shared__ u32 s_win[1 << RW_BITS];
+  u32 bucket = blockIdx.x, half = 0;
+  if (split == 2) {
+    bucket = (blockIdx.x >> 4) * 8u + (blockIdx.x & 7u);
+    half = (blockIdx.x >> 3) & 1u;
+  }
+  if (bucket >= nbuckets) return;   // whole workgroup
+  const int sb = wb - (split == 2 ? 1 : 0);   // position bits inside a window
+  const u32 smask = (1u << sb) - 1u;
+  const u64 first = (u64) bucket << wb;
+  const u64 end = first + (1ull << wb) < N ? first + (1ull << wb) : N;
+  const u64 cnt = end - first;
+  const u32 *bp = pos + first, *bh = heads + first;
+  // four pairs per lane and step while whole groups are left (first is a
+  // multiple of 4 whenever wb >= 2; both arrays are 16-byte aligned then)
+  const u64 cnt4 = (wb >= 2) ? (cnt & ~3ull) : 0;
+  for (u64 i = (u64) threadIdx.x * 4; i < cnt4; i += (u64) RW_THREADS * 4) {
+    const uint4 p4 = *reinterpret_cast<const uint4 *>(bp + i);
+    const uint4 h4 = *reinterpret_cast<const uint4 *>(bh + i);
+    if (split == 1 || ((p4.x >> sb) & 1u) == half) s_win[p4.x & smask] = h4.x;
+    if (split == 1 || ((p4.y >> sb) & 1u) == half) s_win[p4.y & smask] = h4.y;
+    if (split == 1 || ((p4.z >> sb) & 1u) == half) s_win[p4.z & smask] = h4.z;
+    if (split == 1 || ((p4.w >> sb) & 1u) == half) s_win[p4.w & smask] = h4.w;
+  }
+  for (u64 i = cnt4 + threadIdx.x; i < cnt; i += RW_THREADS) {
+    const u32 p = bp[i];
+    if (split == 1 || ((p >> sb) & 1u) == half) s_win[p & smask] = bh[i];
+  }
+  __syncthreads();
+  const u64 wfirst = first + ((u64) half << sb);
+  if (wfirst >= N) return;
+  const u64 wend = wfirst + (1ull << sb) < N ? wfirst + (1ull << sb) : N;
+  const u64 wcnt = wend - wfirst;
+  u32 *out = rank + wfirst;
+  const u64 wcnt4 = (sb >= 2) ? (wcnt & ~3ull) : 0;
+  for (u64 i = (u64) threadIdx.x * 4; i < wcnt4; i += (u64) RW_THREADS * 4)
+    *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(s_win + i);
+  for (u64 i = wcnt4 + threadIdx.x; i < wcnt; i += RW_THREADS) out[i] = s_win[i];
+}
+
 // One doubling round for all tie groups that lie inside one tile of the
 // unresolved list: sort each group by k2 in LDS (bitonic network on the packed
 // key  local group | k2 | slot), derive the new group heads.  Groups that
@@ -2068,7 +2124,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     // there is one part); other parts' entries are never read here
     if (NL > 0) {
       u32 *heads = reinterpret_cast<u32 *>(fkey);          // free key buffer
-      u32 *ppos = c->isa_tmp, *phead = ppos + NL;          // (skey is still being
+      u32 *ppos = c->isa_tmp, *phead = ppos + ((NL + 3) & ~3ull);  // (skey is still being
                                                            // read by the emission)
       u32 *pws = scanws + scan_workspace_words(nwords) + 64;
       k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(c->tiebits, carry, NL,
@@ -2084,12 +2140,52 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       // scatter is bound by the number of 4-byte store transactions, which
       // only an LDS-staged window would remove.)
       const int nbp = bits_for(N - 1);
-      const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
-      TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,
-                                     &pwidth, 1, pws, st, nullptr, nullptr));
-      TRY(launch_emission());   // overlaps with the latency-bound scatter
-      k_rank_scatter<<<(u32) div_up(NL, 1024), 256, 0, st>>>(ppos, phead, NL, rank);
-      HIP_TRY(hipGetLastError());
+      if (!parts) {
+        // all positions are here: partition down to windows that fit the LDS
+        // (one or two passes), then k_rank_window.  GTAMD_RANK_WINDOW_BITS
+        // shrinks the window so that tests reach every shape at small N.
+        int wmax = RW_BITS;
+        if (const char *e = getenv("GTAMD_RANK_WINDOW_BITS")) {
+          const int v = atoi(e);
+          if (v >= 2 && v <= RW_BITS) wmax = v;
+        }
+        int pb = nbp > wmax ? nbp - wmax : 0;
+        if (pb > 16) pb = 16;
+        const int wb = nbp - pb;             // wmax, or wmax + 1 with two halves
+        if (wb > wmax + 1) {
+          gtamd_set_error("rank table: %d position bits do not fit two passes and a "
+                          "%d-bit window", nbp, wmax);
+          return -1;
+        }
+        const int split = wb > wmax ? 2 : 1;
+        const u32 *wpos = sa32, *whead = heads;
+        if (pb > 8) {
+          const int s0 = nbp - pb, w0 = pb - 8, s1 = nbp - 8, w1 = 8;
+          u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
+          TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &w0, 1, pws, st,
+                                         nullptr, nullptr));
+          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
+                                         nullptr, nullptr));
+          wpos = qpos; whead = qhead;
+        } else if (pb > 0) {
+          const int s0 = nbp - pb;
+          TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &pb, 1, pws, st,
+                                         nullptr, nullptr));
+          wpos = ppos; whead = phead;
+        }
+        const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
+        const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
+        k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank);
+        HIP_TRY(hipGetLastError());
+        TRY(launch_emission());   // beside the first (latency-bound) rounds
+      } else {
+        const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
+        TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,
+                                       &pwidth, 1, pws, st, nullptr, nullptr));
+        TRY(launch_emission());   // overlaps with the latency-bound scatter
+        k_rank_scatter<<<(u32) div_up(NL, 1024), 256, 0, st>>>(ppos, phead, NL, rank);
+        HIP_TRY(hipGetLastError());
+      }
     }
     // ---- doubling rounds
     const int nb = bits_for(N - 1);

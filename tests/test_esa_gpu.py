@@ -251,3 +251,24 @@ def test_bucket_table_matches_oracle(gpu, model, n, ks):
                         letters = next((j for j, x in enumerate(seen) if x >= 254), len(seen))
                         assert seen[:letters] == digits[:letters]
                         assert all(d == sigma - 1 for d in digits[letters:])
+
+
+@pytest.mark.parametrize("wbits,n", [
+    (15, 28_000),       # everything in one window, no partition pass
+    (10, 40_000),       # one partition pass
+    (4, 300_000),       # two passes
+    (4, 1_500_000),     # two passes and two workgroups per (twice too large) window
+    (15, 1_500_000),    # the shape a build of this size takes by itself
+])
+def test_rank_table_window_shapes(gpu, monkeypatch, wbits, n):
+    """rank table through LDS windows (k_rank_window): GTAMD_RANK_WINDOW_BITS
+    shrinks the window so that the partition shapes of a 3 Gbp build (two
+    passes, split windows) are reached at test sizes; repeats make sure the
+    doubling rounds really use the table"""
+    monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", str(wbits))
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 77 + wbits, n)
+    if n < 200_000:     # too short for the model's repeats: a tandem repeat instead
+        enc = np.resize(synth.generate(synth.MODEL_UNIFORM_DNA, 5, 700), n).astype(np.uint8)
+    res = esa.suffixerator_tables(enc, 4)
+    assert res.stats["refine_rounds"] > 0
+    _assert_same_as_oracle(enc, 4, res)

@@ -111,6 +111,9 @@ template <int BITS> struct Pay {
   static __device__ __forceinline__ u32 before(const Text &t, u64 p) {
     if (p == 0) return UNDEF;
     const u32 c = Sym<BITS>::at(t, p - 1);
+    // a special is stored as code 0 or 1, so any other code needs no look at
+    // the bitmap (one random line less per look-up, most of the time)
+    if (c >= 2u) return c;
     if (is_special(t, p - 1)) return (c & 1u) ? SEP : WILD;
     return c;
   }
@@ -954,7 +957,8 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     const u32 *__restrict__ uidx, const u32 *__restrict__ upos,
     const u32 *__restrict__ ugrp, u32 *__restrict__ k2, u64 m,
     u32 *__restrict__ cv, u32 *__restrict__ hv, u32 *__restrict__ flg,
-    Stats *stats, const u32 *__restrict__ rank, u64 h, u64 n) {
+    u32 *__restrict__ tilecnt, Stats *stats, const u32 *__restrict__ rank, u64 h,
+    u64 n) {
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
   // of reading a k2 array (which a part build fills through the exchange)
   // 28 KB of LDS, so that five workgroups share a CU (the rank lookups below
@@ -1140,24 +1144,47 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       }
     }
   }
-  // number of deferred elements
+  // number of deferred elements: of the tile (k_flag_gather places them from a
+  // scan of these counts) and in all
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) nflag += __shfl_xor(nflag, d, 64);
-  if ((tid & 63) == 0 && nflag) atomicAdd(&stats->count2, nflag);
+  if ((tid & 63) == 0) s_scan[tid >> 6] = nflag;   // free since the scan's last barrier
+  __syncthreads();
+  if (tid == 0) {
+    u32 t = 0;
+    for (int i = 0; i < RT_THREADS / 64; i++) t += s_scan[i];
+    tilecnt[blockIdx.x] = t;
+    if (t) atomicAdd(&stats->count2, t);
+  }
 }
 
-// global path for the deferred elements: composite key (group, k2)
-__global__ __launch_bounds__(256) void k_flag_gather(
-    const u32 *__restrict__ flg, const u32 *__restrict__ foff,
+// global path for the deferred elements: composite key (group, k2).  One
+// workgroup per tile of k_round_tile; tileoff = exclusive scan of its counts.
+__global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
+    const u32 *__restrict__ flg, const u32 *__restrict__ tileoff,
     const u32 *__restrict__ ugrp, const u32 *__restrict__ k2,
     const u32 *__restrict__ upos, u64 m, u64 *__restrict__ ckey,
     u32 *__restrict__ cval, u32 *__restrict__ fj) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m || !flg[j]) return;
-  const u32 o = foff[j];
-  ckey[o] = ((u64) ugrp[j] << 32) | k2[j];
-  cval[o] = upos[j];
-  fj[o] = (u32) j;
+  __shared__ u32 s_scan[4];
+  const u64 base = (u64) blockIdx.x * RT_TILE + (u64) threadIdx.x * RT_PER;
+  u32 f = 0, cnt = 0;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++) {
+    const u64 j = base + c;
+    if (j < m && flg[j]) { f |= 1u << c; cnt++; }
+  }
+  u32 tot;
+  u32 o = tileoff[blockIdx.x] + block_scan_excl_sum(cnt, &tot, s_scan);
+  if (f == 0) return;
+#pragma unroll
+  for (int c = 0; c < RT_PER; c++)
+    if ((f >> c) & 1u) {
+      const u64 j = base + c;
+      ckey[o] = ((u64) ugrp[j] << 32) | k2[j];
+      cval[o] = upos[j];
+      fj[o] = (u32) j;
+      o++;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_flag_heads(
@@ -1312,28 +1339,46 @@ __global__ __launch_bounds__(256) void k_fix_basic(
   if (p == 0) stats->longest = index_offset + i;
 }
 
-// which entries of the unresolved list are tied with their predecessor (need
-// a real LCP)
-__global__ __launch_bounds__(256) void k_tied_flags(
-    const u32 *__restrict__ uidx0, u64 m0, const u64 *__restrict__ tiebits,
-    u32 *__restrict__ tied, u32 *__restrict__ lcpu) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m0) return;
-  const u64 i = uidx0[j];
-  tied[j] = (u32) ((tiebits[i >> 6] >> (i & 63)) & 1ull);
-  lcpu[j] = 0;
+// Which entries of the unresolved list are tied with their predecessor (need
+// a real LCP)?  Counted per workgroup first; after a scan of the counts the
+// same workgroups place (text position, index in the table) of these entries.
+__device__ __forceinline__ bool tied_with_pred(const u64 *__restrict__ tiebits, u64 i) {
+  return (tiebits[i >> 6] >> (i & 63)) & 1ull;
 }
 
-// (text position, slot in the unresolved list) of the entries that need an LCP
+__device__ __forceinline__ void block_count_256(bool flag, u32 *__restrict__ blockcnt) {
+  __shared__ u32 s_cnt[4];
+  const u64 b = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (u32) __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+__global__ __launch_bounds__(256) void k_tied_counts(
+    const u32 *__restrict__ uidx0, u64 m0, const u64 *__restrict__ tiebits,
+    u32 *__restrict__ blockcnt) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  block_count_256(j < m0 && tied_with_pred(tiebits, uidx0[j]), blockcnt);
+}
+
 __global__ __launch_bounds__(256) void k_lcp_pairs(
-    const u32 *__restrict__ tied, const u32 *__restrict__ off,
+    const u32 *__restrict__ boff, const u64 *__restrict__ tiebits,
     const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32, u64 m0,
     u32 *__restrict__ pkey, u32 *__restrict__ pval) {
+  __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m0 || !tied[j]) return;
-  const u32 o = off[j];
-  pkey[o] = sa32[uidx0[j]];
-  pval[o] = (u32) j;
+  u32 i = 0;
+  bool tied = false;
+  if (j < m0) {
+    i = uidx0[j];
+    tied = tied_with_pred(tiebits, i);
+  }
+  u32 tot;
+  const u32 o = boff[blockIdx.x] + block_scan_excl_sum(tied ? 1u : 0u, &tot, s_scan);
+  if (tied) {
+    pkey[o] = sa32[i];
+    pval[o] = i;
+  }
 }
 
 // LCP of the tied entries in TEXT order (the pairs are sorted by position):
@@ -1342,13 +1387,16 @@ __global__ __launch_bounds__(256) void k_lcp_pairs(
 // lcp(p+d, pred(p+d)) >= lcp(p, pred(p)) - d for any distance d -- which is
 // what a part build needs, where a part sees only every R-th position of a
 // repeat.  Inside a repeat only the first position of a chunk pays for the
-// full extension.  One thread walks LCP_CHUNK consecutive pairs.
+// full extension.  One thread walks LCP_CHUNK consecutive pairs.  Every
+// access by table index is a random line; values that do not fit the byte
+// (and only those) also go to a 32-bit side table by index, from which the
+// .llv pairs are collected in index order afterwards.
 constexpr int LCP_CHUNK = 32;
 template <int BITS>
 __global__ __launch_bounds__(256) void k_lcp_chunks(
     Text t, const u32 *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
-    const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32,
-    u8 *__restrict__ lcp, u32 *__restrict__ lcpu, Stats *stats) {
+    const u32 *__restrict__ sa32, u8 *__restrict__ lcp, u32 *__restrict__ lcpfull,
+    Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
   const u64 c = (u64) blockIdx.x * 256 + threadIdx.x;
@@ -1360,17 +1408,15 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     const u64 s = c * LCP_CHUNK + e;
     if (s >= m1) break;
     const u64 p = pkey[s];
-    const u32 j = pval[s];
-    const u64 i = uidx0[j];
+    const u64 i = pval[s];
     const u64 q = sa32[i - 1];
     u64 from = (u64) Key<BITS>::SYMS;
     if (e > 0 && l > from + (p - prevp)) from = l - (p - prevp);
     l = lcp_extend<BITS>(t, q, p, from);
     prevp = p;
     const u32 lv = (u32) l;
-    if (lcp != nullptr)
-      lcp[i] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
-    lcpu[j] = lv;
+    lcp[i] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+    if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i] = lv;
     sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
     nlarge += lv >= GTAMD_LCPOVERFLOW;
     mx = lv > mx ? lv : mx;
@@ -1396,23 +1442,35 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
   }
 }
 
-__global__ __launch_bounds__(256) void k_large_flags(
-    const u32 *__restrict__ lcpu, u64 m0, u32 *__restrict__ large) {
+// .llv pairs in index order: (index into the lcp table, value),
+// src/match/sfx-lcpvalues.c:402-411.  Counted per workgroup, then placed.
+// (An entry of the list that is not tied with its predecessor has the LCP the
+// keys gave it, which is below the key length.)
+__global__ __launch_bounds__(256) void k_large_counts(
+    const u32 *__restrict__ uidx0, const u8 *__restrict__ lcp, u64 m0,
+    u32 *__restrict__ blockcnt) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j < m0) large[j] = lcpu[j] >= GTAMD_LCPOVERFLOW;
+  block_count_256(j < m0 && lcp[uidx0[j]] == GTAMD_LCPOVERFLOW, blockcnt);
 }
 
-// .llv pairs in index order: (index into the lcp table, value),
-// src/match/sfx-lcpvalues.c:402-411
 __global__ __launch_bounds__(256) void k_llv_emit(
-    const u32 *__restrict__ uidx0, const u32 *__restrict__ lcpu,
-    const u32 *__restrict__ large, const u32 *__restrict__ off, u64 m0,
+    const u32 *__restrict__ uidx0, const u8 *__restrict__ lcp,
+    const u32 *__restrict__ lcpfull, const u32 *__restrict__ boff, u64 m0,
     u64 index_offset, u64 *__restrict__ llv) {
+  __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= m0 || !large[j]) return;
-  const u64 o = off[j];
-  llv[2 * o] = index_offset + uidx0[j];
-  llv[2 * o + 1] = lcpu[j];
+  u32 i = 0;
+  bool large = false;
+  if (j < m0) {
+    i = uidx0[j];
+    large = lcp[i] == GTAMD_LCPOVERFLOW;
+  }
+  u32 tot;
+  const u64 o = boff[blockIdx.x] + block_scan_excl_sum(large ? 1u : 0u, &tot, s_scan);
+  if (large) {
+    llv[2 * o] = index_offset + i;
+    llv[2 * o + 1] = lcpfull[i];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2218,17 +2276,19 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
                 (unsigned long long) m);
       if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
       HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
-      k_round_tile<<<(u32) div_up(m, RT_TILE), RT_THREADS, 0, st>>>(
-          uidx, upos, ugrp, k2, m, cvo, hv, flg, c->d_stats,
+      const u32 ntiles = (u32) div_up(m, RT_TILE);
+      u32 *tilecnt = koff, *tileoff = koff + ntiles + 16;   // (free until the apply step)
+      k_round_tile<<<ntiles, RT_THREADS, 0, st>>>(
+          uidx, upos, ugrp, k2, m, cvo, hv, flg, tilecnt, c->d_stats,
           parts ? nullptr : rank, h, n);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 nf = c->h_stats->count2;
       if (nf > 0) {
         // groups crossing a tile border / larger than a tile: global radix sort
-        TRY(scan_u32(SCAN_SUM, flg, foff, m, false, scanws2, st));
-        k_flag_gather<<<g, 256, 0, st>>>(flg, foff, ugrp, k2, upos, m, ckey_a,
-                                         cval_a, fj);
+        TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, ntiles, false, scanws2, st));
+        k_flag_gather<<<ntiles, RT_THREADS, 0, st>>>(flg, tileoff, ugrp, k2, upos, m,
+                                                     ckey_a, cval_a, fj);
         HIP_TRY(hipGetLastError());
         TRY(radix_sort_pairs<u64, u32>(ckey_a, cval_a, ckey_b, cval_b, nf, cs, cw,
                                   cnp, rws2, st, nullptr, nullptr));
@@ -2264,8 +2324,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     // written its provisional values)
     TRY(launch_emission());
     HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
-    u32 *lcpu = hv, *large = keep, *loff = koff, *tied = cval_b;
     const u32 g0 = (u32) div_up(m0, 256);
+    u32 *bcnt0 = koff, *boff0 = koff + g0 + 16;   // per-workgroup counts and their scan
+    u32 *lcpfull = rank;   // the rank table has done its work
     if (m0 > 0) {
       // .suf/.bwt of the tied entries: random accesses, on the second stream
       // (behind the emission there) while this stream sorts the LCP pairs
@@ -2276,20 +2337,20 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
           want_bwt ? c->bwt : nullptr, c->d_stats, index_offset);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_emitted, c->st2));
-      k_tied_flags<<<g0, 256, 0, st>>>(uidx0, m0, c->tiebits, tied, lcpu);
-      HIP_TRY(hipGetLastError());
     }
     if (want_lcp && m0 > 0) {
       // entries tied with their predecessor, sorted by text position
-      TRY(scan_u32(SCAN_SUM, tied, loff, m0, false, scanws2, st));
-      k_total<<<1, 1, 0, st>>>(loff, tied, m0, c->d_stats);
+      k_tied_counts<<<g0, 256, 0, st>>>(uidx0, m0, c->tiebits, bcnt0);
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, bcnt0, boff0, g0, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(boff0, bcnt0, g0, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 m1 = c->h_stats->count;
       // (text position, slot) pairs, 32-bit keys
       u32 *pkey_a = reinterpret_cast<u32 *>(ckey_a), *pkey_b = reinterpret_cast<u32 *>(ckey_b);
       u32 *pval_b = uidx2;   // the round buffers are free now
-      k_lcp_pairs<<<g0, 256, 0, st>>>(tied, loff, uidx0, sa32, m0, pkey_a, cval_a);
+      k_lcp_pairs<<<g0, 256, 0, st>>>(boff0, c->tiebits, uidx0, sa32, m0, pkey_a, cval_a);
       HIP_TRY(hipGetLastError());
       int ps[8], pw[8], pn = 0;
       for (int b = 0; b < nb; b += 8) {
@@ -2302,12 +2363,12 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       const u32 *pk = (pn & 1) ? pkey_b : pkey_a;
       const u32 *pv = (pn & 1) ? pval_b : cval_a;
       k_lcp_chunks<BITS><<<(u32) div_up(div_up(m1, LCP_CHUNK), 256), 256, 0, st>>>(
-          c->text, pk, pv, m1, uidx0, sa32, c->lcp, lcpu, c->d_stats);
+          c->text, pk, pv, m1, sa32, c->lcp, lcpfull, c->d_stats);
       HIP_TRY(hipGetLastError());
-      k_large_flags<<<g0, 256, 0, st>>>(lcpu, m0, large);
+      k_large_counts<<<g0, 256, 0, st>>>(uidx0, c->lcp, m0, bcnt0);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, large, loff, m0, false, scanws2, st));
-      k_total<<<1, 1, 0, st>>>(loff, large, m0, c->d_stats);
+      TRY(scan_u32(SCAN_SUM, bcnt0, boff0, g0, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(boff0, bcnt0, g0, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 pairs = c->h_stats->count;
@@ -2319,7 +2380,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         c->llv_cap = pairs + pairs / 4 + 1024;
       }
       if (pairs > 0) {
-        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, lcpu, large, loff, m0,
+        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, c->lcp, lcpfull, boff0, m0,
                                        index_offset, c->llv);
         HIP_TRY(hipGetLastError());
       }

@@ -256,6 +256,72 @@ __global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
   }
 }
 
+// DNA: one thread makes the keys of FOUR consecutive suffixes from one pair of
+// text words and one pair of bitmap words (the general kernel spends ~140
+// instructions per suffix, mostly on re-deriving the same windows, and is
+// bound by them, not by its 36 GB of stores); stores are 16 bytes per lane.
+// Same keys as make_key<2>, bit for bit.
+__global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
+                                                    u64 *__restrict__ keys,
+                                                    u32 *__restrict__ vals) {
+  using K = Key<2>;
+  using P = Pay<2>;
+  constexpr int SYMS = K::SYMS;
+  static_assert(28 + 3 + SYMS <= 64, "four windows must fit one word pair");
+  const u64 p0 = ((u64) blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= N) return;
+  const u64 w = p0 >> 5;
+  const int o = (int) (p0 & 31) * 2;           // 0, 8, ..., 56
+  const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
+  const u64 a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;   // symbols p0 .. p0+31
+  const u64 a_lo = lo << o;                                 // the ones behind
+  const u64 sw = p0 >> 6;
+  const int so = (int) (p0 & 63);              // multiple of 4
+  const u64 s0 = sp_word(t, sw), s1 = sp_word(t, sw + 1);
+  const u64 S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;   // specials p0 .. p0+63
+  // the symbol in front of p0
+  u32 pay;
+  if (p0 == 0) {
+    pay = P::UNDEF;
+  } else {
+    const u32 c = o ? (u32) (hi >> (64 - o)) & 3u : (u32) tb_word(t, w - 1) & 3u;
+    const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
+    pay = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+  u64 key[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const u64 win = g ? (a_hi << (2 * g)) | (a_lo >> (64 - 2 * g)) : a_hi;
+    const u64 s = (S >> g) & ((1ull << SYMS) - 1ull);
+    const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+    if (d == 0) {
+      key[g] = (~0ull << K::DSHIFT) | pay;
+    } else {
+      u64 pre = win >> K::LOW_BITS;
+      u32 dc = 0;
+      if (d < SYMS) {
+        pre |= (1ull << (2 * (SYMS - d))) - 1ull;
+        dc = (u32) (SYMS - d);
+      }
+      key[g] = (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
+    }
+    // in front of the next suffix: this one's first symbol
+    const u32 c = (u32) (win >> 62);
+    pay = (c < 2u && (s & 1ull)) ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+  if (p0 + 4 <= N) {
+    *reinterpret_cast<ulonglong2 *>(keys + p0) = make_ulonglong2(key[0], key[1]);
+    *reinterpret_cast<ulonglong2 *>(keys + p0 + 2) = make_ulonglong2(key[2], key[3]);
+    *reinterpret_cast<uint4 *>(vals + p0) =
+        make_uint4((u32) p0, (u32) p0 + 1u, (u32) p0 + 2u, (u32) p0 + 3u);
+  } else {
+    for (int g = 0; g < 4 && p0 + g < N; g++) {
+      keys[p0 + g] = key[g];
+      vals[p0 + g] = (u32) (p0 + g);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // part builds: lexicographic range partition (the reference's -parts idea,
 // src/match/sfx-partssuf.c:172-347, filter src/match/sfx-suffixer.c:375-398)
@@ -308,10 +374,15 @@ __global__ __launch_bounds__(256) void k_part_count(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   s_part[threadIdx.x] = 0;
   __syncthreads();
+  // workgroups stride over the 1024-position blocks; the per-part counts go to
+  // the global counters once per workgroup (an atomic per block on the same
+  // few addresses costs ~12 ns each, in sequence)
+  const u64 nblk = (N + 1023) / 1024;
+  for (u64 blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
   u32 c = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const u64 p = (u64) blockIdx.x * 1024 + (u64) j * 256 + threadIdx.x;
+    const u64 p = blk * 1024 + (u64) j * 256 + threadIdx.x;
     bool in = false;
     u32 o = 0xFFFFFFFFu;
     if (p < N) {
@@ -330,13 +401,15 @@ __global__ __launch_bounds__(256) void k_part_count(
       atomicAdd(&s_part[o], 1u);
     const u64 m = __ballot(in);
     if (lane == 0) {
-      inrange[(u64) blockIdx.x * 16 + j * 4 + w] = m;
+      inrange[blk * 16 + j * 4 + w] = m;
       c += (u32) __popcll(m);
     }
   }
   if (lane == 0) s_cnt[w] = c;
   __syncthreads();
-  if (threadIdx.x == 0) cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  if (threadIdx.x == 0) cnt[blk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  __syncthreads();   // s_cnt is written again in the next turn
+  }
   if (s_part[threadIdx.x])
     atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
 }
@@ -357,7 +430,11 @@ __global__ __launch_bounds__(256) void k_part_count_dna(
   if (threadIdx.x < 16) s_part[threadIdx.x] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x, p0 = w * 32;
+  // workgroups stride over the 8192-position tiles (one load of the owner map
+  // and one set of global atomics per workgroup, see k_part_count)
+  const u64 ntiles = (N + 8191) / 8192;
+  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const u64 w = tile * 256 + threadIdx.x, p0 = w * 32;
   u32 mask = 0;
   u64 clo = 0, chi = 0;          // 8 + 8 counters of 8 bits (at most 32 each)
   u64 ow[4] = {0, 0, 0, 0};
@@ -414,6 +491,7 @@ __global__ __launch_bounds__(256) void k_part_count_dna(
         const u32 v = (u32) (f[k] >> (16 * q)) & 0xFFFFu;
         if (v) atomicAdd(&s_part[part], v);
       }
+  }
   }
   __syncthreads();
   if (threadIdx.x < 16 && s_part[threadIdx.x])
@@ -662,17 +740,33 @@ __global__ __launch_bounds__(256) void k_tiebits(const u64 *__restrict__ keys,
   using K = Key<BITS>;
   __shared__ u32 s_cnt[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // a wave walks 16 consecutive groups of 64 entries: all loads are issued up
+  // front, and the key in front of a group is the last lane of the group before.
+  // The workgroups stride over the tiles and add to the one global counter once
+  // at their end: an atomic per tile (732 K at 3 Gbp, ~12 ns each on one
+  // address) used to cost more than the 24 GB this kernel reads.
   u32 cnt = 0;
+  const u64 ntiles = (N + 4095) / 4096;
+  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const u64 wbase = tile * 4096 + (u64) w * 1024;
+  u64 k[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    const u64 i = (u64) blockIdx.x * 4096 + (u64) r * 256 + threadIdx.x;
-    const u64 k = i < N ? keys[i] : ~0ull;
-    u64 prev = __shfl_up(k, 1, 64);
-    if (lane == 0) prev = (i > 0 && i < N) ? keys[i - 1] : ~k;
-    const bool tie = i > 0 && i < N && (k >> K::DSHIFT) == (prev >> K::DSHIFT) &&
-                     K::dcode(k) == 0;
+    const u64 i = wbase + (u64) r * 64 + lane;
+    k[r] = i < N ? keys[i] : ~0ull;
+  }
+  u64 before = (wbase > 0 && wbase < N) ? keys[wbase - 1] : ~k[0];   // wave-uniform
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const u64 i = wbase + (u64) r * 64 + lane;
+    u64 prev = __shfl_up(k[r], 1, 64);
+    if (lane == 0) prev = before;
+    before = __shfl(k[r], 63, 64);
+    const bool tie = i > 0 && i < N && (k[r] >> K::DSHIFT) == (prev >> K::DSHIFT) &&
+                     K::dcode(k[r]) == 0;
     const u64 m = __ballot(tie);
     if (lane == 0 && i < N) { tiebits[i >> 6] = m; cnt += (u32) __popcll(m); }
+  }
   }
   if (lane == 0) s_cnt[w] = cnt;
   __syncthreads();
@@ -699,10 +793,13 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, ties = 0;
   u32 mx = 0;
+  // (workgroups stride over the tiles: one set of atomics per workgroup, not
+  // per tile -- see k_tiebits)
+  const u64 ntiles = (N + FIN_TILE - 1) / FIN_TILE;
+  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #pragma unroll
   for (int r = 0; r < FIN_PER_THREAD; r++) {
-    const u64 i0 = (u64) blockIdx.x * FIN_TILE +
-                   ((u64) r * FIN_THREADS + threadIdx.x) * 4;
+    const u64 i0 = tile * FIN_TILE + ((u64) r * FIN_THREADS + threadIdx.x) * 4;
     u64 k[4];
     u32 p[4];
     if (i0 + 4 <= N) {
@@ -779,6 +876,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
     tw |= __shfl_xor(tw, 4, 64);
     tw |= __shfl_xor(tw, 8, 64);
     if (tiebits != nullptr && (lane & 15) == 0 && i0 < N) tiebits[i0 >> 6] = tw;
+  }
   }
   // block reduction of the statistics, one atomic each per block
 #pragma unroll
@@ -1144,8 +1242,8 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       }
     }
   }
-  // number of deferred elements: of the tile (k_flag_gather places them from a
-  // scan of these counts) and in all
+  // number of deferred elements of the tile (k_flag_gather places them from a
+  // scan of these counts; the scan also gives their total)
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) nflag += __shfl_xor(nflag, d, 64);
   if ((tid & 63) == 0) s_scan[tid >> 6] = nflag;   // free since the scan's last barrier
@@ -1154,7 +1252,6 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     u32 t = 0;
     for (int i = 0; i < RT_THREADS / 64; i++) t += s_scan[i];
     tilecnt[blockIdx.x] = t;
-    if (t) atomicAdd(&stats->count2, t);
   }
 }
 
@@ -1399,10 +1496,12 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
-  const u64 c = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, nlarge = 0;
   u32 mx = 0;
+  const u64 nchunks = (m1 + LCP_CHUNK - 1) / LCP_CHUNK;
+  for (u64 c = (u64) blockIdx.x * 256 + threadIdx.x; c < nchunks;
+       c += (u64) gridDim.x * 256) {
   u64 prevp = 0, l = 0;
   for (int e = 0; e < LCP_CHUNK; e++) {
     const u64 s = c * LCP_CHUNK + e;
@@ -1420,6 +1519,7 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
     nlarge += lv >= GTAMD_LCPOVERFLOW;
     mx = lv > mx ? lv : mx;
+  }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -1471,6 +1571,14 @@ __global__ __launch_bounds__(256) void k_llv_emit(
     llv[2 * o] = index_offset + i;
     llv[2 * o + 1] = lcpfull[i];
   }
+}
+
+// grid of a kernel whose workgroups stride over `tiles` tiles: enough
+// workgroups to fill the 256 CUs several times over, few enough that their
+// closing atomics do not queue up on one address
+static inline u32 stride_grid(u64 tiles) {
+  const u64 cap = 256 * 16;
+  return (u32) (tiles < cap ? (tiles ? tiles : 1) : cap);
 }
 
 // ---------------------------------------------------------------------------
@@ -1941,7 +2049,10 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   // ---- keygen (whole table, or the pairs of this part's key range)
   u64 NL = N, index_offset = 0;
   if (!parts) {
-    k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+    if (BITS == 2)
+      k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+    else
+      k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
     HIP_TRY(hipGetLastError());
   } else {
     // range cuts from a histogram of the key bins over every 16th suffix;
@@ -1986,11 +2097,11 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       c->have_pos_owner = true;
     }
     if (c->have_pos_owner)
-      k_part_count_dna<<<(u32) div_up(N, 8192), 256, 0, st>>>(c->text, N, lo, hi,
+      k_part_count_dna<<<stride_grid(div_up(N, 8192)), 256, 0, st>>>(c->text, N, lo, hi,
                                                              c->d_owner, inrange, cnt,
                                                              d_partcnt, c->pos_owner);
     else
-      k_part_count<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, lo, hi, c->d_owner, R,
+      k_part_count<BITS><<<stride_grid(nblk), 256, 0, st>>>(c->text, N, lo, hi, c->d_owner, R,
                                                      inrange, cnt, d_partcnt);
     HIP_TRY(hipGetLastError());
     TRY(scan_u32(SCAN_SUM, cnt, off, nblk, false, sws, st));
@@ -2061,7 +2172,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     HIP_TRY(hipEventRecord(c->ev_sorted, st));
     HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
     if (NL > 0) {
-      k_finalize<BITS><<<(u32) div_up(NL, FIN_TILE), FIN_THREADS, 0, c->st2>>>(
+      k_finalize<BITS><<<stride_grid(div_up(NL, FIN_TILE)), FIN_THREADS, 0, c->st2>>>(
           skey, sa32, NL, prefixlength, want_suf ? c->suf : nullptr,
           want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, nullptr,
           c->d_stats, prev_key, has_prev, index_offset);
@@ -2071,8 +2182,8 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     return 0;
   };
   if (NL > 0) {
-    k_tiebits<BITS><<<(u32) div_up(NL, 4096), 256, 0, st>>>(skey, NL, c->tiebits,
-                                                           c->d_stats);
+    k_tiebits<BITS><<<stride_grid(div_up(NL, 4096)), 256, 0, st>>>(skey, NL, c->tiebits,
+                                                                   c->d_stats);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -2275,18 +2386,19 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         fprintf(stderr, "gtamd: round %u h=%llu tied=%llu\n", rounds, (unsigned long long) h,
                 (unsigned long long) m);
       if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
-      HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, sizeof(u32), st));
       const u32 ntiles = (u32) div_up(m, RT_TILE);
       u32 *tilecnt = koff, *tileoff = koff + ntiles + 16;   // (free until the apply step)
       k_round_tile<<<ntiles, RT_THREADS, 0, st>>>(
           uidx, upos, ugrp, k2, m, cvo, hv, flg, tilecnt, c->d_stats,
           parts ? nullptr : rank, h, n);
       HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, ntiles, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(tileoff, tilecnt, ntiles, c->d_stats);
+      HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
-      const u64 nf = c->h_stats->count2;
+      const u64 nf = c->h_stats->count;
       if (nf > 0) {
         // groups crossing a tile border / larger than a tile: global radix sort
-        TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, ntiles, false, scanws2, st));
         k_flag_gather<<<ntiles, RT_THREADS, 0, st>>>(flg, tileoff, ugrp, k2, upos, m,
                                                      ckey_a, cval_a, fj);
         HIP_TRY(hipGetLastError());
@@ -2362,7 +2474,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
                                      rws2, st, nullptr, nullptr));
       const u32 *pk = (pn & 1) ? pkey_b : pkey_a;
       const u32 *pv = (pn & 1) ? pval_b : cval_a;
-      k_lcp_chunks<BITS><<<(u32) div_up(div_up(m1, LCP_CHUNK), 256), 256, 0, st>>>(
+      k_lcp_chunks<BITS><<<stride_grid(div_up(div_up(m1, LCP_CHUNK), 256)), 256, 0, st>>>(
           c->text, pk, pv, m1, sa32, c->lcp, lcpfull, c->d_stats);
       HIP_TRY(hipGetLastError());
       k_large_counts<<<g0, 256, 0, st>>>(uidx0, c->lcp, m0, bcnt0);

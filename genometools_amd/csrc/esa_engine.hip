@@ -938,14 +938,29 @@ __global__ __launch_bounds__(256) void k_unres_emit(
   const int lane = threadIdx.x & 63;
   const u64 wave = ((u64) blockIdx.x * 256 + threadIdx.x) >> 6;
   const u64 lt = (1ull << lane) - 1ull;
+  // lanes 0..16 fetch the wave's words (and the one behind them), offsets and
+  // carries in one go; the walk below takes them from registers, so that its
+  // only memory traffic is the list itself
+  const u64 w0 = wave * UE_WORDS_PER_WAVE;
+  u64 my_t = 0;
+  u32 my_off = 0, my_carry = 0;
+  if (lane <= UE_WORDS_PER_WAVE && w0 + lane < nwords) {
+    my_t = tiebits[w0 + lane];
+    if (lane < UE_WORDS_PER_WAVE) {
+      my_off = off[w0 + lane];
+      my_carry = carry[w0 + lane];
+    }
+  }
+#pragma unroll
   for (int k = 0; k < UE_WORDS_PER_WAVE; k++) {
-    const u64 w = wave * UE_WORDS_PER_WAVE + k;
+    const u64 w = w0 + k;
     if (w >= nwords) return;
-    const u64 t = tiebits[w];
-    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    const u64 t = __shfl(my_t, k, 64);
+    const u64 nx = __shfl(my_t, k + 1, 64);    // 0 behind the last word
+    const u32 offw = __shfl(my_off, k, 64), carryw = __shfl(my_carry, k, 64);
     const u64 u = t | (t >> 1) | (nx << 63);
     if (!((u >> lane) & 1ull)) continue;
-    const u32 j = off[w] + (u32) __popcll(u & lt);
+    const u32 j = offw + (u32) __popcll(u & lt);
     const u64 i = w * 64 + lane;
     // head of i's group: highest "not tied" entry at or below i
     const u64 below = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
@@ -953,7 +968,7 @@ __global__ __launch_bounds__(256) void k_unres_emit(
     uidx0[j] = (u32) i;
     uidx[j] = (u32) i;
     upos[j] = sa32[i];
-    ugrp[j] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carry[w];
+    ugrp[j] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carryw;
   }
 }
 

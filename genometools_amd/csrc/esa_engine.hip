@@ -322,6 +322,188 @@ __global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
   }
 }
 
+// DNA, whole-table builds: keygen and the first radix pass in one.  The lowest
+// sorted digit is dcode (5 bits), which is 0 for every suffix with no special
+// among its first 20 symbols -- 99.5 % of a genome -- so that pass is a stable
+// partition that moves almost nothing: all dcode-0 pairs stay in text order,
+// the few others go behind them by class.  Written as a pass of the general
+// sort it costs a keygen store, a histogram read and a full scatter (29 ms at
+// 3 Gbp).  Here: k_dc_hist_dna counts the classes per 4096-position tile from
+// the special bitmap alone; after the sort's own column scan k_keygen_pass0_dna
+// makes the keys (16 consecutive suffixes per thread from one word pair), packs
+// the tile's dcode-0 pairs in LDS and writes them as one coalesced run at their
+// final place of this pass; the rare others are ranked by one wave, in
+// position order, with the ballot match of the scatter kernel.
+constexpr int KP_TILE = 4096;          // = the sort's tile
+constexpr int KP_PER = 16;
+constexpr int KP_ROW = 256;            // = words per tile in the sort's histogram
+
+__device__ __forceinline__ u32 dna_dcode_of(u64 s /* special bits of 20 positions */) {
+  constexpr int SYMS = Key<2>::SYMS;
+  if (s == 0) return 0;
+  const int d = __ffsll((unsigned long long) s) - 1;
+  return d == 0 ? Key<2>::DMAX : (u32) (SYMS - d);
+}
+
+__global__ __launch_bounds__(256) void k_dc_hist_dna(Text t, u64 N, u32 *__restrict__ hist) {
+  constexpr int SYMS = Key<2>::SYMS;
+  __shared__ u32 h[32];
+  if (threadIdx.x < 32) h[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 p0 = (u64) blockIdx.x * KP_TILE + (u64) threadIdx.x * KP_PER;
+  u32 n0 = 0;
+  if (p0 < N) {
+    const int npos = N - p0 < KP_PER ? (int) (N - p0) : KP_PER;
+    const u64 S = sp_window(t, p0);
+    if ((S & ((1ull << (npos + SYMS - 1)) - 1ull)) == 0) {
+      n0 = (u32) npos;
+    } else {
+      for (int g = 0; g < npos; g++) {
+        const u32 dc = dna_dcode_of((S >> g) & ((1ull << SYMS) - 1ull));
+        if (dc == 0) n0++; else atomicAdd(&h[dc], 1u);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) n0 += __shfl_xor(n0, d, 64);
+  if ((threadIdx.x & 63) == 0 && n0) atomicAdd(&h[0], n0);
+  __syncthreads();
+  hist[(u64) blockIdx.x * KP_ROW + threadIdx.x] = threadIdx.x < 32 ? h[threadIdx.x] : 0u;
+}
+
+typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
+
+__global__ __launch_bounds__(256) void k_keygen_pass0_dna(
+    Text t, u64 N, const u32 *__restrict__ hist_scanned, u64 *__restrict__ keys,
+    u32 *__restrict__ vals) {
+  using K = Key<2>;
+  using P = Pay<2>;
+  constexpr int SYMS = K::SYMS;
+  static_assert(16 + (KP_PER - 1) + SYMS <= 64, "the windows of a thread must fit one word pair");
+  __shared__ u64 s_key[KP_TILE];
+  __shared__ u32 s_val[KP_TILE];
+  __shared__ u32 s_base[32], s_run_mem[32];
+  __shared__ u32 s_scan[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const u64 tile_base = (u64) blockIdx.x * KP_TILE;
+  const u32 tile_valid = (u32) (N - tile_base < (u64) KP_TILE ? N - tile_base : (u64) KP_TILE);
+  if (tid < 32) {
+    s_base[tid] = hist_scanned[(u64) blockIdx.x * KP_ROW + tid];
+    s_run_mem[tid] = 0;
+  }
+  const u64 p0 = tile_base + (u64) tid * KP_PER;
+  const int npos = p0 >= N ? 0 : (N - p0 < KP_PER ? (int) (N - p0) : KP_PER);
+  u64 key[KP_PER];
+  u32 zero = 0;                       // bit g: suffix p0 + g has dcode 0
+  if (npos > 0) {
+    const u64 w = p0 >> 5;
+    const int o = (int) (p0 & 31) * 2;           // 0 or 32
+    const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
+    const u64 a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;   // symbols p0 .. p0+31
+    const u64 a_lo = lo << o;
+    const u64 sw = p0 >> 6;
+    const int so = (int) (p0 & 63);              // 0, 16, 32, 48
+    const u64 s0 = sp_word(t, sw), s1 = sp_word(t, sw + 1);
+    const u64 S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;   // specials p0 .. p0+63
+    u32 pay;
+    if (p0 == 0) {
+      pay = P::UNDEF;
+    } else {
+      const u32 c = o ? (u32) (hi >> (64 - o)) & 3u : (u32) tb_word(t, w - 1) & 3u;
+      const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
+      pay = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
+    }
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) {
+      const u64 win = g ? (a_hi << (2 * g)) | (a_lo >> (64 - 2 * g)) : a_hi;
+      const u64 s = (S >> g) & ((1ull << SYMS) - 1ull);
+      const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+      if (d == 0) {
+        key[g] = (~0ull << K::DSHIFT) | pay;
+      } else {
+        u64 pre = win >> K::LOW_BITS;
+        u32 dc = 0;
+        if (d < SYMS) {
+          pre |= (1ull << (2 * (SYMS - d))) - 1ull;
+          dc = (u32) (SYMS - d);
+        }
+        key[g] = (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
+      }
+      if (s == 0 && g < npos) zero |= 1u << g;
+      const u32 c = (u32) (win >> 62);
+      pay = (c < 2u && (s & 1ull)) ? ((c & 1u) ? P::SEP : P::WILD) : c;
+    }
+  }
+  // places inside the tile: dcode-0 pairs from the front in position order,
+  // the others behind them, also in position order
+  u32 cnt0;
+  u32 off0 = block_scan_excl_sum((u32) __popc(zero), &cnt0, s_scan);
+  const u32 before = (u32) tid * KP_PER < tile_valid ? (u32) tid * KP_PER : tile_valid;
+  u32 offr = cnt0 + (before - off0);
+#pragma unroll
+  for (int g = 0; g < KP_PER; g++) {
+    if (g < npos) {
+      const u32 at = ((zero >> g) & 1u) ? off0++ : offr++;
+      s_key[at] = key[g];
+      s_val[at] = (u32) (p0 + g);
+    }
+  }
+  __syncthreads();
+  // the dcode-0 run, 16 bytes per lane where the output index allows it
+  const u32 ob0 = s_base[0];
+  {
+    const u32 head = (ob0 & 1u) < cnt0 ? (ob0 & 1u) : cnt0;     // to an even index
+    if ((u32) tid < head) keys[ob0 + tid] = s_key[tid];
+    const u32 pairs = (cnt0 - head) >> 1;
+    for (u32 q = (u32) tid; q < pairs; q += 256) {
+      const u32 e = head + 2u * q;
+      *reinterpret_cast<ulonglong2 *>(keys + ob0 + e) = make_ulonglong2(s_key[e], s_key[e + 1]);
+    }
+    if (tid == 0 && head + 2u * pairs < cnt0) keys[ob0 + cnt0 - 1] = s_key[cnt0 - 1];
+  }
+  {
+    const u32 mis = (4u - (ob0 & 3u)) & 3u;                      // to a multiple of 4
+    const u32 head = mis < cnt0 ? mis : cnt0;
+    if ((u32) tid < head) vals[ob0 + tid] = s_val[tid];
+    const u32 quads = (cnt0 - head) >> 2;
+    for (u32 q = (u32) tid; q < quads; q += 256) {
+      const u32 e = head + 4u * q;
+      *reinterpret_cast<uint4 *>(vals + ob0 + e) =
+          make_uint4(s_val[e], s_val[e + 1], s_val[e + 2], s_val[e + 3]);
+    }
+    const u32 done = head + 4u * quads;
+    if ((u32) tid < cnt0 - done) vals[ob0 + done + tid] = s_val[done + tid];
+  }
+  const u32 nrare = tile_valid - cnt0;
+  if (nrare == 0 || tid >= 64) return;
+  // one wave ranks the rest by class, 64 at a time
+  lds_vu32 *s_run = (lds_vu32 *) s_run_mem;
+  for (u32 base = 0; base < nrare; base += 64) {
+    const u32 idx = base + (u32) lane;
+    const bool valid = idx < nrare;
+    const u64 k = valid ? s_key[cnt0 + idx] : 0ull;
+    const u32 v = valid ? s_val[cnt0 + idx] : 0u;
+    const u32 c = valid ? K::dcode(k) : 32u;      // 32: no pair in this lane
+    u32 mlo = ~0u, mhi = ~0u;
+#pragma unroll
+    for (int b = 0; b < 6; b++) {
+      u32 sx = (u32) ((int) (c << (31 - b)) >> 31);
+      asm volatile("" : "+v"(sx));
+      const u64 bal = __ballot(sx != 0);
+      mlo = __builtin_amdgcn_bitop3_b32(mlo, (u32) bal, sx, 0x90);
+      mhi = __builtin_amdgcn_bitop3_b32(mhi, (u32) (bal >> 32), sx, 0x90);
+    }
+    const u32 intra = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+    const u32 old = s_run[c & 31u];
+    if (valid && intra == 0) s_run[c] = old + (u32) __popc(mlo) + (u32) __popc(mhi);
+    if (valid) {
+      const u32 g = s_base[c] + old + intra;
+      keys[g] = k;
+      vals[g] = v;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // part builds: lexicographic range partition (the reference's -parts idea,
 // src/match/sfx-partssuf.c:172-347, filter src/match/sfx-suffixer.c:375-398)
@@ -2063,8 +2245,19 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
 
   // ---- keygen (whole table, or the pairs of this part's key range)
   u64 NL = N, index_offset = 0;
+  // DNA whole-table builds: the keygen also does the sort's first pass (the
+  // dcode digit); GTAMD_FUSED_PASS0=0 takes the plain keygen + full sort
+  bool pass0_done = false;
   if (!parts) {
-    if (BITS == 2)
+    const char *fz = getenv("GTAMD_FUSED_PASS0");
+    if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
+      const u32 ntiles = (u32) div_up(N, KP_TILE);
+      k_dc_hist_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws);
+      HIP_TRY(hipGetLastError());
+      TRY(radix_scan_tile_hist(c->rws, N, st));
+      k_keygen_pass0_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws, c->k0, c->v0);
+      pass0_done = true;
+    } else if (BITS == 2)
       k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
     else
       k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
@@ -2147,6 +2340,14 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
 
   // ---- first sort: all key bits above the payload
   int shifts[16], widths[16], np = 0;
+  if (pass0_done) {   // the dcode digit is sorted: the prefix bits are left
+    static_assert((64 - Key<2>::LOW_BITS) % 8 == 0, "whole passes over the DNA prefix");
+    for (int b = K::LOW_BITS; b < 64; b += 8) {
+      shifts[np] = b;
+      widths[np] = 64 - b < 8 ? 64 - b : 8;
+      np++;
+    }
+  } else
   for (int b = K::DSHIFT; b < 64; b += 8) {   // dcode and prefix, contiguous
     shifts[np] = b;
     widths[np] = 64 - b < 8 ? 64 - b : 8;

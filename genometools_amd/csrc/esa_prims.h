@@ -26,3 +26,11 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
                      const int *shifts, const int *widths, int npasses,
                      u32 *ws, hipStream_t st, hipEvent_t *ev_pairs,
                      int *n_ev, u8 *dig_a = nullptr, u8 *dig_b = nullptr);
+
+// For a caller that makes the first pass of a sort itself (the DNA keygen does:
+// it writes its keys partitioned on the lowest digit straight away).  ws is the
+// sort's workspace; its first ceil(n / 4096) * 256 words are the tile-major digit
+// histogram the caller has filled (row t = counts of tile t, 4096 pairs per
+// tile); on return every entry is the global output index where that tile's
+// pairs of that digit start, exactly what the sort's own passes use.
+int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st);

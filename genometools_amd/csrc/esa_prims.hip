@@ -765,6 +765,19 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
   return 0;
 }
 
+int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st) {
+  const u32 ntiles = (u32) div_up(n, RS_TILE);
+  u32 *hist = ws, *scanws = ws + (u64) ntiles * RADIX;
+  const u32 nchunks = (ntiles + CS_ROWS - 1) / CS_ROWS;
+  k_cs_chunksum<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
+  HIP_TRY(hipGetLastError());
+  k_cs_chunkbase<<<1, RADIX, 0, st>>>(scanws, nchunks);
+  HIP_TRY(hipGetLastError());
+  k_cs_rows<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 template int radix_sort_pairs<u64, u32>(u64 *, u32 *, u64 *, u32 *, u64,
                                         const int *, const int *, int, u32 *,
                                         hipStream_t, hipEvent_t *, int *, u8 *,

@@ -1164,11 +1164,23 @@ __global__ __launch_bounds__(256) void k_unres_emit(
 __global__ __launch_bounds__(256) void k_heads(
     const u64 *__restrict__ tiebits, const u32 *__restrict__ carry, u64 N,
     u32 rank_offset, u32 *__restrict__ heads) {
-  const u64 base = (u64) blockIdx.x * 1024;
+  // four consecutive entries per thread (one 16-byte store): they share their
+  // bitmap word, the head of an entry is the head of the one before it unless
+  // it starts a group itself
+  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= N) return;
+  const u64 t = tiebits[i0 >> 6];
+  u32 h[4];
+  h[0] = group_head(tiebits, carry, i0);
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u64 i = base + (u64) j * 256 + threadIdx.x;
-    if (i < N) heads[i] = rank_offset + group_head(tiebits, carry, i);
+  for (int g = 1; g < 4; g++)
+    h[g] = ((t >> ((i0 + g) & 63)) & 1ull) ? h[g - 1] : (u32) (i0 + g);
+  if (i0 + 4 <= N) {
+    *reinterpret_cast<uint4 *>(heads + i0) =
+        make_uint4(rank_offset + h[0], rank_offset + h[1], rank_offset + h[2],
+                   rank_offset + h[3]);
+  } else {
+    for (int g = 0; g < 4 && i0 + g < N; g++) heads[i0 + g] = rank_offset + h[g];
   }
 }
 
@@ -2255,7 +2267,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       k_dc_hist_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws);
       HIP_TRY(hipGetLastError());
       TRY(radix_scan_tile_hist(c->rws, N, st));
-      k_keygen_pass0_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws, c->k0, c->v0);
+      // (into the second buffer pair: the five passes left then end in the
+      // first, where the six passes of the plain path end too)
+      k_keygen_pass0_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws, c->k1, c->v1);
       pass0_done = true;
     } else if (BITS == 2)
       k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
@@ -2354,12 +2368,14 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     np++;
   }
   int nev = 0;
-  TRY(radix_sort_pairs<u64, u32>(c->k0, c->v0, c->k1, c->v1, NL, shifts, widths, np,
+  u64 *ka = pass0_done ? c->k1 : c->k0, *kb = pass0_done ? c->k0 : c->k1;
+  u32 *va = pass0_done ? c->v1 : c->v0, *vb = pass0_done ? c->v0 : c->v1;
+  TRY(radix_sort_pairs<u64, u32>(ka, va, kb, vb, NL, shifts, widths, np,
                             c->rws, st, c->ev_scatter, &nev, c->dig0, c->dig1));
-  u64 *skey = (np & 1) ? c->k1 : c->k0;   // sorted keys
-  u32 *sa32 = (np & 1) ? c->v1 : c->v0;   // positions in suffix order
-  u64 *fkey = (np & 1) ? c->k0 : c->k1;   // free key-sized buffer
-  u32 *rank = (np & 1) ? c->v0 : c->v1;   // free value-sized buffer
+  u64 *skey = (np & 1) ? kb : ka;   // sorted keys
+  u32 *sa32 = (np & 1) ? vb : va;   // positions in suffix order
+  u64 *fkey = (np & 1) ? ka : kb;   // free key-sized buffer
+  u32 *rank = (np & 1) ? va : vb;   // free value-sized buffer
   HIP_TRY(hipEventRecord(c->ev[2], st));
 
   if (want & GTAMD_WANT_BCK) TRY(build_bcktab<BITS>(c, skey, NL, prefixlength, st));

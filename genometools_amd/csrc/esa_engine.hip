@@ -2452,7 +2452,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     TRY(fetch_stats(c));
     m0 = c->h_stats->count;
     // arena layout (u32 units unless noted)
-    const u64 mp = m0 + 64;
+    const u64 mp = (m0 + 64 + 3) & ~3ull;   // every array of the arena 16-byte aligned
     const u64 need = mp * 4 * 18 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
                      scan_workspace_words(m0) * 4 + 4096;
     TRY(ensure_arena(c, need));

@@ -128,12 +128,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(
   for (int i = tid; i < RS_WAVES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
   __syncthreads();
   const u64 base = (u64) blockIdx.x * RS_TILE;
+  constexpr int PER16 = 16 / (int) sizeof(K);   // keys per 16-byte load
+  if (base + RS_TILE <= n && (reinterpret_cast<uintptr_t>(keys) & 15) == 0) {
+    // full tile: 16 bytes per lane and load (the order inside the tile does not
+    // matter to a histogram)
+    K k[RS_ITEMS];
 #pragma unroll
-  for (int j = 0; j < RS_ITEMS; j++) {
-    u64 idx = base + (u64) j * RS_THREADS + tid;
-    if (idx < n) {
-      u32 d = (u32) (keys[idx] >> shift) & mask;
-      atomicAdd(&h[w][d], 1u);
+    for (int j = 0; j < RS_ITEMS / PER16; j++) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(
+          keys + base + ((u64) j * RS_THREADS + tid) * PER16);
+      if (sizeof(K) == 8) {
+        k[j * PER16] = (K) (((u64) q.y << 32) | q.x);
+        k[j * PER16 + 1] = (K) (((u64) q.w << 32) | q.z);
+      } else {
+        k[j * PER16] = (K) q.x;
+        k[j * PER16 + 1] = (K) q.y;
+        if (PER16 > 2) {
+          k[j * PER16 + (PER16 > 2 ? 2 : 0)] = (K) q.z;
+          k[j * PER16 + (PER16 > 2 ? 3 : 0)] = (K) q.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; j++) atomicAdd(&h[w][(u32) (k[j] >> shift) & mask], 1u);
+  } else {
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; j++) {
+      u64 idx = base + (u64) j * RS_THREADS + tid;
+      if (idx < n) {
+        u32 d = (u32) (keys[idx] >> shift) & mask;
+        atomicAdd(&h[w][d], 1u);
+      }
     }
   }
   __syncthreads();

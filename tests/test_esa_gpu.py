@@ -272,3 +272,27 @@ def test_rank_table_window_shapes(gpu, monkeypatch, wbits, n):
     res = esa.suffixerator_tables(enc, 4)
     assert res.stats["refine_rounds"] > 0
     _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 70_001, 1_000_003])
+def test_keygen_with_and_without_fused_first_pass(gpu, monkeypatch, fused, n):
+    """DNA keygen: fused with the sort's dcode pass (k_dc_hist_dna +
+    k_keygen_pass0_dna, the default) and plain (k_keygen_dna + all six passes,
+    GTAMD_FUSED_PASS0=0, the A/B switch) give the reference's tables; sizes
+    around the 16-suffix thread groups and the 4096-suffix tiles, many specials"""
+    monkeypatch.setenv("GTAMD_FUSED_PASS0", fused)
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 1000 + n, n)
+    rng = np.random.default_rng(n)
+    # more specials than the model has: runs and single ones, separators too
+    for at in rng.integers(0, n, size=max(1, n // 200)):
+        enc[at:at + int(rng.integers(1, 40))] = 254
+    for at in rng.integers(1, max(2, n - 1), size=n // 5000):
+        if 0 < at < n - 1 and enc[at - 1] != 255 and enc[at + 1] != 255:
+            enc[at] = 255
+    if enc[0] == 255:
+        enc[0] = 0
+    if enc[-1] == 255:
+        enc[-1] = 0
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)

@@ -1923,8 +1923,14 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
                  scan_workspace_words(div_up(N, 64)) + 64;
   CTX_TRY(hipMalloc(&c->rws, c->rws_words * 4));
   CTX_TRY(hipMalloc(&c->isa_tmp, Npad * 8));
-  CTX_TRY(hipMalloc(&c->dig0, Npad));
-  CTX_TRY(hipMalloc(&c->dig1, Npad));
+  {
+    // digit-byte side arrays of the sort: an experiment switch (esa_prims.hip)
+    const char *db = getenv("GTAMD_DIGBYTES");
+    if (db != nullptr && db[0] == '1') {
+      CTX_TRY(hipMalloc(&c->dig0, Npad));
+      CTX_TRY(hipMalloc(&c->dig1, Npad));
+    }
+  }
   CTX_TRY(hipMalloc(&c->suf, Npad * 8));
   CTX_TRY(hipMalloc(&c->lcp, Npad));
   CTX_TRY(hipMalloc(&c->bwt, Npad));

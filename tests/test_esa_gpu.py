@@ -296,3 +296,27 @@ def test_keygen_with_and_without_fused_first_pass(gpu, monkeypatch, fused, n):
         enc[-1] = 0
     res = esa.suffixerator_tables(enc, 4)
     _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("kind", ["all_wildcards", "alternating", "every_20th", "runs_of_19",
+                                  "separators_every_21"])
+def test_keygen_first_pass_special_heavy(gpu, kind):
+    """tiles in which most or all suffixes have a special among their first 20
+    symbols: the rare-class path of k_keygen_pass0_dna becomes the only path"""
+    n = 3 * 4096 + 77
+    rng = np.random.default_rng(5)
+    enc = rng.integers(0, 4, size=n).astype(np.uint8)
+    if kind == "all_wildcards":
+        enc[:] = 254
+    elif kind == "alternating":
+        enc[::2] = 254
+    elif kind == "every_20th":
+        enc[19::20] = 254
+    elif kind == "runs_of_19":
+        enc[:] = 254
+        enc[::20] = rng.integers(0, 4, size=enc[::20].size)
+    else:
+        enc[21::22] = 255
+        enc[-1] = 0
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)

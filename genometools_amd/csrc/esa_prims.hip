@@ -186,17 +186,40 @@ __global__ __launch_bounds__(RADIX) void k_cs_chunksum(
   chunksum[(u64) blockIdx.x * RADIX + threadIdx.x] = acc;
 }
 
-__global__ __launch_bounds__(RADIX) void k_cs_chunkbase(u32 *__restrict__ chunksum,
-                                                        u32 nchunks) {
-  __shared__ u32 s_scan[4];
-  // column totals, then their exclusive scan over the digits
+// one workgroup of 4 x 256 threads: thread (q, d) walks quarter q of column d
+constexpr int CB_PARTS = 4;
+__global__ __launch_bounds__(RADIX * CB_PARTS) void k_cs_chunkbase(
+    u32 *__restrict__ chunksum, u32 nchunks) {
+  __shared__ u32 s_scan[RADIX * CB_PARTS / 64];
+  __shared__ u32 s_part[CB_PARTS][RADIX];
+  __shared__ u32 s_colbase[RADIX];
+  const u32 d = threadIdx.x & (RADIX - 1), q = threadIdx.x / RADIX;
+  const u32 per = (nchunks + CB_PARTS - 1) / CB_PARTS;
+  const u32 c0 = q * per < nchunks ? q * per : nchunks;
+  const u32 c1 = c0 + per < nchunks ? c0 + per : nchunks;
+  // column totals of the quarters, then the exclusive scan of the whole columns
+  // over the digits
   u32 tot = 0;
-  for (u32 c = 0; c < nchunks; c++) tot += chunksum[(u64) c * RADIX + threadIdx.x];
+  for (u32 c = c0; c < c1; c++) tot += chunksum[(u64) c * RADIX + d];
+  s_part[q][d] = tot;
+  __syncthreads();
+  u32 col = 0, before = 0;
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < CB_PARTS; i++) col += s_part[i][d];
+  }
+  // (the first 256 threads carry the column totals, the others add nothing and
+  // come behind them)
   u32 all;
-  u32 run = block_scan_excl<SCAN_SUM>(tot, &all, s_scan);
-  for (u32 c = 0; c < nchunks; c++) {
-    const u32 v = chunksum[(u64) c * RADIX + threadIdx.x];
-    chunksum[(u64) c * RADIX + threadIdx.x] = run;
+  const u32 colbase =
+      block_scan_excl<SCAN_SUM, RADIX * CB_PARTS>(q == 0 ? col : 0u, &all, s_scan);
+  if (q == 0) s_colbase[d] = colbase;
+  __syncthreads();
+  for (u32 i = 0; i < q; i++) before += s_part[i][d];
+  u32 run = s_colbase[d] + before;
+  for (u32 c = c0; c < c1; c++) {
+    const u32 v = chunksum[(u64) c * RADIX + d];
+    chunksum[(u64) c * RADIX + d] = run;
     run += v;
   }
 }
@@ -768,7 +791,7 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
       const u32 nchunks = (ntiles + CS_ROWS - 1) / CS_ROWS;
       k_cs_chunksum<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
       HIP_TRY(hipGetLastError());
-      k_cs_chunkbase<<<1, RADIX, 0, st>>>(scanws, nchunks);
+      k_cs_chunkbase<<<1, RADIX * CB_PARTS, 0, st>>>(scanws, nchunks);
       HIP_TRY(hipGetLastError());
       k_cs_rows<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
       HIP_TRY(hipGetLastError());
@@ -800,7 +823,7 @@ int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st) {
   const u32 nchunks = (ntiles + CS_ROWS - 1) / CS_ROWS;
   k_cs_chunksum<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
   HIP_TRY(hipGetLastError());
-  k_cs_chunkbase<<<1, RADIX, 0, st>>>(scanws, nchunks);
+  k_cs_chunkbase<<<1, RADIX * CB_PARTS, 0, st>>>(scanws, nchunks);
   HIP_TRY(hipGetLastError());
   k_cs_rows<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
   HIP_TRY(hipGetLastError());

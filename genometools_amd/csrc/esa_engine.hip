@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
 // final place of this pass; the rare others are ranked by one wave, in
 // position order, with the ballot match of the scatter kernel.
 constexpr int KP_TILE = 4096;          // = the sort's tile
-constexpr int KP_PER = 16;
+constexpr int KP_PER = 8;              // consecutive suffixes per thread
+constexpr int KP_THREADS = KP_TILE / KP_PER;   // 512: 8 waves per workgroup, 3 workgroups per CU
 constexpr int KP_ROW = 256;            // = words per tile in the sort's histogram
 
 __device__ __forceinline__ u32 dna_dcode_of(u64 s /* special bits of 20 positions */) {
@@ -345,7 +346,8 @@ __device__ __forceinline__ u32 dna_dcode_of(u64 s /* special bits of 20 position
   return d == 0 ? Key<2>::DMAX : (u32) (SYMS - d);
 }
 
-__global__ __launch_bounds__(256) void k_dc_hist_dna(Text t, u64 N, u32 *__restrict__ hist) {
+__global__ __launch_bounds__(KP_THREADS) void k_dc_hist_dna(Text t, u64 N,
+                                                            u32 *__restrict__ hist) {
   constexpr int SYMS = Key<2>::SYMS;
   __shared__ u32 h[32];
   if (threadIdx.x < 32) h[threadIdx.x] = 0;
@@ -368,22 +370,24 @@ __global__ __launch_bounds__(256) void k_dc_hist_dna(Text t, u64 N, u32 *__restr
   for (int d = 32; d >= 1; d >>= 1) n0 += __shfl_xor(n0, d, 64);
   if ((threadIdx.x & 63) == 0 && n0) atomicAdd(&h[0], n0);
   __syncthreads();
-  hist[(u64) blockIdx.x * KP_ROW + threadIdx.x] = threadIdx.x < 32 ? h[threadIdx.x] : 0u;
+  if (threadIdx.x < KP_ROW)
+    hist[(u64) blockIdx.x * KP_ROW + threadIdx.x] = threadIdx.x < 32 ? h[threadIdx.x] : 0u;
 }
 
 typedef __attribute__((address_space(3))) volatile u32 lds_vu32;
 
-__global__ __launch_bounds__(256) void k_keygen_pass0_dna(
+__global__ __launch_bounds__(KP_THREADS) void k_keygen_pass0_dna(
     Text t, u64 N, const u32 *__restrict__ hist_scanned, u64 *__restrict__ keys,
     u32 *__restrict__ vals) {
   using K = Key<2>;
   using P = Pay<2>;
   constexpr int SYMS = K::SYMS;
-  static_assert(16 + (KP_PER - 1) + SYMS <= 64, "the windows of a thread must fit one word pair");
+  static_assert(32 - KP_PER + (KP_PER - 1) + SYMS <= 64 && 32 % KP_PER == 0,
+                "the windows of a thread must fit one word pair");
   __shared__ u64 s_key[KP_TILE];
   __shared__ u32 s_val[KP_TILE];
   __shared__ u32 s_base[32], s_run_mem[32];
-  __shared__ u32 s_scan[4];
+  __shared__ u32 s_scan[KP_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63;
   const u64 tile_base = (u64) blockIdx.x * KP_TILE;
   const u32 tile_valid = (u32) (N - tile_base < (u64) KP_TILE ? N - tile_base : (u64) KP_TILE);
@@ -397,12 +401,12 @@ __global__ __launch_bounds__(256) void k_keygen_pass0_dna(
   u32 zero = 0;                       // bit g: suffix p0 + g has dcode 0
   if (npos > 0) {
     const u64 w = p0 >> 5;
-    const int o = (int) (p0 & 31) * 2;           // 0 or 32
+    const int o = (int) (p0 & 31) * 2;           // a multiple of 2 * KP_PER
     const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
     const u64 a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;   // symbols p0 .. p0+31
     const u64 a_lo = lo << o;
     const u64 sw = p0 >> 6;
-    const int so = (int) (p0 & 63);              // 0, 16, 32, 48
+    const int so = (int) (p0 & 63);              // a multiple of KP_PER
     const u64 s0 = sp_word(t, sw), s1 = sp_word(t, sw + 1);
     const u64 S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;   // specials p0 .. p0+63
     u32 pay;
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(256) void k_keygen_pass0_dna(
   // places inside the tile: dcode-0 pairs from the front in position order,
   // the others behind them, also in position order
   u32 cnt0;
-  u32 off0 = block_scan_excl_sum((u32) __popc(zero), &cnt0, s_scan);
+  u32 off0 = block_scan_excl<SCAN_SUM, KP_THREADS>((u32) __popc(zero), &cnt0, s_scan);
   const u32 before = (u32) tid * KP_PER < tile_valid ? (u32) tid * KP_PER : tile_valid;
   u32 offr = cnt0 + (before - off0);
 #pragma unroll
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void k_keygen_pass0_dna(
     const u32 head = (ob0 & 1u) < cnt0 ? (ob0 & 1u) : cnt0;     // to an even index
     if ((u32) tid < head) keys[ob0 + tid] = s_key[tid];
     const u32 pairs = (cnt0 - head) >> 1;
-    for (u32 q = (u32) tid; q < pairs; q += 256) {
+    for (u32 q = (u32) tid; q < pairs; q += KP_THREADS) {
       const u32 e = head + 2u * q;
       *reinterpret_cast<ulonglong2 *>(keys + ob0 + e) = make_ulonglong2(s_key[e], s_key[e + 1]);
     }
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256) void k_keygen_pass0_dna(
     const u32 head = mis < cnt0 ? mis : cnt0;
     if ((u32) tid < head) vals[ob0 + tid] = s_val[tid];
     const u32 quads = (cnt0 - head) >> 2;
-    for (u32 q = (u32) tid; q < quads; q += 256) {
+    for (u32 q = (u32) tid; q < quads; q += KP_THREADS) {
       const u32 e = head + 4u * q;
       *reinterpret_cast<uint4 *>(vals + ob0 + e) =
           make_uint4(s_val[e], s_val[e + 1], s_val[e + 2], s_val[e + 3]);
@@ -2270,12 +2274,12 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     const char *fz = getenv("GTAMD_FUSED_PASS0");
     if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
-      k_dc_hist_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws);
+      k_dc_hist_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws);
       HIP_TRY(hipGetLastError());
       TRY(radix_scan_tile_hist(c->rws, N, st));
       // (into the second buffer pair: the five passes left then end in the
       // first, where the six passes of the plain path end too)
-      k_keygen_pass0_dna<<<ntiles, 256, 0, st>>>(c->text, N, c->rws, c->k1, c->v1);
+      k_keygen_pass0_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws, c->k1, c->v1);
       pass0_done = true;
     } else if (BITS == 2)
       k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);

@@ -1267,7 +1267,7 @@ constexpr int RT_PER = RT_TILE / RT_THREADS;   // 8
 __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     const u32 *__restrict__ uidx, const u32 *__restrict__ upos,
     const u32 *__restrict__ ugrp, u32 *__restrict__ k2, u64 m,
-    u32 *__restrict__ cv, u32 *__restrict__ hv, u32 *__restrict__ flg,
+    u32 *__restrict__ cv, u32 *__restrict__ hv, u8 *__restrict__ flg,
     u32 *__restrict__ tilecnt, Stats *stats, const u32 *__restrict__ rank, u64 h,
     u64 n) {
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
@@ -1336,6 +1336,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   // does any group of this tile split in this round?  (inside a long repeat
   // most rounds leave a group as it is: every member's k2 is the same)
   int splits = 0;
+  u32 openbits = 0;   // deferred slots of this thread: one byte per thread in flg
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) tid * RT_PER + c;
@@ -1351,10 +1352,12 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     // local group | deferred | k2 | slot: a group is deferred as a whole, so
     // the flag bit never reorders anything
     s_key[e] = ((u64) lg << 44) | ((u64) open << 43) | ((u64) kk << 11) | (u64) e;
-    if (e < cnt) flg[base + e] = open;
+    openbits |= (u32) open << c;
     if (open && rank != nullptr) k2[base + e] = kraw;   // for the global path
     nflag += open;
   }
+  static_assert(RT_PER == 8, "one flag byte per thread");
+  flg[(u64) blockIdx.x * RT_THREADS + tid] = (u8) openbits;
   // (the barrier also orders the s_key writes before the network's reads)
   const int any_split = __syncthreads_or(splits);
   if (any_split) {
@@ -1471,18 +1474,15 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
 // global path for the deferred elements: composite key (group, k2).  One
 // workgroup per tile of k_round_tile; tileoff = exclusive scan of its counts.
 __global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
-    const u32 *__restrict__ flg, const u32 *__restrict__ tileoff,
+    const u8 *__restrict__ flg, const u32 *__restrict__ tileoff,
     const u32 *__restrict__ ugrp, const u32 *__restrict__ k2,
     const u32 *__restrict__ upos, u64 m, u64 *__restrict__ ckey,
     u32 *__restrict__ cval, u32 *__restrict__ fj) {
   __shared__ u32 s_scan[4];
   const u64 base = (u64) blockIdx.x * RT_TILE + (u64) threadIdx.x * RT_PER;
-  u32 f = 0, cnt = 0;
-#pragma unroll
-  for (int c = 0; c < RT_PER; c++) {
-    const u64 j = base + c;
-    if (j < m && flg[j]) { f |= 1u << c; cnt++; }
-  }
+  // (the tile kernel sets no bit at or behind m)
+  const u32 f = base < m ? (u32) flg[(u64) blockIdx.x * RT_THREADS + threadIdx.x] : 0u;
+  const u32 cnt = (u32) __popc(f);
   u32 tot;
   u32 o = tileoff[blockIdx.x] + block_scan_excl_sum(cnt, &tot, s_scan);
   if (f == 0) return;
@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_round_apply(
     const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
     const u32 *__restrict__ uidx, const u32 *__restrict__ ugrp, u64 m,
     u32 rank_offset, u32 *__restrict__ sa32, u32 *__restrict__ rank,
-    u32 *__restrict__ keep, u32 *__restrict__ blockcnt) {
+    u64 *__restrict__ keep, u32 *__restrict__ blockcnt) {
   __shared__ u32 s_cnt[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   bool kept = false;
@@ -1537,25 +1537,28 @@ __global__ __launch_bounds__(256) void k_round_apply(
     const bool resolved = head && nexthead;
     if (resolved) sa32[i] = p;   // final place; unresolved ones move again
     kept = !resolved;
-    keep[j] = kept ? 1u : 0u;
   }
-  // survivors of this block: the compaction scans these counts, not the flags
+  // survivors: one bit each (a word per wave) for the compaction, which scans
+  // the counts of the blocks, not the flags
   const u64 b = __ballot(kept);
-  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = (u32) __popcll(b);
+  if ((threadIdx.x & 63) == 0) {
+    keep[((u64) blockIdx.x * 256 + threadIdx.x) >> 6] = b;
+    s_cnt[threadIdx.x >> 6] = (u32) __popcll(b);
+  }
   __syncthreads();
   if (threadIdx.x == 0) blockcnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // boff: exclusive scan of the block counts
 __global__ __launch_bounds__(256) void k_round_compact(
-    const u32 *__restrict__ keep, const u32 *__restrict__ boff,
+    const u64 *__restrict__ keep, const u32 *__restrict__ boff,
     const u32 *__restrict__ blockcnt, const u32 *__restrict__ uidx,
     const u32 *__restrict__ cval, const u32 *__restrict__ gnew, u64 m,
     u32 *__restrict__ uidx2, u32 *__restrict__ upos2, u32 *__restrict__ ugrp2,
     Stats *stats) {
   __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  const u32 k = j < m ? keep[j] : 0u;
+  const u32 k = (u32) (keep[j >> 6] >> (j & 63)) & 1u;   // (no bit at or behind m)
   u32 tot;
   const u32 o = boff[blockIdx.x] + block_scan_excl_sum(k, &tot, s_scan);
   if (k) {
@@ -2479,11 +2482,11 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     u32 *cval_a = a32; a32 += mp;
     u32 *cval_b = a32; a32 += mp;
     u32 *hv = a32; a32 += mp;      // head values -> new group ids
-    u32 *keep = a32; a32 += mp;
+    u64 *keep = reinterpret_cast<u64 *>(a32); a32 += mp;   // 1 bit per slot
     u32 *koff = a32; a32 += mp;
     u32 *k2 = a32; a32 += mp;      // rank of the suffix h further on
     u32 *cvo = a32; a32 += mp;     // positions in the round's new order
-    u32 *flg = a32; a32 += mp;     // deferred to the global path
+    u8 *flg = reinterpret_cast<u8 *>(a32); a32 += mp;     // deferred to the global path (1 bit per slot)
     u32 *foff = a32; a32 += mp;
     u32 *fj = a32; a32 += mp;
     u32 *sendq = a32; a32 += mp;   // part builds: rank queries

@@ -7,7 +7,7 @@ tandem repeats, special runs, separators; DNA and protein) through
 each compared with the CPU oracle / host reader.  Dev tool; stops at the first
 difference and prints the seed.
 
-  python tools/fuzz_gpu.py --seconds 300 [--seed 1]
+  python tools/fuzz_gpu.py --seconds 300 [--seed 1] [--first CASE]
 """
 import argparse
 import os
@@ -132,8 +132,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0, help="first case number (to replay a stretch)")
     a = ap.parse_args()
-    t0, case = time.time(), 0
+    t0, case = time.time(), a.first
     with tempfile.TemporaryDirectory() as tmp:
         while time.time() - t0 < a.seconds:
             seed = a.seed * 1000003 + case

@@ -91,7 +91,12 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
   const int narrow = which == GTAMD_TAB_SUF && entrysize == 4;
   char path[4096];
   const uint64_t entries = gtamd_esa_table_entries(ctx, which);
-  const uint64_t chunk = (64u << 20) / (narrow ? 8 : entrysize);   /* 64 MiB staging buffers */
+  /* 64 MiB staging buffers (GTAMD_TABLE_CHUNK=BYTES: a test hook that forces
+     many pieces through the two-buffer hand-over on small tables) */
+  const char *chunkenv = getenv("GTAMD_TABLE_CHUNK");
+  const uint64_t chunkbytes = chunkenv != NULL && atoll(chunkenv) >= 64 ? (uint64_t) atoll(chunkenv)
+                                                                       : (64u << 20);
+  const uint64_t chunk = chunkbytes / (narrow ? 8 : entrysize);
   table_writer w;
   pthread_t thread;
   int rc = 0, k = 0;

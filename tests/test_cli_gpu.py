@@ -47,6 +47,31 @@ def test_cli_writes_reference_files(cli, name, tmp_path):
                 assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
 
 
+@pytest.mark.parametrize("chunk", ["64", "4096", "100000"])
+@pytest.mark.parametrize("suftabuint", [False, True])
+def test_cli_tables_written_in_many_pieces(cli, chunk, suftabuint, tmp_path, monkeypatch):
+    """the table files leave through two staging buffers and a writer thread;
+    GTAMD_TABLE_CHUNK shrinks the 64 MiB pieces so that a fixture's tables take
+    hundreds of hand-overs (incl. the narrowing of the 32-bit suffix table)"""
+    monkeypatch.setenv("GTAMD_TABLE_CHUNK", chunk)
+    name = "Duplicate.fna"
+    e = GOLDEN[name]
+    idx = str(tmp_path / "idx")
+    args = [cli, "-dna", "-suf", "-lcp", "-bwt", "-db", ou.fixture_path(name), "-indexname", idx]
+    subprocess.run(args + (["-suftabuint"] if suftabuint else []), check=True)
+    for ext in ("lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
+    with open(idx + ".suf", "rb") as f:
+        raw = f.read()
+    if suftabuint:
+        import numpy as np
+        wide = np.frombuffer(raw, dtype="<u4").astype("<u8").tobytes()
+        assert hashlib.md5(wide).hexdigest() == e["tables"]["suf"]["md5"]
+    else:
+        assert hashlib.md5(raw).hexdigest() == e["tables"]["suf"]["md5"]
+
+
 @pytest.mark.parametrize("stem", ["Duplicate.fna.ushort", "TTTN.fna.bit",
                                   "Atinsert_seqrange_3-7.fna.uint32", "Reads1.fna.eqlen",
                                   "protein_long_x.faa.bytecompress", "gt_in_line.fna.direct"])

@@ -2541,9 +2541,19 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       u32 *ppos = c->isa_tmp, *phead = ppos + ((NL + 3) & ~3ull);  // (skey is still being
                                                            // read by the emission)
       u32 *pws = scanws + scan_workspace_words(nwords) + 64;
-      k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(c->tiebits, carry, NL,
-                                                     (u32) index_offset, heads);
-      HIP_TRY(hipGetLastError());
+      // (a whole-table build makes the heads inside its first partition pass)
+      int wmax = RW_BITS;
+      if (const char *e = getenv("GTAMD_RANK_WINDOW_BITS")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= RW_BITS) wmax = v;
+      }
+      const bool heads_array = parts || bits_for(N - 1) <= wmax;
+      if (heads_array) {
+        k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(c->tiebits, carry, NL,
+                                                       (u32) index_offset, heads);
+        HIP_TRY(hipGetLastError());
+      }
+      const GroupHeadValues headgen = {c->tiebits, carry, (u32) index_offset};
       // one pass on the 8 leading position bits: windows of N/256 positions.
       // (Measured at 3 Gbp: direct scatter 120 ms; 256 windows 61 ms + 23 ms
       // for the pass; 4096 windows 53 ms + 38 ms; 4096 windows pinned to XCDs
@@ -2558,11 +2568,6 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         // all positions are here: partition down to windows that fit the LDS
         // (one or two passes), then k_rank_window.  GTAMD_RANK_WINDOW_BITS
         // shrinks the window so that tests reach every shape at small N.
-        int wmax = RW_BITS;
-        if (const char *e = getenv("GTAMD_RANK_WINDOW_BITS")) {
-          const int v = atoi(e);
-          if (v >= 2 && v <= RW_BITS) wmax = v;
-        }
         int pb = nbp > wmax ? nbp - wmax : 0;
         if (pb > 16) pb = 16;
         const int wb = nbp - pb;             // wmax, or wmax + 1 with two halves
@@ -2576,15 +2581,21 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         if (pb > 8) {
           const int s0 = nbp - pb, w0 = pb - 8, s1 = nbp - 8, w1 = 8;
           u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
-          TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &w0, 1, pws, st,
-                                         nullptr, nullptr));
+          if (heads_array)
+            TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &w0, 1, pws, st,
+                                           nullptr, nullptr));
+          else
+            TRY(radix_pass_group_heads(sa32, headgen, ppos, phead, NL, s0, w0, pws, st));
           TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
                                          nullptr, nullptr));
           wpos = qpos; whead = qhead;
         } else if (pb > 0) {
           const int s0 = nbp - pb;
-          TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &pb, 1, pws, st,
-                                         nullptr, nullptr));
+          if (heads_array)
+            TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &pb, 1, pws, st,
+                                           nullptr, nullptr));
+          else
+            TRY(radix_pass_group_heads(sa32, headgen, ppos, phead, NL, s0, pb, pws, st));
           wpos = ppos; whead = phead;
         }
         const u32 nbuckets = (u32) div_up(NL, 1ull << wb);

@@ -34,3 +34,18 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
 // tile); on return every entry is the global output index where that tile's
 // pairs of that digit start, exactly what the sort's own passes use.
 int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st);
+
+// One pass of the same sort whose VALUES are not read but made on the fly:
+// value of input pair i = offset + (head of the tie group of entry i), from the
+// tie bitmap ("entry i has the key of entry i-1", one bit per entry) and the
+// per-word carries (head of the group that reaches into word w).  The rank-table
+// build uses it for its first partition pass: no array of heads is written or
+// read.  Result in (keys_b, vals_b).
+struct GroupHeadValues {
+  const u64 *tiebits;
+  const u32 *carry;
+  u32 offset;
+};
+int radix_pass_group_heads(const u32 *keys_a, GroupHeadValues gen, u32 *keys_b,
+                           u32 *vals_b, u64 n, int shift, int width, u32 *ws,
+                           hipStream_t st);

@@ -324,12 +324,31 @@ __device__ __forceinline__ u32 xcd_tile(u32 b, u32 ntiles) {
 // from 16-byte loads.)
 typedef __attribute__((address_space(3))) volatile u16 lds_vu16;
 
-template <bool FULL, bool DIG, typename K, typename V>
+// no generator: the values are read
+struct ReadValues {
+  static constexpr bool active = false;
+  __device__ __forceinline__ u32 operator()(u64) const { return 0; }
+};
+// head of the tie group of entry i (GroupHeadValues of esa_prims.h)
+struct MakeGroupHeads {
+  static constexpr bool active = true;
+  GroupHeadValues g;
+  __device__ __forceinline__ u32 operator()(u64 i) const {
+    const u64 w = i >> 6;
+    const int b = (int) (i & 63);
+    const u64 below = b == 63 ? ~0ull : ((2ull << b) - 1ull);
+    const u64 z = ~g.tiebits[w] & below;
+    return g.offset + (z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : g.carry[w]);
+  }
+};
+
+template <bool FULL, bool DIG, typename K, typename V, typename VG = ReadValues>
 __device__ __forceinline__ void rs_scatter_tile(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
     K *__restrict__ keys_out, V *__restrict__ vals_out, const u32 valid, int shift,
     u32 mask, u32 gbase, u8 *__restrict__ dig_out, int next_shift, u32 next_mask,
-    K *s_key, V *s_val, u16 *s_cnt_generic /* [RS_WAVES][RADIX] */, u32 *s_obase) {
+    K *s_key, V *s_val, u16 *s_cnt_generic /* [RS_WAVES][RADIX] */, u32 *s_obase,
+    const VG vg = VG(), u64 first = 0 /* index of the tile's first pair */) {
   // volatile: lanes read counters that other lanes of the wave have updated
   lds_vu16 *s_cnt = (lds_vu16 *) s_cnt_generic;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -342,7 +361,7 @@ __device__ __forceinline__ void rs_scatter_tile(
     const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
     if (FULL || e < valid) {
       key[j] = keys_in[e];
-      val[j] = vals_in[e];
+      val[j] = VG::active ? (V) vg(first + e) : vals_in[e];
     } else {
       key[j] = (K) ~(K) 0;
       val[j] = 0;
@@ -814,6 +833,61 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     K *tk = kin; kin = kout; kout = tk;
     V *tv = vin; vin = vout; vout = tv;
   }
+  return 0;
+}
+
+// scatter pass with generated values (XCD-aware tile order).  last_valid: pairs
+// of the last tile, from the host -- the in-kernel form  min(n - tile_base, 4096)
+// was miscompiled in this kernel (hipcc 7.2: the s_cselect that follows the
+// 64-bit compare read a stale SCC, the partial tile ran as a full one).
+template <typename K, typename VG>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter_gen(
+    const K *__restrict__ keys_in, const VG vg, K *__restrict__ keys_out,
+    u32 *__restrict__ vals_out, u32 last_valid, int shift, u32 mask,
+    const u32 *__restrict__ hist_scanned, u32 ntiles) {
+  __shared__ K s_key[RS_TILE];
+  __shared__ u32 s_val[RS_TILE];
+  __shared__ u16 s_cnt[RS_WAVES * RADIX];
+  __shared__ u32 s_obase[RADIX];
+  const int tid = threadIdx.x;
+  const u32 tile = xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const u64 tile_base = (u64) tile * RS_TILE;
+  const bool last = tile + 1u == ntiles;
+  for (int i = tid; i < RS_WAVES * RADIX / 2; i += RS_THREADS)
+    reinterpret_cast<u32 *>(s_cnt)[i] = 0;
+  u32 gbase = 0;
+  if (tid < RADIX) gbase = hist_scanned[(u64) tile * RADIX + tid];
+  if (!last || last_valid == (u32) RS_TILE)
+    rs_scatter_tile<true, false, K, u32, VG>(keys_in + tile_base, nullptr, keys_out, vals_out,
+                                             (u32) RS_TILE, shift, mask, gbase, nullptr, 0, 0u,
+                                             s_key, s_val, s_cnt, s_obase, vg, tile_base);
+  else
+    rs_scatter_tile<false, false, K, u32, VG>(keys_in + tile_base, nullptr, keys_out, vals_out,
+                                              last_valid, shift, mask, gbase, nullptr, 0, 0u,
+                                              s_key, s_val, s_cnt, s_obase, vg, tile_base);
+}
+
+int radix_pass_group_heads(const u32 *keys_a, GroupHeadValues gen, u32 *keys_b,
+                           u32 *vals_b, u64 n, int shift, int width, u32 *ws,
+                           hipStream_t st) {
+  if (n == 0) return 0;
+  if (n >= (1ull << 32)) {
+    gtamd_set_error("radix_pass_group_heads: %llu pairs exceed the 32-bit index range",
+                    (unsigned long long) n);
+    return -1;
+  }
+  const u32 ntiles = (u32) div_up(n, RS_TILE);
+  const u32 mask = (1u << width) - 1u;
+  const u32 last_valid = (u32) (n - (u64) (ntiles - 1) * RS_TILE);
+  k_rs_hist<u32><<<ntiles, RS_THREADS, 0, st>>>(keys_a, n, shift, mask, ws, ntiles);
+  HIP_TRY(hipGetLastError());
+  if (radix_scan_tile_hist(ws, n, st) != 0) return -1;
+  MakeGroupHeads mg;
+  mg.g = gen;
+  k_rs_scatter_gen<u32, MakeGroupHeads><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
+      keys_a, mg, keys_b, vals_b, last_valid, shift, mask, ws, ntiles);
+  HIP_TRY(hipGetLastError());
   return 0;
 }
 

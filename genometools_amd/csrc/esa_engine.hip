@@ -2553,7 +2553,7 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
                                                        (u32) index_offset, heads);
         HIP_TRY(hipGetLastError());
       }
-      const GroupHeadValues headgen = {c->tiebits, carry, (u32) index_offset};
+      const GroupHeadValues headgen = {c->tiebits, carry, nwords, (u32) index_offset};
       // one pass on the 8 leading position bits: windows of N/256 positions.
       // (Measured at 3 Gbp: direct scatter 120 ms; 256 windows 61 ms + 23 ms
       // for the pass; 4096 windows 53 ms + 38 ms; 4096 windows pinned to XCDs

@@ -44,6 +44,7 @@ int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st);
 struct GroupHeadValues {
   const u64 *tiebits;
   const u32 *carry;
+  u64 nwords;     // words of the bitmap (and entries of carry)
   u32 offset;
 };
 int radix_pass_group_heads(const u32 *keys_a, GroupHeadValues gen, u32 *keys_b,

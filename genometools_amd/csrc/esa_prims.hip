@@ -327,18 +327,29 @@ typedef __attribute__((address_space(3))) volatile u16 lds_vu16;
 // no generator: the values are read
 struct ReadValues {
   static constexpr bool active = false;
-  __device__ __forceinline__ u32 operator()(u64) const { return 0; }
+  __device__ __forceinline__ void prefetch(u64, int, u64 &, u32 &) const {}
+  __device__ __forceinline__ u32 make(u64, u64, u32) const { return 0; }
 };
-// head of the tie group of entry i (GroupHeadValues of esa_prims.h)
+// head of the tie group of entry i (GroupHeadValues of esa_prims.h).  The 64
+// lanes of a wave ask, per item, for 64 consecutive entries = ONE bitmap word
+// (item j of lane l is entry base + j*64 + l, base a multiple of 64): lane j
+// fetches word and carry of item j once, the items take them by lane read.
 struct MakeGroupHeads {
   static constexpr bool active = true;
   GroupHeadValues g;
-  __device__ __forceinline__ u32 operator()(u64 i) const {
-    const u64 w = i >> 6;
+  __device__ __forceinline__ void prefetch(u64 wave_first, int lane, u64 &t, u32 &c) const {
+    if (lane < RS_ITEMS) {
+      u64 w = (wave_first >> 6) + (u64) lane;
+      if (w >= g.nwords) w = g.nwords - 1;      // behind the table: never used
+      t = g.tiebits[w];
+      c = g.carry[w];
+    }
+  }
+  __device__ __forceinline__ u32 make(u64 i, u64 t, u32 c) const {
     const int b = (int) (i & 63);
     const u64 below = b == 63 ? ~0ull : ((2ull << b) - 1ull);
-    const u64 z = ~g.tiebits[w] & below;
-    return g.offset + (z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : g.carry[w]);
+    const u64 z = ~t & below;
+    return g.offset + (z ? ((u32) i & ~63u) + (63u - (u32) __clzll((long long) z)) : c);
   }
 };
 
@@ -356,12 +367,16 @@ __device__ __forceinline__ void rs_scatter_tile(
   K key[RS_ITEMS];
   V val[RS_ITEMS];
   u32 rk[RS_ITEMS];   // rank inside the wave's stream << 8 | digit
+  u64 vg_t = 0;
+  u32 vg_c = 0;
+  if (VG::active) vg.prefetch(first + (u64) w * RS_WAVE_CHUNK, lane, vg_t, vg_c);
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
     if (FULL || e < valid) {
       key[j] = keys_in[e];
-      val[j] = VG::active ? (V) vg(first + e) : vals_in[e];
+      val[j] = VG::active ? (V) vg.make(first + e, __shfl(vg_t, j, 64), __shfl(vg_c, j, 64))
+                          : vals_in[e];
     } else {
       key[j] = (K) ~(K) 0;
       val[j] = 0;

@@ -456,9 +456,11 @@ __device__ __forceinline__ void rs_scatter_tile(
 template <typename K, typename V, int XCD>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
     const K *__restrict__ keys_in, const V *__restrict__ vals_in,
-    K *__restrict__ keys_out, V *__restrict__ vals_out, u64 n, int shift,
+    K *__restrict__ keys_out, V *__restrict__ vals_out, u32 last_valid, int shift,
     u32 mask, const u32 *__restrict__ hist_scanned, u32 ntiles,
     u8 *__restrict__ dig_out, int next_shift, u32 next_mask) {
+  // last_valid: pairs of the last tile, from the host (not min(n - tile_base,
+  // 4096) in here: see the note at k_rs_scatter_gen)
   // 53 KB of LDS in all, so that three workgroups (24 waves) share a CU:
   // 16-bit counters (a tile has 4096 pairs) and the scan scratch laid over
   // the key staging area, which is not written before the scan is done
@@ -475,8 +477,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(
                             : (XCD ? xcd_tile(blockIdx.x, ntiles) : blockIdx.x);
   if (tile >= ntiles) return;   // whole block leaves together
   const u64 tile_base = (u64) tile * RS_TILE;
-  const u32 valid = (u32) ((n - tile_base) < (u64) RS_TILE ? (n - tile_base)
-                                                            : (u64) RS_TILE);
+  const u32 valid = tile + 1u == ntiles ? last_valid : (u32) RS_TILE;
   for (int i = tid; i < RS_WAVES * RADIX / 2; i += RS_THREADS)
     reinterpret_cast<u32 *>(s_cnt)[i] = 0;
   // this tile's global write base per digit: strided, latency-bound load,
@@ -748,6 +749,7 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     return -1;
   }
   const u32 ntiles = (u32) div_up(n, RS_TILE);
+  const u32 last_valid = (u32) (n - (u64) (ntiles - 1) * RS_TILE);
   u32 *hist = ws;
   u32 *scanws = ws + (u64) ntiles * RADIX;
   K *kin = keys_a, *kout = keys_b;
@@ -833,13 +835,13 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
     if (ev_pairs != nullptr) HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev], st));
     if (g_xcd_mode == 2)
       k_rs_scatter<K, V, 2><<<((ntiles + 8u * OS_CHUNK - 1u) / (8u * OS_CHUNK)) * 8u * OS_CHUNK, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
+          kin, vin, kout, vout, last_valid, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else if (!g_xcd_remap)
       k_rs_scatter<K, V, 0><<<ntiles, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
+          kin, vin, kout, vout, last_valid, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     else
       k_rs_scatter<K, V, 1><<<((ntiles + 7u) >> 3) * 8u, RS_THREADS, 0, st>>>(
-          kin, vin, kout, vout, n, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
+          kin, vin, kout, vout, last_valid, shifts[p], mask, hist, ntiles, dout, nsh, nmk);
     HIP_TRY(hipGetLastError());
     if (ev_pairs != nullptr) {
       HIP_TRY(hipEventRecord(ev_pairs[2 * *n_ev + 1], st));

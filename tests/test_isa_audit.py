@@ -56,7 +56,7 @@ def _audit(asm):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
                     reason="needs hipcc")
-@pytest.mark.parametrize("src", ["esa_prims.hip", "esa_engine.hip", "esa_encode.hip"])
+@pytest.mark.parametrize("src", ["esa_prims.hip", "esa_engine.hip", "esa_encode.hip", "esa_synth.hip"])
 def test_value_selects_take_scc_from_a_compare(src, tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = os.path.join(_lib.HERE, "csrc")

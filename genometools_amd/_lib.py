@@ -46,7 +46,9 @@ class EsaStats(ctypes.Structure):
                 ("lcptabsum", ctypes.c_uint64),
                 ("prefixlength", ctypes.c_uint32),
                 ("refine_rounds", ctypes.c_uint32),
-                ("tied_suffixes", ctypes.c_uint64)]
+                ("tied_suffixes", ctypes.c_uint64),
+                ("pair_suffixes", ctypes.c_uint64),
+                ("device_bytes", ctypes.c_uint64)]
 
 
 class EsaTiming(ctypes.Structure):
@@ -92,6 +94,7 @@ ABI = {
     "gtamd_esa_destroy": (None, [_P]),
     "gtamd_esa_set_part": (_INT, [_P, _U32, _U32]),
     "gtamd_esa_set_prefixlength": (_INT, [_P, _U32]),
+    "gtamd_esa_set_readmode": (_INT, [_P, _INT]),
     "gtamd_esa_set_comm": (_INT, [_P, _P, _P, _P]),
     "gtamd_esa_set_sequence_bytes": (_INT, [_P, _P, _U64, _INT]),
     "gtamd_esa_set_sequence_packed": (_INT, [_P, _P, _P, _U64]),

@@ -21,6 +21,7 @@
 // (src/core/encseq.c:6449-6530, src/match/sfx-bentsedg.c:75-80) is shared.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 #include "../../include/gtamd_esa.h"
 #include "esa_prims.h"
@@ -135,6 +136,18 @@ template <int BITS> struct Key {
   static constexpr u32 DMAX = (1u << L::DCODE_BITS) - 1u;  // suffix starts special
   static constexpr u64 PAY_MASK = (1ull << L::PAYLOAD_BITS) - 1ull;
   static_assert(DSHIFT >= L::PAYLOAD_BITS, "key layout does not fit 64 bits");
+  // the unsorted bits between dcode and payload carry the position bits above
+  // 2^32 (part builds of sequences with n >= 2^32: the 32-bit value of the
+  // sort holds the low half), so the pairs stay 12 bytes
+  static constexpr int SPARE_SHIFT = L::PAYLOAD_BITS;
+  static constexpr int SPARE_BITS = DSHIFT - L::PAYLOAD_BITS;   // 16 (DNA), 5
+  static constexpr u64 SPARE_MASK = (1ull << SPARE_BITS) - 1ull;
+  static __device__ __forceinline__ u64 poshi(u64 key) {
+    return (key >> SPARE_SHIFT) & SPARE_MASK;
+  }
+  static __device__ __forceinline__ u64 with_poshi(u64 key, u64 p) {
+    return key | ((p >> 32) << SPARE_SHIFT);
+  }
   static __device__ __forceinline__ u32 dcode(u64 key) {
     return (u32) (key >> DSHIFT) & DMAX;
   }
@@ -169,9 +182,12 @@ __device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l,
 // ---------------------------------------------------------------------------
 // pack: bytes -> packed words + special bitmap
 // ---------------------------------------------------------------------------
+// readmode of the reference (src/core/readmode.h): the sequence is read in
+// reverse (rev: symbol p comes from position n - 1 - p) and / or complemented
+// (cpl: letter c becomes 3 - c, DNA only; specials stay what they are)
 template <int BITS>
 __global__ __launch_bounds__(256) void k_pack_symbols(
-    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ tb, u64 nwords) {
+    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ tb, u64 nwords, int rev, int cpl) {
   constexpr int SPW = KeyLayout<BITS>::SYMS_PER_WORD;
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
   if (w >= nwords) return;
@@ -182,9 +198,9 @@ __global__ __launch_bounds__(256) void k_pack_symbols(
     const u64 p = base + i;
     u64 c = 0;
     if (p < n) {
-      const u32 b = enc[p];
+      const u32 b = enc[rev ? n - 1 - p : p];
       // a special keeps its kind in the low bit: 0 wildcard, 1 separator
-      c = b >= GTAMD_WILDCARD ? (b == GTAMD_SEPARATOR ? 1u : 0u) : b;
+      c = b >= GTAMD_WILDCARD ? (b == GTAMD_SEPARATOR ? 1u : 0u) : (cpl ? 3u - b : b);
     }
     word |= c << (64 - BITS * (i + 1));
   }
@@ -192,12 +208,12 @@ __global__ __launch_bounds__(256) void k_pack_symbols(
 }
 
 __global__ __launch_bounds__(256) void k_pack_specials(
-    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ sp, u64 nwords) {
+    const u8 *__restrict__ enc, u64 n, u64 *__restrict__ sp, u64 nwords, int rev) {
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
   if (w >= nwords) return;
   const u64 base = w * 64;
   u64 word = 0;
-  if (base + 64 <= n && (((uintptr_t) (enc + base)) & 15) == 0) {
+  if (!rev && base + 64 <= n && (((uintptr_t) (enc + base)) & 15) == 0) {
     const uint4 *v = reinterpret_cast<const uint4 *>(enc + base);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(256) void k_pack_specials(
   } else {
     for (int i = 0; i < 64; i++) {
       const u64 p = base + i;
-      if (p < n ? enc[p] >= GTAMD_WILDCARD : p == n) word |= 1ull << i;
+      if (p < n ? enc[rev ? n - 1 - p : p] >= GTAMD_WILDCARD : p == n) word |= 1ull << i;
     }
   }
   if (base <= n && n < base + 64) word |= 1ull << (n - base);  // virtual end
@@ -241,17 +257,20 @@ __device__ __forceinline__ u64 make_key(const Text &t, u64 p) {
   return (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
 }
 
+// keys of the suffixes [first, end) (a whole table, or one text tile of a part
+// build), written to local indices 0 .. end - first; the value is the low half
+// of the position, the high half rides in the key's spare bits
 template <int BITS>
-__global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
+__global__ __launch_bounds__(256) void k_keygen(Text t, u64 first, u64 end,
                                                 u64 *__restrict__ keys,
                                                 u32 *__restrict__ vals) {
-  const u64 base = (u64) blockIdx.x * 1024;
+  const u64 base = first + (u64) blockIdx.x * 1024;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const u64 p = base + (u64) j * 256 + threadIdx.x;
-    if (p < N) {
-      keys[p] = make_key<BITS>(t, p);
-      vals[p] = (u32) p;
+    if (p < end) {
+      keys[p - first] = Key<BITS>::with_poshi(make_key<BITS>(t, p), p);
+      vals[p - first] = (u32) p;
     }
   }
 }
@@ -260,16 +279,16 @@ __global__ __launch_bounds__(256) void k_keygen(Text t, u64 N,
 // text words and one pair of bitmap words (the general kernel spends ~140
 // instructions per suffix, mostly on re-deriving the same windows, and is
 // bound by them, not by its 36 GB of stores); stores are 16 bytes per lane.
-// Same keys as make_key<2>, bit for bit.
-__global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
+// Same keys as make_key<2>, bit for bit.  `first` is a multiple of 4.
+__global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 first, u64 end,
                                                     u64 *__restrict__ keys,
                                                     u32 *__restrict__ vals) {
   using K = Key<2>;
   using P = Pay<2>;
   constexpr int SYMS = K::SYMS;
   static_assert(28 + 3 + SYMS <= 64, "four windows must fit one word pair");
-  const u64 p0 = ((u64) blockIdx.x * 256 + threadIdx.x) * 4;
-  if (p0 >= N) return;
+  const u64 p0 = first + ((u64) blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 >= end) return;
   const u64 w = p0 >> 5;
   const int o = (int) (p0 & 31) * 2;           // 0, 8, ..., 56
   const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
@@ -288,6 +307,7 @@ __global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
     const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
     pay = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
   }
+  const u64 poshi = (p0 >> 32) << K::SPARE_SHIFT;   // (p0 + 3 has the same high half)
   u64 key[4];
 #pragma unroll
   for (int g = 0; g < 4; g++) {
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
     const u64 s = (S >> g) & ((1ull << SYMS) - 1ull);
     const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
     if (d == 0) {
-      key[g] = (~0ull << K::DSHIFT) | pay;
+      key[g] = (~0ull << K::DSHIFT) | pay | poshi;
     } else {
       u64 pre = win >> K::LOW_BITS;
       u32 dc = 0;
@@ -303,21 +323,22 @@ __global__ __launch_bounds__(256) void k_keygen_dna(Text t, u64 N,
         pre |= (1ull << (2 * (SYMS - d))) - 1ull;
         dc = (u32) (SYMS - d);
       }
-      key[g] = (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
+      key[g] = (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay | poshi;
     }
     // in front of the next suffix: this one's first symbol
     const u32 c = (u32) (win >> 62);
     pay = (c < 2u && (s & 1ull)) ? ((c & 1u) ? P::SEP : P::WILD) : c;
   }
-  if (p0 + 4 <= N) {
-    *reinterpret_cast<ulonglong2 *>(keys + p0) = make_ulonglong2(key[0], key[1]);
-    *reinterpret_cast<ulonglong2 *>(keys + p0 + 2) = make_ulonglong2(key[2], key[3]);
-    *reinterpret_cast<uint4 *>(vals + p0) =
+  const u64 l0 = p0 - first;
+  if (p0 + 4 <= end) {
+    *reinterpret_cast<ulonglong2 *>(keys + l0) = make_ulonglong2(key[0], key[1]);
+    *reinterpret_cast<ulonglong2 *>(keys + l0 + 2) = make_ulonglong2(key[2], key[3]);
+    *reinterpret_cast<uint4 *>(vals + l0) =
         make_uint4((u32) p0, (u32) p0 + 1u, (u32) p0 + 2u, (u32) p0 + 3u);
   } else {
-    for (int g = 0; g < 4 && p0 + g < N; g++) {
-      keys[p0 + g] = key[g];
-      vals[p0 + g] = (u32) (p0 + g);
+    for (int g = 0; g < 4 && p0 + g < end; g++) {
+      keys[l0 + g] = key[g];
+      vals[l0 + g] = (u32) (p0 + g);
     }
   }
 }
@@ -509,11 +530,25 @@ __global__ __launch_bounds__(KP_THREADS) void k_keygen_pass0_dna(
 }
 
 // ---------------------------------------------------------------------------
-// part builds: lexicographic range partition (the reference's -parts idea,
-// src/match/sfx-partssuf.c:172-347, filter src/match/sfx-suffixer.c:375-398)
+// part builds.  The suffix array is cut into R lexicographic ranges of (almost)
+// equal size, the reference's -parts idea (src/match/sfx-partssuf.c:172-347,
+// filter src/match/sfx-suffixer.c:375-398); part r builds slice r of every
+// table.  What a part does per suffix falls with R:
+//   * the TEXT is cut into R tiles of T positions; part r makes the keys of its
+//     tile only and sends every (key, position) pair to the part whose key
+//     range it falls into (alltoallv); received in source order the pairs of a
+//     part are in text order again, which the stable sort needs;
+//   * the rank table (inverse suffix array) of the prefix doubling is cut by
+//     TEXT POSITION: part t holds the ranks of the suffixes that start in tile
+//     t.  The owner of position q is q / T -- no owner map, no text look-up --
+//     so a round is: queries (offset in the tile) to the tile owners, answers
+//     back, and the new ranks of refined suffixes to the tile owners.
 // ---------------------------------------------------------------------------
 constexpr int PART_BITS = 14;
 constexpr int PART_BINS = 1 << PART_BITS;
+constexpr u32 DEST_LOCAL = 0xFEu;   // handled in place, not sent
+constexpr u32 DEST_NONE = 0xFFu;    // nothing to do for this item
+constexpr int DEST_MAXPARTS = 128;  // parts of one build (destination fits a byte)
 
 // leading PART_BITS bits of the key of suffix p (the bits the range partition
 // looks at): the padded symbol prefix only, without dcode and payload
@@ -529,16 +564,18 @@ __device__ __forceinline__ u32 key_bin(const Text &t, u64 p) {
   return (u32) (pre >> (K::PFX_BITS - PART_BITS));
 }
 
-// histogram of the key bins over every `stride`-th suffix: enough to place
-// the range cuts; exact slice sizes come from the count pass
+// histogram of the key bins over every `stride`-th suffix of [first, end):
+// enough to place the range cuts; exact slice sizes come from the exchange
 template <int BITS>
-__global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N, u64 stride,
+__global__ __launch_bounds__(256) void k_key_hist(Text t, u64 first, u64 end, u64 stride,
                                                   u32 *__restrict__ hist) {
   __shared__ u32 h[PART_BINS];
   for (int i = threadIdx.x; i < PART_BINS; i += 256) h[i] = 0;
   __syncthreads();
-  const u64 nsamp = (N + stride - 1) / stride;
-  for (u64 i = (u64) blockIdx.x * 256 + threadIdx.x; i < nsamp;
+  // sample positions: the multiples of stride inside the tile
+  const u64 s0 = (first + stride - 1) / stride;
+  const u64 s1 = (end + stride - 1) / stride;
+  for (u64 i = s0 + (u64) blockIdx.x * 256 + threadIdx.x; i < s1;
        i += (u64) gridDim.x * 256)
     atomicAdd(&h[key_bin<BITS>(t, i * stride)], 1u);
   __syncthreads();
@@ -546,233 +583,23 @@ __global__ __launch_bounds__(256) void k_key_hist(Text t, u64 N, u64 stride,
     if (h[i]) atomicAdd(&hist[i], h[i]);
 }
 
-// One block per 1024 text positions, one lane per position: which suffixes
-// fall into the bins [lo, hi)?  Writes the answer as a bitmask (one 64-bit
-// word per wave and slab), the number of in-range suffixes of the block, and
-// adds the block's counts per part to partcnt (for the exact slice offsets).
-template <int BITS>
-__global__ __launch_bounds__(256) void k_part_count(
-    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner, u32 numparts,
-    u64 *__restrict__ inrange, u32 *__restrict__ cnt,
-    unsigned long long *__restrict__ partcnt) {
-  __shared__ u32 s_cnt[4];
-  __shared__ u32 s_part[256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  s_part[threadIdx.x] = 0;
-  __syncthreads();
-  // workgroups stride over the 1024-position blocks; the per-part counts go to
-  // the global counters once per workgroup (an atomic per block on the same
-  // few addresses costs ~12 ns each, in sequence)
-  const u64 nblk = (N + 1023) / 1024;
-  for (u64 blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-  u32 c = 0;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u64 p = blk * 1024 + (u64) j * 256 + threadIdx.x;
-    bool in = false;
-    u32 o = 0xFFFFFFFFu;
-    if (p < N) {
-      const u32 b = key_bin<BITS>(t, p);
-      in = b >= lo && b < hi;
-      o = owner[b];
-    }
-    // suffixes per part: a few hot counters, so count with ballots (one LDS
-    // add per wave and part) rather than 256 contended atomics
-    if (numparts <= 16) {
-      for (u32 r = 0; r < numparts; r++) {
-        const u64 mr = __ballot(o == r);
-        if (lane == 0 && mr) atomicAdd(&s_part[r], (u32) __popcll(mr));
-      }
-    } else if (o != 0xFFFFFFFFu)
-      atomicAdd(&s_part[o], 1u);
-    const u64 m = __ballot(in);
-    if (lane == 0) {
-      inrange[blk * 16 + j * 4 + w] = m;
-      c += (u32) __popcll(m);
-    }
-  }
-  if (lane == 0) s_cnt[w] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) cnt[blk] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-  __syncthreads();   // s_cnt is written again in the next turn
-  }
-  if (s_part[threadIdx.x])
-    atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
-}
-
-// The same for DNA and at most 16 parts, one thread per packed text word: the
-// bins of 32 consecutive suffixes are sliding 14-bit windows over two words,
-// specials come from one 64-position window of the bitmap.  Per-part counts
-// ride in byte-wide fields of two registers.  8 bitmask/count blocks of 1024
-// positions per thread block.
-__global__ __launch_bounds__(256) void k_part_count_dna(
-    Text t, u64 N, u32 lo, u32 hi, const u8 *__restrict__ owner,
-    u64 *__restrict__ inrange, u32 *__restrict__ cnt,
-    unsigned long long *__restrict__ partcnt, u8 *__restrict__ pos_owner) {
-  __shared__ u8 s_owner[PART_BINS];
-  __shared__ u32 s_part[16];
-  for (int i = threadIdx.x; i < PART_BINS / 4; i += 256)
-    reinterpret_cast<u32 *>(s_owner)[i] = reinterpret_cast<const u32 *>(owner)[i];
-  if (threadIdx.x < 16) s_part[threadIdx.x] = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  // workgroups stride over the 8192-position tiles (one load of the owner map
-  // and one set of global atomics per workgroup, see k_part_count)
-  const u64 ntiles = (N + 8191) / 8192;
-  for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-  const u64 w = tile * 256 + threadIdx.x, p0 = w * 32;
-  u32 mask = 0;
-  u64 clo = 0, chi = 0;          // 8 + 8 counters of 8 bits (at most 32 each)
-  u64 ow[4] = {0, 0, 0, 0};
-  if (p0 < N) {
-    const u64 W0 = tb_word(t, w), W1 = tb_word(t, w + 1);
-    const u64 S = sp_window(t, p0);
-    const int npos = N - p0 < 32 ? (int) (N - p0) : 32;
-#pragma unroll
-    for (int i = 0; i < 32; i++) {
-      if (i < npos) {
-        const u64 x = i == 0 ? W0 : (W0 << (2 * i)) | (W1 >> (64 - 2 * i));
-        u32 b = (u32) (x >> (64 - PART_BITS));
-        const u32 s7 = (u32) (S >> i) & 0x7Fu;
-        if (s7) b |= (1u << (2 * (7 - (__ffs(s7) - 1)))) - 1u;   // pad behind d letters
-        mask |= (u32) (b >= lo && b < hi) << i;
-        const u32 o = s_owner[b];
-        if (o < 8) clo += 1ull << (8 * o); else chi += 1ull << (8 * (o - 8));
-        ow[i >> 3] |= (u64) o << (8 * (i & 7));
-      }
-    }
-    // owners of the 32 suffixes: four 8-byte stores
-    if (npos == 32) {
-      ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(pos_owner + p0);
-      ulonglong2 a, b2;
-      a.x = ow[0]; a.y = ow[1]; b2.x = ow[2]; b2.y = ow[3];
-      dst[0] = a; dst[1] = b2;
-    } else
-      for (int i = 0; i < npos; i++) pos_owner[p0 + i] = (u8) (ow[i >> 3] >> (8 * (i & 7)));
-  }
-  // bitmask words: two threads per 64 positions
-  const u32 other = __shfl_xor(mask, 1, 64);
-  // (every word of a started 1024-position block is written, also behind N)
-  const bool started = (w >> 5) < (N + 1023) / 1024;
-  if ((lane & 1) == 0 && started) inrange[w >> 1] = (u64) mask | ((u64) other << 32);
-  // suffixes in range per 1024 positions (32 threads)
-  u32 c = (u32) __popc(mask);
-#pragma unroll
-  for (int d = 1; d < 32; d <<= 1) c += __shfl_xor(c, d, 64);
-  if ((lane & 31) == 0 && started) cnt[w >> 5] = c;
-  // per-part counts: widen to 16-bit fields, add up the wave, then the block
-  u64 f[4] = {clo & 0x00FF00FF00FF00FFull, (clo >> 8) & 0x00FF00FF00FF00FFull,
-              chi & 0x00FF00FF00FF00FFull, (chi >> 8) & 0x00FF00FF00FF00FFull};
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-#pragma unroll
-    for (int k = 0; k < 4; k++) f[k] += __shfl_xor(f[k], d, 64);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        // f[0]: parts 0,2,4,6  f[1]: 1,3,5,7  f[2]: 8,10,12,14  f[3]: 9,11,13,15
-        const u32 part = (u32) (k >> 1) * 8 + 2 * q + (k & 1);
-        const u32 v = (u32) (f[k] >> (16 * q)) & 0xFFFFu;
-        if (v) atomicAdd(&s_part[part], v);
-      }
-  }
-  }
-  __syncthreads();
-  if (threadIdx.x < 16 && s_part[threadIdx.x])
-    atomicAdd(&partcnt[threadIdx.x], (unsigned long long) s_part[threadIdx.x]);
-}
-
-// order-preserving emission of the (key, position) pairs of this part: the
-// threads of a block share out the SET bits of its 16 mask words, so full
-// keys are built for this part's suffixes only
-template <int BITS>
-__global__ __launch_bounds__(256) void k_part_emit(
-    Text t, u64 N, const u64 *__restrict__ inrange, const u32 *__restrict__ off,
-    const u32 *__restrict__ cnt, u64 *__restrict__ keys, u32 *__restrict__ vals) {
-  __shared__ u64 s_mask[16];
-  __shared__ u32 s_pre[17];
-  if (threadIdx.x < 16) s_mask[threadIdx.x] = inrange[(u64) blockIdx.x * 16 + threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u32 a = 0;
-    for (int i = 0; i < 16; i++) { s_pre[i] = a; a += (u32) __popcll(s_mask[i]); }
-    s_pre[16] = a;
-  }
-  __syncthreads();
-  const u32 total = s_pre[16];
-  const u64 out0 = off[blockIdx.x];
-  (void) cnt;
-  for (u32 k = threadIdx.x; k < total; k += 256) {
-    // word that holds the k-th set bit, then the bit inside it
-    int wi = 0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) wi += (s_pre[i] <= k);
-    u64 m = s_mask[wi];
-    u32 r = k - s_pre[wi];
-    while (r--) m &= m - 1;            // drop the r lowest set bits
-    const int bit = __ffsll((unsigned long long) m) - 1;
-    // word wi = slab j (wi / 4), wave w (wi % 4): position j*256 + w*64 + bit
-    const u64 p = (u64) blockIdx.x * 1024 + (u64) (wi >> 2) * 256 + (u64) (wi & 3) * 64 + bit;
-    keys[out0 + k] = make_key<BITS>(t, p);
-    vals[out0 + k] = (u32) p;
-  }
-  (void) N;
-}
-
-// distributed rank lookup: which part owns the suffix h symbols further on
-template <int BITS>
-__global__ __launch_bounds__(256) void k_query_dest(
-    Text t, const u32 *__restrict__ upos, u64 m, u64 h,
-    const u8 *__restrict__ owner, u32 *__restrict__ dkey,
-    u32 *__restrict__ dval, u32 *__restrict__ counts) {
-  __shared__ u32 s_cnt[256];
-  s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j < m) {
-    u64 q = (u64) upos[j] + h;
-    if (q > t.n) q = t.n;
-    const u32 d = owner[key_bin<BITS>(t, q)];
-    dkey[j] = d;
-    dval[j] = (u32) j;
-    atomicAdd(&s_cnt[d], 1u);
-  }
-  __syncthreads();
-  if (s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void k_query_fill(
-    const u32 *__restrict__ upos, const u32 *__restrict__ order, u64 m, u64 h,
-    u64 n, u32 *__restrict__ sendq) {
-  const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (s >= m) return;
-  u64 q = (u64) upos[order[s]] + h;
-  sendq[s] = (u32) (q > n ? n : q);
-}
-
-// ---- the same bucketing for at most 16 parts, without a sort -----------------
-constexpr u32 Q_LOCAL = 0xFEu;   // destination code of a query this part answers itself
-// pos_owner[p] = part that owns suffix p (written while the range membership of
-// all suffixes is computed), so a query's destination is one byte away.
-// k_q_count: destination of every query (kept as a byte) and, per block of 256
-// queries, how many go to each part -- laid out part-major, so that ONE
-// exclusive scan over numparts * blocks counters gives every block its write
-// offset inside every part's segment of the send buffer.
-__global__ __launch_bounds__(256) void k_q_count(
-    const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ pos_owner,
-    u32 numparts, u32 self, u64 nblocks, u8 *__restrict__ dest,
-    u32 *__restrict__ bcount) {
-  __shared__ u32 s_cnt[4][16];
+// ---- bucketing by destination part, without a sort ---------------------------
+// k_dest_count: destination of every item (kept as a byte) and, per block of 256
+// items, how many go to each part -- laid out part-major, so that ONE exclusive
+// scan over numparts * blocks counters gives every block its write offset inside
+// every part's segment of the send buffer.  k_dest_place then puts the items
+// there (stable); items for this part itself are handled on the spot.
+// F: dest(j) -> part, DEST_LOCAL or DEST_NONE; local(j); emit(j, at).
+template <typename F>
+__global__ __launch_bounds__(256) void k_dest_count(F f, u64 m, u32 numparts, u64 nblocks,
+                                                    u8 *__restrict__ dest,
+                                                    u32 *__restrict__ bcount) {
+  __shared__ u32 s_cnt[4][DEST_MAXPARTS];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  u32 d = 0xFFu;
+  u32 d = DEST_NONE;
   if (j < m) {
-    u64 q = (u64) upos[j] + h;
-    if (q > n) q = n;
-    d = pos_owner[q];
-    if (d == self) d = Q_LOCAL;      // answered from the own table, not sent
+    d = f.dest(j);
     dest[j] = (u8) d;
   }
   for (u32 r = 0; r < numparts; r++) {
@@ -786,55 +613,193 @@ __global__ __launch_bounds__(256) void k_q_count(
         s_cnt[3][threadIdx.x];
 }
 
-// k_q_place: queries and their slots to their place in the send buffer (stable);
-// the ones this part owns itself are answered on the spot
-__global__ __launch_bounds__(256) void k_q_place(
-    const u32 *__restrict__ upos, u64 m, u64 h, u64 n, const u8 *__restrict__ dest,
-    u32 numparts, u64 nblocks, const u32 *__restrict__ boff, u32 *__restrict__ sendq,
-    u32 *__restrict__ order, const u32 *__restrict__ rank, u32 *__restrict__ k2) {
-  __shared__ u32 s_cnt[4][16];
+template <typename F>
+__global__ __launch_bounds__(256) void k_dest_place(F f, u64 m, u32 numparts, u64 nblocks,
+                                                    const u8 *__restrict__ dest,
+                                                    const u32 *__restrict__ boff) {
+  __shared__ u32 s_cnt[4][DEST_MAXPARTS];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const u32 d = j < m ? dest[j] : 0xFFu;
-  u32 before = 0;                 // queries of this wave's lower lanes to the same part
+  const u32 d = j < m ? dest[j] : DEST_NONE;
+  u32 before = 0;                 // items of this wave's lower lanes to the same part
   for (u32 r = 0; r < numparts; r++) {
     const u64 mr = __ballot(d == r);
     if (lane == 0) s_cnt[w][r] = (u32) __popcll(mr);
     if (d == r) before = (u32) __popcll(mr & ((1ull << lane) - 1ull));
   }
   __syncthreads();
-  if (j >= m) return;
-  u64 q = (u64) upos[j] + h;
-  if (q > n) q = n;
-  if (d == Q_LOCAL) { k2[j] = rank[q]; return; }
+  if (j >= m || d == DEST_NONE) return;
+  if (d == DEST_LOCAL) { f.local(j); return; }
   u32 at = boff[(u64) d * nblocks + blockIdx.x] + before;
   for (int x = 0; x < w; x++) at += s_cnt[x][d];
-  sendq[at] = (u32) q;
-  order[at] = (u32) j;
+  f.emit(j, at);
 }
 
 // send counts per part from the scanned block counters: segment boundaries
-__global__ void k_q_totals(const u32 *__restrict__ boff, const u32 *__restrict__ bcount,
-                           u32 numparts, u64 nblocks, u32 *__restrict__ counts) {
+__global__ void k_dest_totals(const u32 *__restrict__ boff, const u32 *__restrict__ bcount,
+                              u32 numparts, u64 nblocks, u32 *__restrict__ counts) {
   const u32 r = threadIdx.x;
   if (r >= numparts) return;
   const u64 first = (u64) r * nblocks, last = first + nblocks - 1;
   counts[r] = boff[last] + bcount[last] - boff[first];
 }
 
-__global__ __launch_bounds__(256) void k_answer(const u32 *__restrict__ q,
-                                                u64 cnt,
-                                                const u32 *__restrict__ rank,
-                                                u32 *__restrict__ ans) {
+// tile geometry of a part build: position q lives in tile q / T
+struct Tiles {
+  u64 T;        // positions per tile
+  u32 self;     // this part
+  __device__ __forceinline__ u32 owner(u64 q, u64 *off) const {
+    const u64 d = q / T;
+    *off = q - d * T;
+    return (u32) d;
+  }
+};
+
+// (key, position) pairs of the own text tile to the owners of their key range
+struct OwnerOfKey {
+  const u64 *keys;
+  const u32 *vals;
+  const u8 *owner;     // bin -> part
+  u64 *keys_out;
+  u32 *vals_out;
+  __device__ __forceinline__ u32 dest(u64 j) const {
+    return owner[keys[j] >> (64 - PART_BITS)];
+  }
+  __device__ __forceinline__ void local(u64) const {}
+  __device__ __forceinline__ void emit(u64 j, u32 at) const {
+    keys_out[at] = keys[j];
+    vals_out[at] = vals[j];
+  }
+};
+
+// first ranks of the suffixes [c0, c0 + m) of this part's slice to the owners
+// of their text positions: rank = slice offset + head of the entry's tie group
+template <typename P> struct InitialRanks {
+  const P *sa;
+  const u64 *tiebits;
+  const u32 *carry;
+  u64 c0, index_offset;
+  Tiles tl;
+  P *isa;              // this part's tile of the rank table
+  u32 *soff;
+  P *srank;
+  __device__ __forceinline__ u32 dest(u64 j) const {
+    u64 off;
+    const u32 d = tl.owner((u64) sa[c0 + j], &off);
+    return d == tl.self ? DEST_LOCAL : d;
+  }
+  __device__ __forceinline__ P rank_of(u64 i) const {
+    const u64 w = i >> 6;
+    const int b = (int) (i & 63);
+    const u64 below = b == 63 ? ~0ull : ((2ull << b) - 1ull);
+    const u64 z = ~tiebits[w] & below;
+    const u64 head = z ? w * 64 + (u64) (63 - __clzll((long long) z)) : (u64) carry[w];
+    return (P) (index_offset + head);
+  }
+  __device__ __forceinline__ void local(u64 j) const {
+    u64 off;
+    (void) tl.owner((u64) sa[c0 + j], &off);
+    isa[off] = rank_of(c0 + j);
+  }
+  __device__ __forceinline__ void emit(u64 j, u32 at) const {
+    u64 off;
+    (void) tl.owner((u64) sa[c0 + j], &off);
+    soff[at] = (u32) off;
+    srank[at] = rank_of(c0 + j);
+  }
+};
+
+// rank queries of a round: k2[j] = rank of suffix upos[j] + h
+template <typename P> struct RankQueries {
+  const P *upos;
+  u64 h, n;
+  Tiles tl;
+  const P *isa;
+  P *k2;
+  u32 *sendq, *order;
+  __device__ __forceinline__ u64 target(u64 j) const {
+    const u64 q = (u64) upos[j] + h;
+    return q > n ? n : q;   // cannot happen for a tied suffix; keeps the access in range
+  }
+  __device__ __forceinline__ u32 dest(u64 j) const {
+    u64 off;
+    const u32 d = tl.owner(target(j), &off);
+    return d == tl.self ? DEST_LOCAL : d;
+  }
+  __device__ __forceinline__ void local(u64 j) const {
+    u64 off;
+    (void) tl.owner(target(j), &off);
+    k2[j] = isa[off];
+  }
+  __device__ __forceinline__ void emit(u64 j, u32 at) const {
+    u64 off;
+    (void) tl.owner(target(j), &off);
+    sendq[at] = (u32) off;
+    order[at] = (u32) j;
+  }
+};
+
+// new ranks of the suffixes a round has refined (slot j moved to a new group)
+template <typename P> struct RankUpdates {
+  const P *cval;         // position now in slot j
+  const u32 *gnew;       // its new group head
+  const u32 *ugrp;       // the slot's old group head
+  u64 index_offset;
+  Tiles tl;
+  P *isa;
+  u32 *soff;
+  P *srank;
+  __device__ __forceinline__ u32 dest(u64 j) const {
+    if (gnew[j] == ugrp[j]) return DEST_NONE;   // the leading subgroup keeps its rank
+    u64 off;
+    const u32 d = tl.owner((u64) cval[j], &off);
+    return d == tl.self ? DEST_LOCAL : d;
+  }
+  __device__ __forceinline__ void local(u64 j) const {
+    u64 off;
+    (void) tl.owner((u64) cval[j], &off);
+    isa[off] = (P) (index_offset + gnew[j]);
+  }
+  __device__ __forceinline__ void emit(u64 j, u32 at) const {
+    u64 off;
+    (void) tl.owner((u64) cval[j], &off);
+    soff[at] = (u32) off;
+    srank[at] = (P) (index_offset + gnew[j]);
+  }
+};
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_isa_store(const u32 *__restrict__ off,
+                                                   const P *__restrict__ rank, u64 cnt,
+                                                   P *__restrict__ isa) {
   const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (i < cnt) ans[i] = rank[q[i]];
+  if (i < cnt) isa[off[i]] = rank[i];
 }
 
-__global__ __launch_bounds__(256) void k_k2_scatter(
-    const u32 *__restrict__ ans, const u32 *__restrict__ order, u64 m,
-    u32 *__restrict__ k2) {
+template <typename P>
+__global__ __launch_bounds__(256) void k_answer(const u32 *__restrict__ q, u64 cnt,
+                                                const P *__restrict__ isa,
+                                                P *__restrict__ ans) {
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i < cnt) ans[i] = isa[q[i]];
+}
+
+template <typename P>
+__global__ __launch_bounds__(256) void k_k2_scatter(const P *__restrict__ ans,
+                                                    const u32 *__restrict__ order, u64 m,
+                                                    P *__restrict__ k2) {
   const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
   if (s < m) k2[order[s]] = ans[s];
+}
+
+// positions of the slice at full width: low half from the sort's values, high
+// half from the spare bits of the sorted keys
+template <int BITS>
+__global__ __launch_bounds__(256) void k_wide_positions(const u64 *__restrict__ keys,
+                                                        const u32 *__restrict__ lo, u64 n,
+                                                        u64 *__restrict__ out) {
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (Key<BITS>::poshi(keys[i]) << 32) | lo[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -964,9 +929,9 @@ __global__ __launch_bounds__(256) void k_tiebits(const u64 *__restrict__ keys,
 
 // Each thread owns 4 consecutive entries so that .lcp/.bwt leave as one
 // 32-bit store and .suf as two 16-byte stores per lane.
-template <int BITS>
+template <int BITS, typename P>
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
-    const u64 *__restrict__ keys, const u32 *__restrict__ pos, u64 N,
+    const u64 *__restrict__ keys, const P *__restrict__ pos, u64 N,
     u32 prefixlength, u64 *__restrict__ suf, u8 *__restrict__ lcp,
     u8 *__restrict__ bwt, u64 *__restrict__ tiebits, Stats *stats,
     u64 prev_key, int has_prev, u64 index_offset) {
@@ -987,18 +952,24 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
   for (int r = 0; r < FIN_PER_THREAD; r++) {
     const u64 i0 = tile * FIN_TILE + ((u64) r * FIN_THREADS + threadIdx.x) * 4;
     u64 k[4];
-    u32 p[4];
+    P p[4];
     if (i0 + 4 <= N) {
       const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(keys + i0);
       const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(keys + i0 + 2);
       k[0] = a.x; k[1] = a.y; k[2] = b.x; k[3] = b.y;
-      const uint4 q = *reinterpret_cast<const uint4 *>(pos + i0);
-      p[0] = q.x; p[1] = q.y; p[2] = q.z; p[3] = q.w;
+      if (sizeof(P) == 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(pos + i0);
+        p[0] = (P) q.x; p[1] = (P) q.y; p[2] = (P) q.z; p[3] = (P) q.w;
+      } else {
+        const ulonglong2 q0 = *reinterpret_cast<const ulonglong2 *>(pos + i0);
+        const ulonglong2 q1 = *reinterpret_cast<const ulonglong2 *>(pos + i0 + 2);
+        p[0] = (P) q0.x; p[1] = (P) q0.y; p[2] = (P) q1.x; p[3] = (P) q1.y;
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         k[c] = i0 + c < N ? keys[i0 + c] : ~0ull;
-        p[c] = i0 + c < N ? pos[i0 + c] : 0u;
+        p[c] = i0 + c < N ? pos[i0 + c] : (P) 0;
       }
     }
     // predecessor key: previous lane's last key, or a global load at the
@@ -1089,6 +1060,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
 // ---------------------------------------------------------------------------
 // tied suffixes: unresolved list, group heads, rank table
 // ---------------------------------------------------------------------------
+// P is the type of text positions and of ranks: u32, or u64 in a part build of
+// a sequence with n >= 2^32 (GTAMD_FORCE_WIDE=1 takes it at any size).  Indices
+// into a part's slice stay 32-bit (a slice has fewer than 2^32 entries).
+
 // per 64-entry word: unresolved mask count and the highest "not tied" index
 __global__ __launch_bounds__(256) void k_tie_words(
     const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
@@ -1116,10 +1091,11 @@ __device__ __forceinline__ u32 group_head(const u64 *tiebits, const u32 *carry,
 // one wave per 64-entry word, one lane per entry: neighbouring lanes write
 // neighbouring slots of the unresolved list
 constexpr int UE_WORDS_PER_WAVE = 16;
+template <typename P>
 __global__ __launch_bounds__(256) void k_unres_emit(
     const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
-    const u32 *__restrict__ carry, const u32 *__restrict__ sa32,
-    u32 *__restrict__ uidx0, u32 *__restrict__ uidx, u32 *__restrict__ upos,
+    const u32 *__restrict__ carry, const P *__restrict__ sa,
+    u32 *__restrict__ uidx0, u32 *__restrict__ uidx, P *__restrict__ upos,
     u32 *__restrict__ ugrp) {
   const int lane = threadIdx.x & 63;
   const u64 wave = ((u64) blockIdx.x * 256 + threadIdx.x) >> 6;
@@ -1153,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_unres_emit(
     const u64 z = ~t & below;
     uidx0[j] = (u32) i;
     uidx[j] = (u32) i;
-    upos[j] = sa32[i];
+    upos[j] = sa[i];
     ugrp[j] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carryw;
   }
 }
@@ -1188,20 +1164,9 @@ __global__ __launch_bounds__(256) void k_heads(
   }
 }
 
-__global__ __launch_bounds__(256) void k_rank_scatter(
-    const u32 *__restrict__ pos, const u32 *__restrict__ heads, u64 N,
-    u32 *__restrict__ rank) {
-  const u64 base = (u64) blockIdx.x * 1024;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const u64 i = base + (u64) j * 256 + threadIdx.x;
-    if (i < N) rank[pos[i]] = heads[i];
-  }
-}
-
-// The same through LDS, for a build that owns ALL positions: after the pairs
-// are partitioned on their leading position bits, bucket b holds exactly the
-// positions [b << wb, (b + 1) << wb) -- and, every position occurring once,
+// The rank table through LDS, for a build that owns ALL positions: after the
+// pairs are partitioned on their leading position bits, bucket b holds exactly
+// the positions [b << wb, (b + 1) << wb) -- and, every position occurring once,
 // exactly the pairs with these indices.  A workgroup scatters one window of
 // heads inside LDS (4-byte LDS stores cost nothing against 4-byte global
 // stores, each of which is a memory transaction of its own: 47 G/s measured)
@@ -1255,33 +1220,203 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
   for (u64 i = wcnt4 + threadIdx.x; i < wcnt; i += RW_THREADS) out[i] = s_win[i];
 }
 
+// ---------------------------------------------------------------------------
+// tie groups of exactly two suffixes ("pairs"): 87 % of the tied suffixes of
+// the human-like workload -- every low-copy repeat makes them -- and the ones
+// that stay tied longest under prefix doubling (an exact 8 K copy takes nine
+// rounds).  Two suffixes need no rank table: ONE comparison on the packed
+// text gives their order and their LCP, and walked in TEXT order the next pair
+// on the same diagonal (a+1, b+1) starts from the previous LCP minus one
+// (Kasai et al.; src/match/sfx-linlcp.c:74-129), so only the first pair of a
+// chunk pays for a long match.  The pairs leave the tie bitmap before the
+// unresolved list and the rank table are built: everything behind sees them
+// as settled suffixes.
+// ---------------------------------------------------------------------------
+// pair heads of a bitmap word: entry i not tied, i+1 tied, i+2 not tied
+__device__ __forceinline__ u64 pair_heads(u64 t, u64 nx) {
+  return ~t & ((t >> 1) | (nx << 63)) & ~((t >> 2) | (nx << 62));
+}
+
+// per word: number of pair heads, and the bitmap without the pairs
+__global__ __launch_bounds__(256) void k_pair_words(
+    const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
+    u64 *__restrict__ tiebits2) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  const u64 ph = pair_heads(t, nx);
+  // a pair head in bit 63 of the word before clears this word's bit 0
+  u64 prevhead = 0;
+  if (w > 0) prevhead = pair_heads(tiebits[w - 1], t) >> 63;
+  cnt[w] = (u32) __popcll(ph);
+  tiebits2[w] = t & ~((ph << 1) | prevhead);
+}
+
+// (smaller position, index of the pair's first entry), one lane per entry
+template <typename P>
+__global__ __launch_bounds__(256) void k_pair_emit(
+    const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
+    const P *__restrict__ sa, P *__restrict__ pkey, u32 *__restrict__ pval) {
+  const int lane = threadIdx.x & 63;
+  const u64 wave = ((u64) blockIdx.x * 256 + threadIdx.x) >> 6;
+  const u64 lt = (1ull << lane) - 1ull;
+  const u64 w0 = wave * UE_WORDS_PER_WAVE;
+  u64 my_t = 0;
+  u32 my_off = 0;
+  if (lane <= UE_WORDS_PER_WAVE && w0 + lane < nwords) {
+    my_t = tiebits[w0 + lane];
+    if (lane < UE_WORDS_PER_WAVE) my_off = off[w0 + lane];
+  }
+#pragma unroll
+  for (int k = 0; k < UE_WORDS_PER_WAVE; k++) {
+    const u64 w = w0 + k;
+    if (w >= nwords) return;
+    const u64 t = __shfl(my_t, k, 64);
+    const u64 nx = __shfl(my_t, k + 1, 64);
+    const u32 offw = __shfl(my_off, k, 64);
+    const u64 ph = pair_heads(t, nx);
+    if (!((ph >> lane) & 1ull)) continue;
+    const u32 j = offw + (u32) __popcll(ph & lt);
+    const u64 i = w * 64 + lane;
+    pkey[j] = sa[i];    // the stable sort left equal keys in position order
+    pval[j] = (u32) i;
+  }
+}
+
+constexpr int LCP_CHUNK = 32;
+constexpr u32 PAIR_SWAP = 1u << 31;
+
+// order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
+// per thread; a pair in the wrong order is swapped in the suffix array here,
+// the tables get their entries from k_pair_apply
+template <int BITS, typename P>
+__global__ __launch_bounds__(256) void k_pair_resolve(
+    Text t, const P *__restrict__ pkey, const u32 *__restrict__ pval, u64 np,
+    P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
+  __shared__ unsigned long long s_sum[4], s_large[4];
+  __shared__ u32 s_max[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned long long sum = 0, nlarge = 0;
+  u32 mx = 0;
+  const u64 nchunks = (np + LCP_CHUNK - 1) / LCP_CHUNK;
+  for (u64 c = (u64) blockIdx.x * 256 + threadIdx.x; c < nchunks;
+       c += (u64) gridDim.x * 256) {
+    u64 preva = 0, l = 0;
+    for (int e = 0; e < LCP_CHUNK; e++) {
+      const u64 s = c * LCP_CHUNK + e;
+      if (s >= np) break;
+      const u64 a = pkey[s];
+      const u64 i = pval[s];
+      const u64 b = sa[i + 1];
+      u64 from = (u64) Key<BITS>::SYMS;
+      if (e > 0 && l > from + (a - preva)) from = l - (a - preva);
+      l = lcp_extend<BITS>(t, a, b, from);
+      preva = a;
+      // the first difference decides: a special is larger than every letter,
+      // two specials compare by position
+      const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
+      const bool a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
+                                        : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
+      if (!a_first) { sa[i] = (P) b; sa[i + 1] = (P) a; }
+      const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
+      res[s] = lv | (a_first ? 0u : PAIR_SWAP);
+      sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
+      nlarge += lv >= GTAMD_LCPOVERFLOW;
+      mx = lv > mx ? lv : mx;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    nlarge += __shfl_xor(nlarge, d, 64);
+    const u32 o = __shfl_xor(mx, d, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) { s_sum[w] = sum; s_large[w] = nlarge; s_max[w] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long S = 0, Lg = 0;
+    u32 M = 0;
+    for (int i = 0; i < 4; i++) {
+      S += s_sum[i]; Lg += s_large[i]; M = s_max[i] > M ? s_max[i] : M;
+    }
+    if (S) atomicAdd(&stats->lcpsum, S);
+    if (Lg) atomicAdd(&stats->numlarge, Lg);
+    if (M) atomicMax(&stats->maxlcp, M);
+  }
+}
+
+// table entries of the pairs (after the emission of the other entries): the
+// LCP of the second entry; .suf and .bwt of both when they changed places
+template <int BITS, typename P>
+__global__ __launch_bounds__(256) void k_pair_apply(
+    Text t, const u32 *__restrict__ pval, const u32 *__restrict__ res, u64 np,
+    const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    u8 *__restrict__ bwt, u32 *__restrict__ lcpfull, u64 index_offset, Stats *stats) {
+  const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (s >= np) return;
+  const u64 i = pval[s];
+  const u32 r = res[s], lv = r & ~PAIR_SWAP;
+  if (lcp != nullptr) {
+    lcp[i + 1] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+    if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + 1] = lv;
+  }
+  const u64 x = sa[i], y = sa[i + 1];
+  if (x == 0) stats->longest = index_offset + i;
+  if (y == 0) stats->longest = index_offset + i + 1;
+  if (r & PAIR_SWAP) {
+    if (suf != nullptr) { suf[i] = x; suf[i + 1] = y; }
+    if (bwt != nullptr) {
+      bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, x));
+      bwt[i + 1] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, y));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // One doubling round for all tie groups that lie inside one tile of the
 // unresolved list: sort each group by k2 in LDS (bitonic network on the packed
 // key  local group | k2 | slot), derive the new group heads.  Groups that
 // reach across a tile border (or are larger than a tile) are left in place
 // and flagged for the global radix path.
+// ---------------------------------------------------------------------------
 constexpr int RT_TILE = 2048;
 constexpr int RT_THREADS = 256;
 constexpr int RT_PER = RT_TILE / RT_THREADS;   // 8
 
+// sort key of the tile: local group (12 bits) | deferred | k2 | slot (11 bits);
+// ranks of a wide build have up to 40 bits
+template <typename P> struct RoundKey {
+  static constexpr int KK = sizeof(P) == 8 ? 40 : 32;
+  static __device__ __forceinline__ u64 pack(u32 lg, bool open, u64 kk, u32 e) {
+    return ((u64) lg << (12 + KK)) | ((u64) open << (11 + KK)) | (kk << 11) | (u64) e;
+  }
+  static __device__ __forceinline__ bool open(u64 key) { return (key >> (11 + KK)) & 1ull; }
+};
+
+template <typename P>
 __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
-    const u32 *__restrict__ uidx, const u32 *__restrict__ upos,
-    const u32 *__restrict__ ugrp, u32 *__restrict__ k2, u64 m,
-    u32 *__restrict__ cv, u32 *__restrict__ hv, u8 *__restrict__ flg,
-    u32 *__restrict__ tilecnt, Stats *stats, const u32 *__restrict__ rank, u64 h,
-    u64 n) {
+    const u32 *__restrict__ uidx, const P *__restrict__ upos,
+    const u32 *__restrict__ ugrp, P *__restrict__ k2, u64 m,
+    P *__restrict__ cv, u32 *__restrict__ hv, u8 *__restrict__ flg,
+    u32 *__restrict__ tilecnt, const P *__restrict__ rank, u64 h, u64 n) {
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
   // of reading a k2 array (which a part build fills through the exchange)
-  // 28 KB of LDS, so that five workgroups share a CU (the rank lookups below
-  // are latency-bound random reads: more waves in flight hide more of it).
-  // The group numbers and second keys are only needed until the sort keys are
-  // built, so they are staged in the memory of the keys themselves.
+  // 28 KB of LDS (32-bit positions), so that five workgroups share a CU (the
+  // rank lookups below are latency-bound random reads: more waves in flight
+  // hide more of it).  The group numbers and second keys are only needed until
+  // the sort keys are built, so they are staged in the memory of the keys
+  // themselves (64-bit ranks have a staging area of their own).
+  using RK = RoundKey<P>;
+  constexpr bool WIDE = sizeof(P) == 8;
   __shared__ u64 s_key[RT_TILE];
-  __shared__ u32 s_pos[RT_TILE];
+  __shared__ P s_pos[RT_TILE];
+  __shared__ u64 s_k2w[WIDE ? RT_TILE : 1];
   __shared__ u16 s_start[RT_TILE + 2];   // first slot of each local group
   __shared__ u32 s_scan[4];
   u32 *s_grp = reinterpret_cast<u32 *>(s_key);
-  u32 *s_k2 = s_grp + RT_TILE;
+  u32 *s_k2n = s_grp + RT_TILE;
   const int tid = threadIdx.x;
   const u64 base = (u64) blockIdx.x * RT_TILE;
   const u32 cnt = (u32) ((m - base) < (u64) RT_TILE ? (m - base) : (u64) RT_TILE);
@@ -1292,38 +1427,41 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
     const u32 e = (u32) c * RT_THREADS + tid;
+    P kv = 0;
     if (e < cnt) {
-      const u32 p = upos[base + e];
+      const P p = upos[base + e];
       s_grp[e] = ugrp[base + e];
       s_pos[e] = p;
       if (rank != nullptr) {
         u64 q = (u64) p + h;
         if (q > n) q = n;  // cannot happen for a tied suffix; keeps the load in range
-        s_k2[e] = rank[q];
+        kv = rank[q];
       } else
-        s_k2[e] = k2[base + e];
+        kv = k2[base + e];
     } else {
       s_grp[e] = 0xFFFFFFFFu;   // padding: one trailing pseudo group
       s_pos[e] = 0;
-      s_k2[e] = 0;
     }
+    if (WIDE) s_k2w[e] = (u64) kv; else s_k2n[e] = (u32) kv;
   }
   __syncthreads();
   // from here on a thread owns 8 consecutive slots; it takes their group
   // numbers and second keys into registers before the keys overwrite them
-  u32 gr[RT_PER], kr[RT_PER];
-  u32 kprev = tid > 0 ? s_k2[(u32) tid * RT_PER - 1] : 0u;
-  u32 gprev = tid > 0 ? s_grp[(u32) tid * RT_PER - 1] : 0u;
+  u32 gr[RT_PER];
+  u64 kr[RT_PER];
+  const u32 e0 = (u32) tid * RT_PER;
+  u64 kprev = tid > 0 ? (WIDE ? s_k2w[e0 - 1] : (u64) s_k2n[e0 - 1]) : 0ull;
+  u32 gprev = tid > 0 ? s_grp[e0 - 1] : 0u;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
-    gr[c] = s_grp[(u32) tid * RT_PER + c];
-    kr[c] = s_k2[(u32) tid * RT_PER + c];
+    gr[c] = s_grp[e0 + c];
+    kr[c] = WIDE ? s_k2w[e0 + c] : (u64) s_k2n[e0 + c];
   }
   // local group numbers: inclusive count of group starts
   u32 startflags = 0, nstart = 0;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
-    const u32 e = (u32) tid * RT_PER + c;
+    const u32 e = e0 + c;
     const bool st = e == 0 || gr[c] != gprev;
     gprev = gr[c];
     startflags |= (u32) st << c;
@@ -1339,21 +1477,21 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   u32 openbits = 0;   // deferred slots of this thread: one byte per thread in flg
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
-    const u32 e = (u32) tid * RT_PER + c;
+    const u32 e = e0 + c;
     const bool start = (startflags >> c) & 1u;
     lg += start;
     const u32 g = gr[c];
     const bool open = e < cnt && ((first_open && g == g_first) ||
                                   (last_open && g == g_last));
-    const u32 kraw = kr[c];
-    const u32 kk = open ? 0u : kraw;
+    const u64 kraw = kr[c];
+    const u64 kk = open ? 0ull : kraw;
     splits |= (e < cnt && !open && !start && kraw != kprev);
     kprev = kraw;
     // local group | deferred | k2 | slot: a group is deferred as a whole, so
     // the flag bit never reorders anything
-    s_key[e] = ((u64) lg << 44) | ((u64) open << 43) | ((u64) kk << 11) | (u64) e;
+    s_key[e] = RK::pack(lg, open, kk, e);
     openbits |= (u32) open << c;
-    if (open && rank != nullptr) k2[base + e] = kraw;   // for the global path
+    if (open && rank != nullptr) k2[base + e] = (P) kraw;   // for the global path
     nflag += open;
   }
   static_assert(RT_PER == 8, "one flag byte per thread");
@@ -1367,7 +1505,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       u32 lgw = lg;   // local group number of this thread's last slot
 #pragma unroll
       for (int c = RT_PER - 1; c >= 0; c--) {
-        const u32 e = (u32) tid * RT_PER + c;
+        const u32 e = e0 + c;
         if ((startflags >> c) & 1u) { s_start[lgw] = (u16) e; lgw--; }
       }
       if (tid == 0) s_start[tot + 1] = (u16) RT_TILE;
@@ -1378,9 +1516,9 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       u32 lgw = lg;
 #pragma unroll
       for (int c = RT_PER - 1; c >= 0; c--) {
-        const u32 e = (u32) tid * RT_PER + c;
+        const u32 e = e0 + c;
         if ((startflags >> c) & 1u) {
-          const bool open = (s_key[e] >> 43) & 1u;
+          const bool open = RK::open(s_key[e]);
           if (e < cnt && !open) {
             const u32 size = (u32) s_start[lgw + 1] - e;
             gmax = size > gmax ? size : gmax;
@@ -1436,7 +1574,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   u32 hval[RT_PER], hmax = 0;
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
-    const u32 e = (u32) tid * RT_PER + c;
+    const u32 e = e0 + c;
     const u64 key = s_key[e];
     const bool head = e == 0 || (key >> 11) != (s_key[e - 1] >> 11);
     const u32 v = (head && e < cnt) ? uidx[base + e] : 0u;
@@ -1446,13 +1584,12 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   u32 carry = block_scan_excl_max(hmax, &tot, s_scan);
 #pragma unroll
   for (int c = 0; c < RT_PER; c++) {
-    const u32 e = (u32) tid * RT_PER + c;
+    const u32 e = e0 + c;
     carry = hval[c] > carry ? hval[c] : carry;
     if (e < cnt) {
       const u64 key = s_key[e];
       const u32 src = (u32) (key & 2047u);
-      const bool open = (key >> 43) & 1u;
-      if (!open) {
+      if (!RK::open(key)) {
         cv[base + e] = s_pos[src];
         hv[base + e] = carry;
       }
@@ -1471,13 +1608,16 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   }
 }
 
-// global path for the deferred elements: composite key (group, k2).  One
+// global path for the deferred elements: order by (group, k2) with two stable
+// sorts -- on k2, then on the group -- of an index into the deferred list.  One
 // workgroup per tile of k_round_tile; tileoff = exclusive scan of its counts.
+template <typename P>
 __global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
     const u8 *__restrict__ flg, const u32 *__restrict__ tileoff,
-    const u32 *__restrict__ ugrp, const u32 *__restrict__ k2,
-    const u32 *__restrict__ upos, u64 m, u64 *__restrict__ ckey,
-    u32 *__restrict__ cval, u32 *__restrict__ fj) {
+    const u32 *__restrict__ ugrp, const P *__restrict__ k2,
+    const P *__restrict__ upos, u64 m, P *__restrict__ fk2, P *__restrict__ fk2_sort,
+    u32 *__restrict__ fgrp, P *__restrict__ fpos, u32 *__restrict__ fj,
+    u32 *__restrict__ perm) {
   __shared__ u32 s_scan[4];
   const u64 base = (u64) blockIdx.x * RT_TILE + (u64) threadIdx.x * RT_PER;
   // (the tile kernel sets no bit at or behind m)
@@ -1490,25 +1630,45 @@ __global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
   for (int c = 0; c < RT_PER; c++)
     if ((f >> c) & 1u) {
       const u64 j = base + c;
-      ckey[o] = ((u64) ugrp[j] << 32) | k2[j];
-      cval[o] = upos[j];
+      const P k = k2[j];
+      fk2[o] = k;
+      fk2_sort[o] = k;
+      fgrp[o] = ugrp[j];
+      fpos[o] = upos[j];
       fj[o] = (u32) j;
+      perm[o] = o;
       o++;
     }
 }
 
-__global__ __launch_bounds__(256) void k_flag_heads(
-    const u64 *__restrict__ ckey, const u32 *__restrict__ uidx,
-    const u32 *__restrict__ fj, u64 nf, u32 *__restrict__ fhv) {
+__global__ __launch_bounds__(256) void k_gather_u32(const u32 *__restrict__ src,
+                                                    const u32 *__restrict__ idx, u64 n,
+                                                    u32 *__restrict__ dst) {
   const u64 r = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (r >= nf) return;
-  const bool head = r == 0 || ckey[r] != ckey[r - 1];
-  fhv[r] = head ? uidx[fj[r]] : 0u;
+  if (r < n) dst[r] = src[idx[r]];
 }
 
+template <typename P>
+__global__ __launch_bounds__(256) void k_flag_heads(
+    const u32 *__restrict__ perm, const u32 *__restrict__ fgrp, const P *__restrict__ fk2,
+    const P *__restrict__ fpos, const u32 *__restrict__ uidx, const u32 *__restrict__ fj,
+    u64 nf, u32 *__restrict__ fhv, P *__restrict__ cvs) {
+  const u64 r = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (r >= nf) return;
+  const u32 a = perm[r];
+  bool head = r == 0;
+  if (!head) {
+    const u32 b = perm[r - 1];
+    head = fgrp[a] != fgrp[b] || fk2[a] != fk2[b];
+  }
+  fhv[r] = head ? uidx[fj[r]] : 0u;
+  cvs[r] = fpos[a];
+}
+
+template <typename P>
 __global__ __launch_bounds__(256) void k_flag_scatter(
-    const u32 *__restrict__ cvs, const u32 *__restrict__ fhv,
-    const u32 *__restrict__ fj, u64 nf, u32 *__restrict__ cv,
+    const P *__restrict__ cvs, const u32 *__restrict__ fhv,
+    const u32 *__restrict__ fj, u64 nf, P *__restrict__ cv,
     u32 *__restrict__ hv) {
   const u64 r = (u64) blockIdx.x * 256 + threadIdx.x;
   if (r >= nf) return;
@@ -1518,24 +1678,28 @@ __global__ __launch_bounds__(256) void k_flag_scatter(
 }
 
 // write the round's result back: positions into the suffix array, new group
-// heads into the rank table; flag what is still tied
+// heads into the rank table (a build that holds the whole table; a part build
+// sends them to the owners of the positions, RankUpdates); flag what is still
+// tied
+template <typename P>
 __global__ __launch_bounds__(256) void k_round_apply(
-    const u32 *__restrict__ cval, const u32 *__restrict__ gnew,
+    const P *__restrict__ cval, const u32 *__restrict__ gnew,
     const u32 *__restrict__ uidx, const u32 *__restrict__ ugrp, u64 m,
-    u32 rank_offset, u32 *__restrict__ sa32, u32 *__restrict__ rank,
+    u64 rank_offset, P *__restrict__ sa, P *__restrict__ rank,
     u64 *__restrict__ keep, u32 *__restrict__ blockcnt) {
   __shared__ u32 s_cnt[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   bool kept = false;
   if (j < m) {
-    const u32 p = cval[j], g = gnew[j], i = uidx[j];
+    const P p = cval[j];
+    const u32 g = gnew[j], i = uidx[j];
     // slot j stays inside its old group's range, so ugrp[j] is the old group of
     // whichever suffix now sits here; the leading subgroup keeps that id
-    if (g != ugrp[j]) rank[p] = rank_offset + g;
+    if (rank != nullptr && g != ugrp[j]) rank[p] = (P) (rank_offset + g);
     const bool head = g == i;
     const bool nexthead = j + 1 == m || gnew[j + 1] == uidx[j + 1];
     const bool resolved = head && nexthead;
-    if (resolved) sa32[i] = p;   // final place; unresolved ones move again
+    if (resolved) sa[i] = p;   // final place; unresolved ones move again
     kept = !resolved;
   }
   // survivors: one bit each (a word per wave) for the compaction, which scans
@@ -1550,11 +1714,12 @@ __global__ __launch_bounds__(256) void k_round_apply(
 }
 
 // boff: exclusive scan of the block counts
+template <typename P>
 __global__ __launch_bounds__(256) void k_round_compact(
     const u64 *__restrict__ keep, const u32 *__restrict__ boff,
     const u32 *__restrict__ blockcnt, const u32 *__restrict__ uidx,
-    const u32 *__restrict__ cval, const u32 *__restrict__ gnew, u64 m,
-    u32 *__restrict__ uidx2, u32 *__restrict__ upos2, u32 *__restrict__ ugrp2,
+    const P *__restrict__ cval, const u32 *__restrict__ gnew, u64 m,
+    u32 *__restrict__ uidx2, P *__restrict__ upos2, u32 *__restrict__ ugrp2,
     Stats *stats) {
   __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
@@ -1576,6 +1741,11 @@ __global__ void k_total(const u32 *__restrict__ off, const u32 *__restrict__ cnt
   stats->count = n ? off[n - 1] + cnt[n - 1] : 0u;
 }
 
+__global__ void k_total2(const u32 *__restrict__ off, const u32 *__restrict__ cnt,
+                         u64 n, Stats *stats) {
+  stats->count2 = n ? off[n - 1] + cnt[n - 1] : 0u;
+}
+
 // ---------------------------------------------------------------------------
 // few, shallow ties (random coincidences on non-repetitive input): resolve
 // each tie group by comparing the suffixes on the packed text directly, no
@@ -1593,10 +1763,12 @@ __device__ bool suffix_less(const Text &t, u64 p, u64 q, bool *deep) {
   return Sym<BITS>::at(t, p + l) < Sym<BITS>::at(t, q + l);
 }
 
-template <int BITS>
+// (works on a private copy of nothing: a group that gives up has not been
+// touched, so the other paths can take it over)
+template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_direct_ties(
     Text t, const u32 *__restrict__ uidx0, const u32 *__restrict__ ugrp, u64 m0,
-    u32 *__restrict__ sa32, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
     u8 *__restrict__ bwt, bool want_lcp, u64 index_offset, Stats *stats) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m0) return;
@@ -1605,10 +1777,10 @@ __global__ __launch_bounds__(256) void k_direct_ties(
   int g = 1;
   while (j + g < m0 && ugrp[j + g] == i0 && g <= DIRECT_MAX_GROUP) g++;
   if (g > DIRECT_MAX_GROUP) { stats->dfallback = 1; return; }
-  u32 pos[DIRECT_MAX_GROUP];
+  u64 pos[DIRECT_MAX_GROUP];
   bool deep = false;
   for (int k = 0; k < g; k++) {       // insertion sort
-    const u32 p = sa32[i0 + k];
+    const u64 p = sa[i0 + k];
     int a = k;
     while (a > 0 && suffix_less<BITS>(t, p, pos[a - 1], &deep)) {
       pos[a] = pos[a - 1];
@@ -1620,7 +1792,7 @@ __global__ __launch_bounds__(256) void k_direct_ties(
   for (int k = 0; k < g; k++) {
     const u64 i = (u64) i0 + k;
     const u64 p = pos[k];
-    sa32[i] = (u32) p;
+    sa[i] = (P) p;
     if (suf != nullptr) suf[i] = p;
     if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
     if (p == 0) stats->longest = index_offset + i;
@@ -1636,17 +1808,16 @@ __global__ __launch_bounds__(256) void k_direct_ties(
 // ---------------------------------------------------------------------------
 // tied suffixes: final LCP / BWT / .suf entries and .llv
 // ---------------------------------------------------------------------------
-// .suf and .bwt entries of every suffix that took part in the refinement, and
-// the flag "this entry is tied with its predecessor" (needs a real LCP)
-template <int BITS>
+// .suf and .bwt entries of every suffix that took part in the refinement
+template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_fix_basic(
     Text t, const u32 *__restrict__ uidx0, u64 m0,
-    const u32 *__restrict__ sa32, u64 *__restrict__ suf, u8 *__restrict__ bwt,
+    const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ bwt,
     Stats *stats, u64 index_offset) {
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   if (j >= m0) return;
   const u64 i = uidx0[j];
-  const u64 p = sa32[i];
+  const u64 p = sa[i];
   if (suf != nullptr) suf[i] = p;
   if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
   if (p == 0) stats->longest = index_offset + i;
@@ -1674,10 +1845,11 @@ __global__ __launch_bounds__(256) void k_tied_counts(
   block_count_256(j < m0 && tied_with_pred(tiebits, uidx0[j]), blockcnt);
 }
 
+template <typename P>
 __global__ __launch_bounds__(256) void k_lcp_pairs(
     const u32 *__restrict__ boff, const u64 *__restrict__ tiebits,
-    const u32 *__restrict__ uidx0, const u32 *__restrict__ sa32, u64 m0,
-    u32 *__restrict__ pkey, u32 *__restrict__ pval) {
+    const u32 *__restrict__ uidx0, const P *__restrict__ sa, u64 m0,
+    P *__restrict__ pkey, u32 *__restrict__ pval) {
   __shared__ u32 s_scan[4];
   const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
   u32 i = 0;
@@ -1689,7 +1861,7 @@ __global__ __launch_bounds__(256) void k_lcp_pairs(
   u32 tot;
   const u32 o = boff[blockIdx.x] + block_scan_excl_sum(tied ? 1u : 0u, &tot, s_scan);
   if (tied) {
-    pkey[o] = sa32[i];
+    pkey[o] = sa[i];
     pval[o] = i;
   }
 }
@@ -1704,11 +1876,10 @@ __global__ __launch_bounds__(256) void k_lcp_pairs(
 // access by table index is a random line; values that do not fit the byte
 // (and only those) also go to a 32-bit side table by index, from which the
 // .llv pairs are collected in index order afterwards.
-constexpr int LCP_CHUNK = 32;
-template <int BITS>
+template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_lcp_chunks(
-    Text t, const u32 *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
-    const u32 *__restrict__ sa32, u8 *__restrict__ lcp, u32 *__restrict__ lcpfull,
+    Text t, const P *__restrict__ pkey, const u32 *__restrict__ pval, u64 m1,
+    const P *__restrict__ sa, u8 *__restrict__ lcp, u32 *__restrict__ lcpfull,
     Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
@@ -1724,12 +1895,12 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     if (s >= m1) break;
     const u64 p = pkey[s];
     const u64 i = pval[s];
-    const u64 q = sa32[i - 1];
+    const u64 q = sa[i - 1];
     u64 from = (u64) Key<BITS>::SYMS;
     if (e > 0 && l > from + (p - prevp)) from = l - (p - prevp);
     l = lcp_extend<BITS>(t, q, p, from);
     prevp = p;
-    const u32 lv = (u32) l;
+    const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
     lcp[i] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
     if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i] = lv;
     sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
@@ -1759,33 +1930,53 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
 }
 
 // .llv pairs in index order: (index into the lcp table, value),
-// src/match/sfx-lcpvalues.c:402-411.  Counted per workgroup, then placed.
-// (An entry of the list that is not tied with its predecessor has the LCP the
-// keys gave it, which is below the key length.)
-__global__ __launch_bounds__(256) void k_large_counts(
-    const u32 *__restrict__ uidx0, const u8 *__restrict__ lcp, u64 m0,
-    u32 *__restrict__ blockcnt) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  block_count_256(j < m0 && lcp[uidx0[j]] == GTAMD_LCPOVERFLOW, blockcnt);
+// src/match/sfx-lcpvalues.c:402-411.  The byte table itself says where they
+// are (an entry of 255; the first sort's own LCPs are below the key length):
+// 16 entries per thread, counted per workgroup, then placed.
+constexpr int LLV_PER = 16;
+constexpr int LLV_TILE = 256 * LLV_PER;
+
+__device__ __forceinline__ u32 llv_mask(const u8 *__restrict__ lcp, u64 i0, u64 N) {
+  u32 mask = 0;
+  if (i0 + LLV_PER <= N && ((reinterpret_cast<uintptr_t>(lcp + i0)) & 15) == 0) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(lcp + i0);
+    const u32 v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++)
+        if (((v[a] >> (8 * b)) & 255u) == GTAMD_LCPOVERFLOW) mask |= 1u << (4 * a + b);
+  } else {
+    for (int k = 0; k < LLV_PER; k++)
+      if (i0 + k < N && lcp[i0 + k] == GTAMD_LCPOVERFLOW) mask |= 1u << k;
+  }
+  return mask;
+}
+
+__global__ __launch_bounds__(256) void k_large_counts(const u8 *__restrict__ lcp, u64 N,
+                                                      u32 *__restrict__ blockcnt) {
+  __shared__ u32 s_scan[4];
+  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * LLV_PER;
+  const u32 c = i0 < N ? (u32) __popc(llv_mask(lcp, i0, N)) : 0u;
+  u32 tot;
+  (void) block_scan_excl_sum(c, &tot, s_scan);
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_llv_emit(
-    const u32 *__restrict__ uidx0, const u8 *__restrict__ lcp,
-    const u32 *__restrict__ lcpfull, const u32 *__restrict__ boff, u64 m0,
-    u64 index_offset, u64 *__restrict__ llv) {
+    const u8 *__restrict__ lcp, u64 N, const u32 *__restrict__ lcpfull,
+    const u32 *__restrict__ boff, u64 index_offset, u64 *__restrict__ llv) {
   __shared__ u32 s_scan[4];
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  u32 i = 0;
-  bool large = false;
-  if (j < m0) {
-    i = uidx0[j];
-    large = lcp[i] == GTAMD_LCPOVERFLOW;
-  }
+  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * LLV_PER;
+  u32 mask = i0 < N ? llv_mask(lcp, i0, N) : 0u;
   u32 tot;
-  const u64 o = boff[blockIdx.x] + block_scan_excl_sum(large ? 1u : 0u, &tot, s_scan);
-  if (large) {
-    llv[2 * o] = index_offset + i;
-    llv[2 * o + 1] = lcpfull[i];
+  u64 o = boff[blockIdx.x] + block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
+  while (mask) {
+    const int k = __ffs(mask) - 1;
+    mask &= mask - 1;
+    llv[2 * o] = index_offset + i0 + k;
+    llv[2 * o + 1] = lcpfull[i0 + k];
+    o++;
   }
 }
 
@@ -1800,36 +1991,42 @@ static inline u32 stride_grid(u64 tiles) {
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+// device buffer that only grows; growing loses the contents
+struct DevBuf {
+  void *p;
+  u64 bytes;
+  template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
 struct gtamd_esa_ctx {
   int device;
   u32 sigma;
   int bits;                // 2 or 5
   u64 max_n, n, N;         // N = n + 1 entries
+  int readmode;            // GtReadmode of the sequence handed in as bytes
   hipStream_t st, st2;     // st2: table emission beside the refinement
   hipEvent_t ev_sorted, ev_emitted;
-  u32 *isa_tmp;            // partitioned (position, head) pairs of the rank build
   // resident sequence
-  u64 *tb_own, *sp_own;
+  DevBuf tb_own, sp_own;
   Text text;
   bool have_text;
-  // sort buffers
-  u64 *k0, *k1;
-  u32 *v0, *v1;
-  u32 *rws;                // radix / scan workspace
-  u8 *dig0, *dig1;         // digit side arrays of the first sort
-  u64 rws_words;
-  // outputs
-  u64 *suf;
-  u8 *lcp, *bwt;
+  // workspace, allocated by the first run that needs it (what a run needs
+  // depends on the tables wanted and, in a part build, on the slice size)
+  DevBuf k0, k1, v0, v1;   // ping-pong (key, position) pairs of the radix sort
+  DevBuf isa_tmp;          // 8 B per entry: partitioned pairs of the rank build /
+                           // bucketing scratch and 64-bit positions of a part build
+  DevBuf rws;              // radix / scan workspace
+  DevBuf dig0, dig1;       // digit side arrays of the first sort (experiment)
+  DevBuf suf, lcp, bwt;    // outputs at on-disk width
+  DevBuf tiebits, tiebits2;
+  DevBuf arena;            // pair list, unresolved list, round buffers
+  DevBuf xrecv;            // part builds: receive side of the exchanges
   u64 *llv;
   u64 llv_pairs, llv_cap;
   u32 *bck;                      // .bck sections, back to back
   u64 bck_codes, bck_special, bck_dist;
-  u64 *tiebits;
   Stats *d_stats, *h_stats;   // h_stats: pinned host mirror
-  // refinement arena (grow-only)
-  void *arena;
-  u64 arena_bytes;
+  u32 *h_counts;              // pinned: per-part counters read back per round
   u32 user_prefixlength;   // 0 = automatic
   // part build (lexicographic range `part` of `numparts`)
   u32 part, numparts;
@@ -1839,36 +2036,56 @@ struct gtamd_esa_ctx {
   u64 NL, index_offset;    // entries and offset of this part's slice
   u32 *d_parthist;         // PART_BINS counters
   u8 *d_owner;             // bin -> owning part
-  u8 *pos_owner;           // part builds of DNA with <= 16 parts: suffix -> owning part
-  bool have_pos_owner;
-  u32 *xbuf;               // exchange buffers (grow-only)
-  u64 xbuf_words;
+  u32 *d_counts;           // 4 x DEST_MAXPARTS per-part counters
   // results
   u32 want;
   bool ran;
   gtamd_esa_stats stats;
   gtamd_esa_timing timing;
+  u64 alloc_bytes;         // device memory held by the context
   // events
   hipEvent_t ev[8];
   hipEvent_t ev_scatter[2 * 16];
 };
 
 static void free_dev(void *p) { if (p != nullptr) (void) hipFree(p); }
+static void free_buf(DevBuf &b) { free_dev(b.p); b.p = nullptr; b.bytes = 0; }
+
+// grow-only; whoever calls this knows that the old contents are dead
+static int ensure_buf(gtamd_esa_ctx *c, DevBuf &b, u64 bytes, const char *what) {
+  if (bytes <= b.bytes) return 0;
+  HIP_TRY(hipStreamSynchronize(c->st));
+  HIP_TRY(hipStreamSynchronize(c->st2));
+  c->alloc_bytes -= b.bytes;
+  free_buf(b);
+  bytes = (bytes + 255) & ~255ull;
+  if (hipMalloc(&b.p, bytes) != hipSuccess) {
+    (void) hipGetLastError();
+    b.p = nullptr;
+    gtamd_set_error("cannot allocate %llu bytes of device memory for %s (the "
+                    "context holds %llu bytes already)",
+                    (unsigned long long) bytes, what,
+                    (unsigned long long) c->alloc_bytes);
+    return -1;
+  }
+  b.bytes = bytes;
+  c->alloc_bytes += bytes;
+  return 0;
+}
 
 extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c == nullptr) return;
   (void) hipSetDevice(c->device);
   if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
   if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
-  free_dev(c->tb_own); free_dev(c->sp_own);
-  free_dev(c->k0); free_dev(c->k1); free_dev(c->v0); free_dev(c->v1);
-  free_dev(c->isa_tmp);
-  free_dev(c->rws); free_dev(c->dig0); free_dev(c->dig1); free_dev(c->suf); free_dev(c->lcp); free_dev(c->bwt);
-  free_dev(c->llv); free_dev(c->bck); free_dev(c->tiebits); free_dev(c->d_stats);
-  free_dev(c->arena); free_dev(c->d_parthist); free_dev(c->d_owner);
-  free_dev(c->pos_owner);
-  free_dev(c->xbuf);
+  DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
+                    &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
+                    &c->tiebits2, &c->arena, &c->xrecv};
+  for (DevBuf *b : bufs) free_buf(*b);
+  free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
+  free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
+  if (c->h_counts != nullptr) (void) hipHostFree(c->h_counts);
   for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
   if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
@@ -1889,6 +2106,15 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
     }                                                                         \
   } while (0)
 
+// positions a build can address: 32 bits in the sort's value plus the spare
+// key bits (part builds; a single build keeps everything 32-bit)
+static u64 max_positions(int bits) {
+  const int spare = bits == 2 ? Key<2>::SPARE_BITS : Key<5>::SPARE_BITS;
+  const int total = 32 + spare > 40 ? 40 : 32 + spare;   // ranks travel in 40 bits
+  return 1ull << total;
+}
+constexpr u64 SINGLE_LIMIT = (1ull << 32) - 4096;   // entries of one slice / single build
+
 extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
                                            uint32_t numofchars) {
   if (gtamd_device_count() <= device || device < 0) {
@@ -1900,52 +2126,30 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
     gtamd_set_error("alphabet size %u not supported (2..28)", numofchars);
     return nullptr;
   }
-  if (max_n + 1 >= (1ull << 32) - 4096) {
-    gtamd_set_error("sequence of %llu symbols exceeds the 32-bit position "
-                    "range of a single-device build",
-                    (unsigned long long) max_n);
+  const int bits = numofchars <= 4 ? 2 : 5;
+  if (max_n + 1 >= max_positions(bits) - 4096) {
+    gtamd_set_error("sequence of %llu symbols exceeds the position range of "
+                    "this engine (%llu)", (unsigned long long) max_n,
+                    (unsigned long long) max_positions(bits));
     return nullptr;
   }
   gtamd_esa_ctx *c = new gtamd_esa_ctx();
   memset((void *) c, 0, sizeof *c);
   c->device = device;
   c->sigma = numofchars;
-  c->bits = numofchars <= 4 ? 2 : 5;
+  c->bits = bits;
   c->max_n = max_n;
-  const u64 N = max_n + 1;
   CTX_TRY(hipSetDevice(device));
   CTX_TRY(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
   CTX_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
-  const u64 spw = c->bits == 2 ? 32 : 12;
-  CTX_TRY(hipMalloc(&c->tb_own, (div_up(N, spw) + 2) * 8));
-  CTX_TRY(hipMalloc(&c->sp_own, (div_up(N, 64) + 2) * 8));
-  const u64 Npad = N + 8;
-  CTX_TRY(hipMalloc(&c->k0, Npad * 8));
-  CTX_TRY(hipMalloc(&c->k1, Npad * 8));
-  CTX_TRY(hipMalloc(&c->v0, Npad * 4));
-  CTX_TRY(hipMalloc(&c->v1, Npad * 4));
-  c->rws_words = radix_workspace_words(N) + 4 * (div_up(N, 64) + 64) +
-                 scan_workspace_words(div_up(N, 64)) + 64;
-  CTX_TRY(hipMalloc(&c->rws, c->rws_words * 4));
-  CTX_TRY(hipMalloc(&c->isa_tmp, Npad * 8));
-  {
-    // digit-byte side arrays of the sort: an experiment switch (esa_prims.hip)
-    const char *db = getenv("GTAMD_DIGBYTES");
-    if (db != nullptr && db[0] == '1') {
-      CTX_TRY(hipMalloc(&c->dig0, Npad));
-      CTX_TRY(hipMalloc(&c->dig1, Npad));
-    }
-  }
-  CTX_TRY(hipMalloc(&c->suf, Npad * 8));
-  CTX_TRY(hipMalloc(&c->lcp, Npad));
-  CTX_TRY(hipMalloc(&c->bwt, Npad));
-  CTX_TRY(hipMalloc(&c->tiebits, (div_up(N, 64) + 2) * 8));
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
+  CTX_TRY(hipHostMalloc(&c->h_counts, 4 * DEST_MAXPARTS * 4, hipHostMallocDefault));
   CTX_TRY(hipMalloc(&c->d_parthist, PART_BINS * 4));
   CTX_TRY(hipMalloc(&c->d_owner, PART_BINS));
+  CTX_TRY(hipMalloc(&c->d_counts, 4 * DEST_MAXPARTS * 4));
   c->numparts = 1;
   for (auto &e : c->ev) CTX_TRY(hipEventCreate(&e));
   for (auto &e : c->ev_scatter) CTX_TRY(hipEventCreate(&e));
@@ -1955,8 +2159,8 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
 extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
                                   uint32_t numparts) {
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
-  if (numparts == 0 || numparts > 255 || part >= numparts) {
-    gtamd_set_error("invalid part %u of %u (1..255 parts)", part, numparts);
+  if (numparts == 0 || numparts > (u32) DEST_MAXPARTS || part >= numparts) {
+    gtamd_set_error("invalid part %u of %u (1..%d parts)", part, numparts, DEST_MAXPARTS);
     return -1;
   }
   c->part = part;
@@ -1986,6 +2190,24 @@ extern "C" int gtamd_esa_set_prefixlength(gtamd_esa_ctx *c, uint32_t k) {
   return 0;
 }
 
+extern "C" int gtamd_esa_set_readmode(gtamd_esa_ctx *c, int readmode) {
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  if (readmode < 0 || readmode > 3) {
+    gtamd_set_error("invalid readmode %d (0 forward, 1 reverse, 2 complement, "
+                    "3 reverse complement)", readmode);
+    return -1;
+  }
+  // complementing needs a=0 c=1 g=2 t=3 (gt_alphabet_is_dna, src/core/encseq.c:4960)
+  if (readmode >= 2 && c->sigma != 4) {
+    gtamd_set_error("readmode %s is only defined for DNA alphabets",
+                    readmode == 2 ? "cpl" : "rcl");
+    return -1;
+  }
+  c->readmode = readmode;
+  c->have_text = false;   // applies to the next gtamd_esa_set_sequence_bytes
+  return 0;
+}
+
 static int set_n(gtamd_esa_ctx *c, u64 n) {
   if (n > c->max_n) {
     gtamd_set_error("sequence length %llu exceeds the context capacity %llu",
@@ -2004,28 +2226,34 @@ extern "C" int gtamd_esa_set_sequence_bytes(gtamd_esa_ctx *c,
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   TRY(set_n(c, n));
   HIP_TRY(hipSetDevice(c->device));
+  const u64 spw = c->bits == 2 ? 32 : 12;
+  const u64 nw_tb = div_up(c->N, spw), nw_sp = div_up(c->N, 64);
+  TRY(ensure_buf(c, c->tb_own, (nw_tb + 2) * 8, "the packed sequence"));
+  TRY(ensure_buf(c, c->sp_own, (nw_sp + 2) * 8, "the special bitmap"));
   const u8 *d_enc = enc;
   u8 *staged = nullptr;
   if (!is_device && n > 0) {
-    // stage through the (not yet used) key buffer
-    staged = reinterpret_cast<u8 *>(c->k1);
-    HIP_TRY(hipMemcpyAsync(staged, enc, n, hipMemcpyHostToDevice, c->st));
+    HIP_TRY(hipMalloc(&staged, n));
+    if (hipMemcpyAsync(staged, enc, n, hipMemcpyHostToDevice, c->st) != hipSuccess) {
+      free_dev(staged);
+      gtamd_set_error("copying the sequence to the device failed");
+      return -1;
+    }
     d_enc = staged;
   }
-  const u64 spw = c->bits == 2 ? 32 : 12;
-  const u64 nw_tb = div_up(c->N, spw), nw_sp = div_up(c->N, 64);
+  u64 *tb = c->tb_own.as<u64>(), *sp = c->sp_own.as<u64>();
+  const int rev = c->readmode & 1, cpl = c->readmode >> 1;
   if (c->bits == 2)
-    k_pack_symbols<2><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(
-        d_enc, n, c->tb_own, nw_tb);
+    k_pack_symbols<2><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(d_enc, n, tb, nw_tb, rev, cpl);
   else
-    k_pack_symbols<5><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(
-        d_enc, n, c->tb_own, nw_tb);
-  HIP_TRY(hipGetLastError());
-  k_pack_specials<<<(u32) div_up(nw_sp, 256), 256, 0, c->st>>>(d_enc, n,
-                                                              c->sp_own, nw_sp);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(c->st));
-  c->text.tb = c->tb_own; c->text.sp = c->sp_own; c->text.n = n;
+    k_pack_symbols<5><<<(u32) div_up(nw_tb, 256), 256, 0, c->st>>>(d_enc, n, tb, nw_tb, rev, cpl);
+  hipError_t e1 = hipGetLastError();
+  k_pack_specials<<<(u32) div_up(nw_sp, 256), 256, 0, c->st>>>(d_enc, n, sp, nw_sp, rev);
+  hipError_t e2 = hipGetLastError();
+  hipError_t e3 = hipStreamSynchronize(c->st);
+  free_dev(staged);
+  HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3);
+  c->text.tb = tb; c->text.sp = sp; c->text.n = n;
   c->text.nw_tb = nw_tb; c->text.nw_sp = nw_sp;
   c->have_text = true;
   return 0;
@@ -2040,6 +2268,11 @@ extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
     gtamd_set_error("packed input is defined for the 2-bit DNA layout only");
     return -1;
   }
+  if (c->readmode != 0) {
+    gtamd_set_error("packed input is read in place: readmode %d cannot be applied "
+                    "(hand the sequence in as bytes)", c->readmode);
+    return -1;
+  }
   TRY(set_n(c, n));
   c->text.tb = twobit; c->text.sp = specialbits; c->text.n = n;
   c->text.nw_tb = div_up(n, 32); c->text.nw_sp = div_up(n + 1, 64);
@@ -2050,24 +2283,6 @@ extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
 // ---------------------------------------------------------------------------
 // the run
 // ---------------------------------------------------------------------------
-static int ensure_arena(gtamd_esa_ctx *c, u64 bytes) {
-  if (bytes <= c->arena_bytes) return 0;
-  HIP_TRY(hipStreamSynchronize(c->st));
-  free_dev(c->arena);
-  c->arena = nullptr;
-  c->arena_bytes = 0;
-  bytes += bytes / 8 + (1 << 20);
-  if (hipMalloc(&c->arena, bytes) != hipSuccess) {
-    gtamd_set_error("cannot allocate %llu bytes of device memory for the "
-                    "refinement of tied suffixes",
-                    (unsigned long long) bytes);
-    (void) hipGetLastError();
-    return -1;
-  }
-  c->arena_bytes = bytes;
-  return 0;
-}
-
 static int fetch_stats(gtamd_esa_ctx *c) {
   HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats),
                          hipMemcpyDeviceToHost, c->st));
@@ -2081,118 +2296,99 @@ static int bits_for(u64 maxvalue) {
   return b;
 }
 
-static int ensure_xbuf(gtamd_esa_ctx *c, u64 words) {
-  if (words <= c->xbuf_words) return 0;
-  HIP_TRY(hipStreamSynchronize(c->st));
-  free_dev(c->xbuf);
-  c->xbuf = nullptr;
-  c->xbuf_words = 0;
-  words += words / 4 + 4096;
-  HIP_TRY(hipMalloc(&c->xbuf, words * 4));
-  c->xbuf_words = words;
-  return 0;
-}
+// bump allocation inside the arena; a first walk with base == nullptr only
+// adds up the size
+struct Bump {
+  u8 *base;
+  u64 off;
+  template <typename T> T *take(u64 count) {
+    off = (off + 255) & ~255ull;
+    T *p = base != nullptr ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
 
-// host-side collectives of a part build go through the caller's callbacks
-static int comm_allgather(gtamd_esa_ctx *c, const void *send, void *recv,
+// ---- collectives of a part build ----------------------------------------------
+// Every allgather carries a status word in front of the payload: a part that
+// has failed locally (out of memory, a HIP error) says so in the NEXT allgather
+// and all parts leave together -- nobody is left waiting in a collective.
+// `failed` != 0: this part has failed; returns -1 on every part if any has.
+static int comm_allgather(gtamd_esa_ctx *c, int failed, const void *send, void *recv,
                           u32 bytes) {
-  if (c->comm_allgather(c->comm_user, send, recv, bytes) != 0) {
+  const u32 R = c->numparts;
+  if (R == 1 && c->comm_allgather == nullptr) {   // one part, no transport given
+    if (bytes) memcpy(recv, send, bytes);
+    return failed ? -1 : 0;
+  }
+  std::vector<u8> mine(8 + (size_t) bytes), all((size_t) R * (8 + bytes));
+  const u64 status = failed ? 1 : 0;
+  memcpy(mine.data(), &status, 8);
+  if (bytes) memcpy(mine.data() + 8, send, bytes);
+  if (c->comm_allgather(c->comm_user, mine.data(), all.data(), 8 + bytes) != 0) {
     gtamd_set_error("allgather callback failed");
     return -1;
   }
+  int bad = -1;
+  for (u32 r = 0; r < R; r++) {
+    u64 s;
+    memcpy(&s, all.data() + (size_t) r * (8 + bytes), 8);
+    if (s != 0 && bad < 0) bad = (int) r;
+    if (bytes) memcpy((u8 *) recv + (size_t) r * bytes, all.data() + (size_t) r * (8 + bytes) + 8, bytes);
+  }
+  if (bad >= 0) {
+    if (!failed)
+      gtamd_set_error("part %d of the build failed (see its own message)", bad);
+    return -1;
+  }
   return 0;
 }
 
-// k2[j] = rank of suffix upos[j] + h, looked up at the part that owns that
-// suffix: queries are bucketed by owner (one radix pass), exchanged with
-// alltoallv, answered from the owner's rank table, and sent back.
-template <int BITS>
-static int exchange_ranks(gtamd_esa_ctx *c, const u32 *upos, u64 m, u64 h,
-                          const u32 *rank, u32 *k2, u64 *dkey_a, u32 *dval_a,
-                          u64 *dkey_b, u32 *dval_b, u32 *sendq, u32 *rws2,
-                          u64 *all_queries) {
-  hipStream_t st = c->st;
+// device buffers; ordered on the engine's stream (the callback enqueues the
+// exchange on it or synchronises it, see include/gtamd_esa.h)
+static int comm_alltoallv(gtamd_esa_ctx *c, const void *send, const u64 *sc, void *recv,
+                          const u64 *rc, u32 elem, const char *what) {
   const u32 R = c->numparts;
-  u32 *d_counts = c->d_parthist;   // idle after the split: reuse 256 counters
-  HIP_TRY(hipMemsetAsync(d_counts, 0, 256 * 4, st));
-  // few parts and an owner map: bucket without a sort (k_q_count / k_q_place)
-  const bool direct = c->have_pos_owner && R <= 16;
-  const u64 qb = div_up(m, 256);
-  u8 *dest = reinterpret_cast<u8 *>(dkey_b);          // m bytes
-  u32 *bcount = reinterpret_cast<u32 *>(dkey_a);      // R * qb counters, then their scan
-  u32 *boff = bcount + (u64) R * qb + 16;
-  if (m > 0 && direct) {
-    k_q_count<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, c->pos_owner, R, c->part, qb,
-                                        dest, bcount);
-    HIP_TRY(hipGetLastError());
-    TRY(scan_u32(SCAN_SUM, bcount, boff, (u64) R * qb, false, rws2, st));
-    k_q_totals<<<1, 64, 0, st>>>(boff, bcount, R, qb, d_counts);
-    HIP_TRY(hipGetLastError());
-  } else if (m > 0) {
-    k_query_dest<BITS><<<(u32) div_up(m, 256), 256, 0, st>>>(
-        c->text, upos, m, h, c->d_owner, reinterpret_cast<u32 *>(dkey_a), dval_a, d_counts);
-    HIP_TRY(hipGetLastError());
+  if (R == 1 && c->comm_alltoallv == nullptr) {
+    if (sc[0] != rc[0]) { gtamd_set_error("exchange (%s): count mismatch", what); return -1; }
+    if (sc[0])
+      HIP_TRY(hipMemcpyAsync(recv, send, sc[0] * elem, hipMemcpyDeviceToDevice, c->st));
+    return 0;
   }
-  u32 h_counts[256];
-  HIP_TRY(hipMemcpyAsync(h_counts, d_counts, 256 * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  std::vector<u64> sendcounts(R), matrix((size_t) R * R), recvcounts(R);
-  u64 msent = 0;
-  for (u32 r = 0; r < R; r++) { sendcounts[r] = h_counts[r]; msent += h_counts[r]; }
-  // queries this part answers itself are not sent; they still count in the
-  // matrix (its diagonal), which doubles as the termination test
-  const u64 mlocal = direct ? m - msent : 0;
-  if (direct) sendcounts[c->part] = mlocal;
-  TRY(comm_allgather(c, sendcounts.data(), matrix.data(), R * 8));
-  if (direct) sendcounts[c->part] = 0;
-  u64 nrecv = 0, total = 0;
-  for (u32 r = 0; r < R; r++) {
-    recvcounts[r] = (direct && r == c->part) ? 0 : matrix[(size_t) r * R + c->part];
-    nrecv += recvcounts[r];
-  }
-  for (size_t i = 0; i < matrix.size(); i++) total += matrix[i];
-  *all_queries = total;   // zero: no part has tied suffixes left
-  if (total == 0) return 0;
-  const u32 *order = dval_a;
-  if (m > 0 && direct) {
-    k_q_place<<<(u32) qb, 256, 0, st>>>(upos, m, h, c->n, dest, R, qb, boff, sendq, dval_b,
-                                        rank, k2);
-    HIP_TRY(hipGetLastError());
-    order = dval_b;
-  } else if (m > 0) {
-    const int shift0 = 0, width8 = 8;
-    // (the owner is the whole key: 32-bit keys in the 64-bit key buffers)
-    TRY(radix_sort_pairs<u32, u32>(reinterpret_cast<u32 *>(dkey_a), dval_a,
-                                   reinterpret_cast<u32 *>(dkey_b), dval_b, m, &shift0,
-                                   &width8, 1, rws2, st, nullptr, nullptr));
-    order = dval_b;
-    k_query_fill<<<(u32) div_up(m, 256), 256, 0, st>>>(upos, order, m, h, c->n, sendq);
-    HIP_TRY(hipGetLastError());
-  }
-  TRY(ensure_xbuf(c, 2 * nrecv + m + 64));
-  u32 *recvq = c->xbuf, *ans = c->xbuf + nrecv + 16, *recvans = ans + nrecv + 16;
-  HIP_TRY(hipStreamSynchronize(st));
-  if (c->comm_alltoallv(c->comm_user, sendq, sendcounts.data(), recvq,
-                        recvcounts.data(), 4) != 0) {
-    gtamd_set_error("alltoallv callback failed (queries)");
+  if (c->comm_alltoallv(c->comm_user, send, sc, recv, rc, elem, (void *) c->st) != 0) {
+    gtamd_set_error("alltoallv callback failed (%s)", what);
     return -1;
-  }
-  if (nrecv > 0) {
-    k_answer<<<(u32) div_up(nrecv, 256), 256, 0, st>>>(recvq, nrecv, rank, ans);
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(hipStreamSynchronize(st));
-  if (c->comm_alltoallv(c->comm_user, ans, recvcounts.data(), recvans,
-                        sendcounts.data(), 4) != 0) {
-    gtamd_set_error("alltoallv callback failed (answers)");
-    return -1;
-  }
-  if (msent > 0) {
-    k_k2_scatter<<<(u32) div_up(msent, 256), 256, 0, st>>>(recvans, order, msent, k2);
-    HIP_TRY(hipGetLastError());
   }
   return 0;
 }
+
+// bucket m items by destination part: dest bytes, per-block counts and their
+// scan, per-part totals into c->d_counts + slot * DEST_MAXPARTS
+template <typename F>
+static int dest_count(gtamd_esa_ctx *c, const F &f, u64 m, u8 *dest, u32 *bcount, u32 *boff,
+                      u32 *scanws, int slot) {
+  const u32 R = c->numparts;
+  hipStream_t st = c->st;
+  u32 *counts = c->d_counts + slot * DEST_MAXPARTS;
+  HIP_TRY(hipMemsetAsync(counts, 0, DEST_MAXPARTS * 4, st));
+  if (m == 0) return 0;
+  const u64 nb = div_up(m, 256);
+  k_dest_count<F><<<(u32) nb, 256, 0, st>>>(f, m, R, nb, dest, bcount);
+  HIP_TRY(hipGetLastError());
+  TRY(scan_u32(SCAN_SUM, bcount, boff, (u64) R * nb, false, scanws, st));
+  k_dest_totals<<<1, DEST_MAXPARTS, 0, st>>>(boff, bcount, R, nb, counts);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+template <typename F>
+static int dest_place(gtamd_esa_ctx *c, const F &f, u64 m, const u8 *dest, const u32 *boff) {
+  if (m == 0) return 0;
+  const u64 nb = div_up(m, 256);
+  k_dest_place<F><<<(u32) nb, 256, 0, c->st>>>(f, m, c->numparts, nb, dest, boff);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static u64 dest_words(u32 R, u64 m) { return (u64) R * div_up(m ? m : 1, 256) + 16; }
 
 // the three sections of the bucket table from the sorted keys
 template <int BITS>
@@ -2222,9 +2418,9 @@ static int build_bcktab(gtamd_esa_ctx *c, const u64 *skey, u64 NL, u32 k,
   }
   // left borders: exclusive prefix sums; the last entry becomes the number of
   // suffixes that are in a bucket
-  u32 *ws = c->rws;
+  u32 *ws = c->rws.as<u32>();
   u32 *own = nullptr;
-  if (scan_workspace_words(codes + 1) > c->rws_words) {
+  if (scan_workspace_words(codes + 1) * 4 > c->rws.bytes) {
     HIP_TRY(hipMalloc(&own, scan_workspace_words(codes + 1) * 4));
     ws = own;
   }
@@ -2235,11 +2431,41 @@ static int build_bcktab(gtamd_esa_ctx *c, const u64 *skey, u64 NL, u32 k,
   return 0;
 }
 
-template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
+// workspace of a run over `cap` entries
+static u64 rws_words_for(u64 cap) {
+  return radix_workspace_words(cap) + 6 * (div_up(cap, 64) + 64) +
+         scan_workspace_words(div_up(cap, 64)) + 64;
+}
+static int ensure_workspace(gtamd_esa_ctx *c, u64 cap, u32 want, bool dist) {
+  const u64 pad = cap + 8;
+  TRY(ensure_buf(c, c->k0, pad * 8, "sort keys"));
+  TRY(ensure_buf(c, c->k1, pad * 8, "sort keys"));
+  TRY(ensure_buf(c, c->v0, pad * 4, "sort values"));
+  TRY(ensure_buf(c, c->v1, pad * 4, "sort values"));
+  TRY(ensure_buf(c, c->rws, rws_words_for(cap) * 4, "the radix workspace"));
+  TRY(ensure_buf(c, c->tiebits, (div_up(cap, 64) + 2) * 8, "the tie bitmap"));
+  if (want & GTAMD_WANT_SUF) TRY(ensure_buf(c, c->suf, pad * 8, "the suffix table"));
+  if (want & GTAMD_WANT_LCP) TRY(ensure_buf(c, c->lcp, pad, "the lcp table"));
+  if (want & GTAMD_WANT_BWT) TRY(ensure_buf(c, c->bwt, pad, "the bwt table"));
+  if (dist) TRY(ensure_buf(c, c->isa_tmp, pad * 8, "the exchange scratch"));
+  {
+    // digit-byte side arrays of the sort: an experiment switch (esa_prims.hip)
+    const char *db = getenv("GTAMD_DIGBYTES");
+    if (db != nullptr && db[0] == '1') {
+      TRY(ensure_buf(c, c->dig0, pad, "digit bytes"));
+      TRY(ensure_buf(c, c->dig1, pad, "digit bytes"));
+    }
+  }
+  return 0;
+}
+
+// BITS: symbol width; WIDE: positions and ranks are 64-bit (part builds of
+// sequences with n >= 2^32)
+template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, bool dist) {
   using K = Key<BITS>;
+  using P = typename std::conditional<WIDE, u64, u32>::type;
   const u64 N = c->N, n = c->n;
   const u32 R = c->numparts;
-  const bool parts = R > 1;
   hipStream_t st = c->st;
   const bool want_suf = want & GTAMD_WANT_SUF, want_lcp = want & GTAMD_WANT_LCP,
              want_bwt = want & GTAMD_WANT_BWT;
@@ -2251,13 +2477,13 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
                     K::SYMS);
     return -1;
   }
-  if (parts && (want & GTAMD_WANT_BCK)) {
+  if (dist && (want & GTAMD_WANT_BCK)) {
     // as the reference: no bucket table from a run in parts
     // (gt_Sfxiterator_bcktab2file, src/match/sfx-suffixer.c:2206-2217)
     gtamd_set_error("the bucket table is not available from a part build");
     return -1;
   }
-  if (parts && (c->comm_allgather == nullptr || c->comm_alltoallv == nullptr)) {
+  if (R > 1 && (c->comm_allgather == nullptr || c->comm_alltoallv == nullptr)) {
     gtamd_set_error("a part build needs the collective callbacks "
                     "(gtamd_esa_set_comm)");
     return -1;
@@ -2265,44 +2491,87 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   memset(&c->timing, 0, sizeof c->timing);
   memset(&c->stats, 0, sizeof c->stats);
   c->llv_pairs = 0;
-  HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
-  HIP_TRY(hipEventRecord(c->ev[0], st));
+  const bool debug = getenv("GTAMD_DEBUG") != nullptr;
 
   // ---- keygen (whole table, or the pairs of this part's key range)
   u64 NL = N, index_offset = 0;
+  Tiles tl;
+  tl.T = N;
+  tl.self = c->part;
+  u64 Tn = N;                       // positions of the own text tile
+  int fail = 0;                     // local failure, reported in the next allgather
   // DNA whole-table builds: the keygen also does the sort's first pass (the
   // dcode digit); GTAMD_FUSED_PASS0=0 takes the plain keygen + full sort
   bool pass0_done = false;
-  if (!parts) {
+  if (!dist) {
+    TRY(ensure_workspace(c, N, want, false));
+    HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
+    HIP_TRY(hipEventRecord(c->ev[0], st));
     const char *fz = getenv("GTAMD_FUSED_PASS0");
     if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
-      k_dc_hist_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws);
+      k_dc_hist_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws.as<u32>());
       HIP_TRY(hipGetLastError());
-      TRY(radix_scan_tile_hist(c->rws, N, st));
+      TRY(radix_scan_tile_hist(c->rws.as<u32>(), N, st));
       // (into the second buffer pair: the five passes left then end in the
       // first, where the six passes of the plain path end too)
-      k_keygen_pass0_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws, c->k1, c->v1);
+      k_keygen_pass0_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws.as<u32>(),
+                                                      c->k1.as<u64>(), c->v1.as<u32>());
       pass0_done = true;
     } else if (BITS == 2)
-      k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+      k_keygen_dna<<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, 0, N, c->k0.as<u64>(),
+                                                          c->v0.as<u32>());
     else
-      k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, N, c->k0, c->v0);
+      k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, 0, N, c->k0.as<u64>(),
+                                                            c->v0.as<u32>());
     HIP_TRY(hipGetLastError());
   } else {
-    // range cuts from a histogram of the key bins over every 16th suffix;
-    // every part computes the same cuts from the replicated text
-    const u64 stride = N > (1u << 24) ? 16 : 1;
-    HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
-    k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, N, stride, c->d_parthist);
-    HIP_TRY(hipGetLastError());
-    std::vector<u32> hist(PART_BINS);
-    HIP_TRY(hipMemcpyAsync(hist.data(), c->d_parthist, PART_BINS * 4,
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // the own text tile: T positions per part, a multiple of the keygen tile
+    tl.T = div_up(div_up(N, R), 4096) * 4096;
+    const u64 first = (u64) c->part * tl.T < N ? (u64) c->part * tl.T : N;
+    const u64 end = first + tl.T < N ? first + tl.T : N;
+    Tn = end - first;
+    // room for the slice: the tile plus a margin for uneven ranges (grown
+    // below, once the real slice size is known, if that is not enough)
+    u64 cap = Tn + Tn / 8 + 65536;
+    if (cap >= SINGLE_LIMIT) cap = SINGLE_LIMIT - 1;
+    fail |= ensure_workspace(c, cap, want, true) != 0;
+    if (!fail) {
+      HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
+      HIP_TRY(hipEventRecord(c->ev[0], st));
+    }
+    // range cuts from a histogram of the key bins over every 16th suffix: every
+    // part counts its own tile, the sum is the same on every part
+    std::vector<u32> hist(PART_BINS, 0u), allhist((size_t) PART_BINS * R);
+    if (!fail) {
+      const u64 stride = N > (1u << 24) ? 16 : 1;
+      HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
+      if (Tn > 0) {
+        k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, first, end, stride, c->d_parthist);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipMemcpyAsync(hist.data(), c->d_parthist, PART_BINS * 4,
+                             hipMemcpyDeviceToHost, st));
+      // the keys of the tile, meanwhile
+      if (Tn > 0) {
+        if (BITS == 2)
+          k_keygen_dna<<<(u32) div_up(Tn, 1024), 256, 0, st>>>(c->text, first, end,
+                                                               c->k0.as<u64>(), c->v0.as<u32>());
+        else
+          k_keygen<BITS><<<(u32) div_up(Tn, 1024), 256, 0, st>>>(c->text, first, end,
+                                                                 c->k0.as<u64>(), c->v0.as<u32>());
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    TRY(comm_allgather(c, fail, hist.data(), allhist.data(), PART_BINS * 4));
     std::vector<u64> start(PART_BINS + 1);
     start[0] = 0;
-    for (int b = 0; b < PART_BINS; b++) start[b + 1] = start[b] + hist[b];
+    for (int b = 0; b < PART_BINS; b++) {
+      u64 s = 0;
+      for (u32 r = 0; r < R; r++) s += allhist[(size_t) r * PART_BINS + b];
+      start[b + 1] = start[b] + s;
+    }
     const u64 nsamp = start[PART_BINS];
     std::vector<u32> cut(R + 1);
     std::vector<u8> owner(PART_BINS);
@@ -2318,51 +2587,74 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       for (u32 b = cut[r]; b < cut[r + 1]; b++) owner[b] = (u8) r;
     HIP_TRY(hipMemcpyAsync(c->d_owner, owner.data(), PART_BINS,
                            hipMemcpyHostToDevice, st));
-    const u32 lo = cut[c->part], hi = cut[c->part + 1];
-    // exact membership (bitmask), block counts and the sizes of all parts
-    const u64 nblk = div_up(N, 1024);
-    u32 *cnt = c->rws, *off = cnt + nblk + 16, *sws = off + nblk + 16;
-    u64 *inrange = c->k1;            // nblk * 16 words <= N / 64 + 16
-    unsigned long long *d_partcnt =
-        reinterpret_cast<unsigned long long *>(c->d_parthist);  // 256 x u64 fit
-    HIP_TRY(hipMemsetAsync(d_partcnt, 0, 256 * 8, st));
-    c->have_pos_owner = false;
-    if (BITS == 2 && R <= 16 && PART_BITS == 14) {
-      if (c->pos_owner == nullptr) HIP_TRY(hipMalloc(&c->pos_owner, N + 64));
-      c->have_pos_owner = true;
+    // bucket the tile's pairs by the owner of their key range (stable)
+    u8 *dest = c->isa_tmp.as<u8>();
+    u32 *bcount = reinterpret_cast<u32 *>(dest + ((Tn + 255) & ~255ull));
+    u32 *boff = bcount + dest_words(R, Tn);
+    OwnerOfKey own;
+    own.keys = c->k0.as<u64>(); own.vals = c->v0.as<u32>(); own.owner = c->d_owner;
+    own.keys_out = c->k1.as<u64>(); own.vals_out = c->v1.as<u32>();
+    if (((Tn + 255) & ~255ull) + 2 * dest_words(R, Tn) * 4 > c->isa_tmp.bytes ||
+        scan_workspace_words((u64) R * div_up(Tn ? Tn : 1, 256)) * 4 > c->rws.bytes) {
+      gtamd_set_error("%u parts are too many for a tile of %llu positions", R,
+                      (unsigned long long) Tn);
+      fail = 1;
     }
-    if (c->have_pos_owner)
-      k_part_count_dna<<<stride_grid(div_up(N, 8192)), 256, 0, st>>>(c->text, N, lo, hi,
-                                                             c->d_owner, inrange, cnt,
-                                                             d_partcnt, c->pos_owner);
-    else
-      k_part_count<BITS><<<stride_grid(nblk), 256, 0, st>>>(c->text, N, lo, hi, c->d_owner, R,
-                                                     inrange, cnt, d_partcnt);
-    HIP_TRY(hipGetLastError());
-    TRY(scan_u32(SCAN_SUM, cnt, off, nblk, false, sws, st));
-    unsigned long long h_partcnt[256];
-    HIP_TRY(hipMemcpyAsync(h_partcnt, d_partcnt, 256 * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    index_offset = 0;
+    if (!fail) {
+      TRY(dest_count(c, own, Tn, dest, bcount, boff, c->rws.as<u32>(), 0));
+      HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
+                             hipMemcpyDeviceToHost, st));
+      TRY(dest_place(c, own, Tn, dest, boff));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    std::vector<u64> sendcounts(R), recvcounts(R), matrix((size_t) R * R);
+    for (u32 r = 0; r < R; r++) sendcounts[r] = fail ? 0 : c->h_counts[r];
+    TRY(comm_allgather(c, fail, sendcounts.data(), matrix.data(), R * 8));
+    NL = 0;
     u64 allparts = 0;
-    for (u32 r = 0; r < R; r++) {
-      if (r < c->part) index_offset += h_partcnt[r];
-      allparts += h_partcnt[r];
+    for (u32 s = 0; s < R; s++) {
+      recvcounts[s] = matrix[(size_t) s * R + c->part];
+      NL += recvcounts[s];
+      for (u32 q = 0; q < R; q++) {
+        allparts += matrix[(size_t) s * R + q];
+        if (q < c->part) index_offset += matrix[(size_t) s * R + q];
+      }
     }
-    NL = h_partcnt[c->part];
     if (allparts != N) {
       gtamd_set_error("range partition counts %llu suffixes, expected %llu",
                       (unsigned long long) allparts, (unsigned long long) N);
-      return -1;
+      fail = 1;
     }
-    if (NL > 0) {
-      k_part_emit<BITS><<<(u32) nblk, 256, 0, st>>>(c->text, N, inrange, off, cnt,
-                                                    c->k0, c->v0);
-      HIP_TRY(hipGetLastError());
+    if (NL >= SINGLE_LIMIT) {
+      gtamd_set_error("slice of %llu entries exceeds the 32-bit index range of one "
+                      "part: use more parts", (unsigned long long) NL);
+      fail = 1;
+    }
+    // the receive side first (its old contents -- the unbucketed pairs -- are
+    // dead); the rest of the workspace after the exchange
+    if (!fail && NL > cap) {
+      fail |= ensure_buf(c, c->k0, (NL + 8) * 8, "sort keys") != 0;
+      fail |= ensure_buf(c, c->v0, (NL + 8) * 4, "sort values") != 0;
+    }
+    TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+    TRY(comm_alltoallv(c, c->k1.p, sendcounts.data(), c->k0.p, recvcounts.data(), 8,
+                       "keys"));
+    TRY(comm_alltoallv(c, c->v1.p, sendcounts.data(), c->v0.p, recvcounts.data(), 4,
+                       "positions"));
+    if (NL > cap) {
+      HIP_TRY(hipStreamSynchronize(st));   // k1/v1 have been sent
+      fail |= ensure_workspace(c, NL, want, true) != 0;
+      // (a failure here is reported by the next allgather; nothing is launched
+      // on the missing buffers, see `fail` below)
     }
   }
   c->NL = NL;
   c->index_offset = index_offset;
+  if (debug)
+    fprintf(stderr, "gtamd: part %u/%u: tile %llu positions, slice %llu entries at %llu%s\n",
+            c->part, R, (unsigned long long) Tn, (unsigned long long) NL,
+            (unsigned long long) index_offset, WIDE ? " (64-bit positions)" : "");
+  if (dist) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
   HIP_TRY(hipEventRecord(c->ev[1], st));
 
   // ---- first sort: all key bits above the payload
@@ -2381,35 +2673,53 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     np++;
   }
   int nev = 0;
-  u64 *ka = pass0_done ? c->k1 : c->k0, *kb = pass0_done ? c->k0 : c->k1;
-  u32 *va = pass0_done ? c->v1 : c->v0, *vb = pass0_done ? c->v0 : c->v1;
+  u64 *ka = pass0_done ? c->k1.as<u64>() : c->k0.as<u64>(),
+      *kb = pass0_done ? c->k0.as<u64>() : c->k1.as<u64>();
+  u32 *va = pass0_done ? c->v1.as<u32>() : c->v0.as<u32>(),
+      *vb = pass0_done ? c->v0.as<u32>() : c->v1.as<u32>();
   TRY(radix_sort_pairs<u64, u32>(ka, va, kb, vb, NL, shifts, widths, np,
-                            c->rws, st, c->ev_scatter, &nev, c->dig0, c->dig1));
+                            c->rws.as<u32>(), st, c->ev_scatter, &nev, c->dig0.as<u8>(),
+                            c->dig1.as<u8>()));
   u64 *skey = (np & 1) ? kb : ka;   // sorted keys
-  u32 *sa32 = (np & 1) ? vb : va;   // positions in suffix order
+  u32 *sa32 = (np & 1) ? vb : va;   // positions in suffix order (low half)
   u64 *fkey = (np & 1) ? ka : kb;   // free key-sized buffer
-  u32 *rank = (np & 1) ? va : vb;   // free value-sized buffer
+  u32 *fval = (np & 1) ? va : vb;   // free value-sized buffer
   HIP_TRY(hipEventRecord(c->ev[2], st));
 
   if (want & GTAMD_WANT_BCK) TRY(build_bcktab<BITS>(c, skey, NL, prefixlength, st));
 
+  // positions at the width the refinement works with
+  P *sa;
+  if (WIDE) {
+    u64 *sa64 = c->isa_tmp.as<u64>();   // (the bucketing scratch is dead)
+    if (NL > 0) {
+      k_wide_positions<BITS><<<(u32) div_up(NL, 256), 256, 0, st>>>(skey, sa32, NL, sa64);
+      HIP_TRY(hipGetLastError());
+    }
+    sa = reinterpret_cast<P *>(sa64);
+  } else
+    sa = reinterpret_cast<P *>(sa32);
+  u64 *d_suf = want_suf ? c->suf.as<u64>() : nullptr;
+  u8 *d_lcp = want_lcp ? c->lcp.as<u8>() : nullptr;
+  u8 *d_bwt = want_bwt ? c->bwt.as<u8>() : nullptr;
+
   // ---- finalize; a part needs the last key of the preceding range
   u64 prev_key = 0;
   int has_prev = 0;
-  if (parts) {
+  if (R > 1) {
     u64 mine[2] = {NL, 0};
     if (NL > 0)
       HIP_TRY(hipMemcpyAsync(&mine[1], skey + (NL - 1), 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<u64> all(2 * (size_t) R);
-    TRY(comm_allgather(c, mine, all.data(), 16));
+    TRY(comm_allgather(c, 0, mine, all.data(), 16));
     for (u32 r = 0; r < c->part; r++)
       if (all[2 * r] > 0) { prev_key = all[2 * r + 1]; has_prev = 1; }
   }
   // Table emission (k_finalize, bandwidth-bound) runs on the second stream.
-  // It is started where the first stream turns latency-bound (the scatter of
-  // the rank table), so that the two actually overlap; whatever it writes for
-  // tied entries is provisional and overwritten after the join.
+  // It is started where the first stream turns latency-bound (the comparisons
+  // of the pair path, the rounds), so that the two actually overlap; whatever
+  // it writes for tied entries is provisional and overwritten after the join.
   bool emitted = false;
   auto launch_emission = [&]() -> int {
     if (emitted) return 0;
@@ -2417,17 +2727,17 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
     HIP_TRY(hipEventRecord(c->ev_sorted, st));
     HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
     if (NL > 0) {
-      k_finalize<BITS><<<stride_grid(div_up(NL, FIN_TILE)), FIN_THREADS, 0, c->st2>>>(
-          skey, sa32, NL, prefixlength, want_suf ? c->suf : nullptr,
-          want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, nullptr,
+      k_finalize<BITS, P><<<stride_grid(div_up(NL, FIN_TILE)), FIN_THREADS, 0, c->st2>>>(
+          skey, sa, NL, prefixlength, d_suf, d_lcp, d_bwt, nullptr,
           c->d_stats, prev_key, has_prev, index_offset);
       HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev_emitted, c->st2));
     return 0;
   };
+  u64 *tiebits = c->tiebits.as<u64>();
   if (NL > 0) {
-    k_tiebits<BITS><<<stride_grid(div_up(NL, 4096)), 256, 0, st>>>(skey, NL, c->tiebits,
+    k_tiebits<BITS><<<stride_grid(div_up(NL, 4096)), 256, 0, st>>>(skey, NL, tiebits,
                                                                    c->d_stats);
     HIP_TRY(hipGetLastError());
   }
@@ -2435,96 +2745,86 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   TRY(fetch_stats(c));
   const u64 numties = c->h_stats->numties;
   u64 anyties = numties;
-  if (parts) {
+  if (R > 1) {
     std::vector<u64> all(R);
-    TRY(comm_allgather(c, &numties, all.data(), 8));
+    TRY(comm_allgather(c, 0, &numties, all.data(), 8));
     anyties = 0;
     for (u32 r = 0; r < R; r++) anyties += all[r];
   }
   u32 rounds = 0;
-  u64 m0 = 0;
+  u64 m0 = 0, npairs = 0;
   HIP_TRY(hipEventRecord(c->ev[4], st));
   HIP_TRY(hipEventRecord(c->ev[5], st));
   if (anyties > 0) {
-    // ---- unresolved list and group heads
+    // ---- how many suffixes are tied with a neighbour
     const u64 nwords = div_up(NL, 64);
-    u32 *cntw = c->rws;                    // radix workspace is idle now
+    u32 *cntw = c->rws.as<u32>();          // radix workspace is idle now
     u32 *headw = cntw + nwords + 16;
     u32 *offw = headw + nwords + 16;
     u32 *carry = offw + nwords + 16;
-    u32 *scanws = carry + nwords + 16;
-    if (NL > 0) {
-      k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(c->tiebits, nwords,
-                                                            cntw, headw);
+    u32 *pcnt = carry + nwords + 16;       // pair heads per word, and their scan
+    u32 *poff = pcnt + nwords + 16;
+    u32 *scanws = poff + nwords + 16;
+    u32 *pws = scanws + scan_workspace_words(nwords) + 64;   // radix workspace (NL pairs)
+    auto tie_words = [&](const u64 *bits, bool with_pairs) -> int {
+      if (NL > 0) {
+        k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(bits, nwords, cntw, headw);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
+        TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
+        if (with_pairs) TRY(scan_u32(SCAN_SUM, pcnt, poff, nwords, false, scanws, st));
+      }
+      k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
-      TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
-    }
-    k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
-    HIP_TRY(hipGetLastError());
-    TRY(fetch_stats(c));
+      if (with_pairs) {
+        k_total2<<<1, 1, 0, st>>>(poff, pcnt, nwords, c->d_stats);
+        HIP_TRY(hipGetLastError());
+      }
+      TRY(fetch_stats(c));
+      return 0;
+    };
+    TRY(tie_words(tiebits, false));
     m0 = c->h_stats->count;
-    // arena layout (u32 units unless noted)
-    const u64 mp = (m0 + 64 + 3) & ~3ull;   // every array of the arena 16-byte aligned
-    const u64 need = mp * 4 * 18 + mp * 8 * 2 + radix_workspace_words(m0) * 4 +
-                     scan_workspace_words(m0) * 4 + 4096;
-    TRY(ensure_arena(c, need));
-    u32 *a32 = reinterpret_cast<u32 *>(c->arena);
-    u64 *ckey_a = reinterpret_cast<u64 *>(a32); a32 += 2 * mp;
-    u64 *ckey_b = reinterpret_cast<u64 *>(a32); a32 += 2 * mp;
-    u32 *uidx0 = a32; a32 += mp;
-    u32 *uidx = a32; a32 += mp;
-    u32 *upos = a32; a32 += mp;
-    u32 *ugrp = a32; a32 += mp;
-    u32 *uidx2 = a32; a32 += mp;
-    u32 *upos2 = a32; a32 += mp;
-    u32 *ugrp2 = a32; a32 += mp;
-    u32 *cval_a = a32; a32 += mp;
-    u32 *cval_b = a32; a32 += mp;
-    u32 *hv = a32; a32 += mp;      // head values -> new group ids
-    u64 *keep = reinterpret_cast<u64 *>(a32); a32 += mp;   // 1 bit per slot
-    u32 *koff = a32; a32 += mp;
-    u32 *k2 = a32; a32 += mp;      // rank of the suffix h further on
-    u32 *cvo = a32; a32 += mp;     // positions in the round's new order
-    u8 *flg = reinterpret_cast<u8 *>(a32); a32 += mp;     // deferred to the global path (1 bit per slot)
-    u32 *foff = a32; a32 += mp;
-    u32 *fj = a32; a32 += mp;
-    u32 *sendq = a32; a32 += mp;   // part builds: rank queries
-    u32 *rws2 = a32;               // radix + scan workspace for the rounds
-    u32 *scanws2 = rws2 + radix_workspace_words(m0);
-    if (m0 > 0) {
-      k_unres_emit<<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
-          c->tiebits, nwords, offw, carry, sa32, uidx0, uidx, upos, ugrp);
-      HIP_TRY(hipGetLastError());
-    }
     // few shallow ties: settle them by direct comparison, no rank table
     bool settled = false;
     {
       const u64 thresh = NL / 512 > 4096 ? NL / 512 : 4096;
       u64 small = m0 <= thresh;
-      if (parts) {
+      if (R > 1) {
         std::vector<u64> all(R);
-        TRY(comm_allgather(c, &small, all.data(), 8));
+        TRY(comm_allgather(c, 0, &small, all.data(), 8));
         for (u32 r = 0; r < R; r++) small &= all[r];
       }
       if (small) {
-        TRY(launch_emission());
-        HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));   // join the emission
-        if (m0 > 0) {
-          k_direct_ties<BITS><<<(u32) div_up(m0, 256), 256, 0, st>>>(
-              c->text, uidx0, ugrp, m0, sa32, want_suf ? c->suf : nullptr,
-              want_lcp ? c->lcp : nullptr, want_bwt ? c->bwt : nullptr, want_lcp,
-              index_offset, c->d_stats);
-          HIP_TRY(hipGetLastError());
+        const u64 mp = (m0 + 64 + 3) & ~3ull;
+        int bad = ensure_buf(c, c->arena, mp * (12 + sizeof(P)) + 4096, "the tied suffixes") != 0;
+        if (!bad) {
+          Bump a = {c->arena.as<u8>(), 0};
+          u32 *uidx0 = a.take<u32>(mp), *uidx = a.take<u32>(mp), *ugrp = a.take<u32>(mp);
+          P *upos = a.take<P>(mp);
+          if (m0 > 0) {
+            k_unres_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
+                tiebits, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
+            HIP_TRY(hipGetLastError());
+          }
+          TRY(launch_emission());
+          HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));   // join the emission
+          if (m0 > 0) {
+            k_direct_ties<BITS, P><<<(u32) div_up(m0, 256), 256, 0, st>>>(
+                c->text, uidx0, ugrp, m0, sa, d_suf, d_lcp, d_bwt, want_lcp,
+                index_offset, c->d_stats);
+            HIP_TRY(hipGetLastError());
+          }
+          TRY(fetch_stats(c));
         }
-        TRY(fetch_stats(c));
-        u64 gaveup = c->h_stats->dfallback;
-        if (parts) {
+        u64 gaveup = bad ? 1 : c->h_stats->dfallback;
+        if (R > 1) {
           std::vector<u64> all(R);
-          TRY(comm_allgather(c, &gaveup, all.data(), 8));
+          TRY(comm_allgather(c, bad, &gaveup, all.data(), 8));
           gaveup = 0;
           for (u32 r = 0; r < R; r++) gaveup |= all[r];
-        }
+        } else if (bad)
+          return -1;
         settled = gaveup == 0;
         if (!settled) {
           // discard the partial statistics of the direct attempt
@@ -2534,119 +2834,344 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       }
     }
     if (!settled) {
-    // rank table: global ranks of this part's suffixes (all of them when
-    // there is one part); other parts' entries are never read here
+    // ---- pairs leave the bitmap; what is left goes through prefix doubling
+    TRY(ensure_buf(c, c->tiebits2, (nwords + 2) * 8, "the tie bitmap"));
+    u64 *tiebits2 = c->tiebits2.as<u64>();
+    const bool no_pairs = getenv("GTAMD_NO_PAIRS") != nullptr;   // A/B switch
     if (NL > 0) {
+      if (no_pairs) {
+        HIP_TRY(hipMemcpyAsync(tiebits2, tiebits, nwords * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemsetAsync(pcnt, 0, nwords * 4, st));
+      } else {
+        k_pair_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, pcnt, tiebits2);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    TRY(tie_words(tiebits2, true));
+    m0 = c->h_stats->count;
+    npairs = c->h_stats->count2;
+    u64 anyleft = m0;
+    if (R > 1) {
+      std::vector<u64> all(R);
+      TRY(comm_allgather(c, 0, &m0, all.data(), 8));
+      anyleft = 0;
+      for (u32 r = 0; r < R; r++) anyleft += all[r];
+    }
+    if (debug)
+      fprintf(stderr, "gtamd: part %u: %llu tied with a neighbour, %llu pairs, %llu left\n",
+              c->part, (unsigned long long) numties, (unsigned long long) npairs,
+              (unsigned long long) m0);
+    // arena: pair list | unresolved list and round buffers | exchange buffers
+    const u64 pp = (npairs + 64 + 3) & ~3ull;
+    const u64 mp = (m0 + 64 + 3) & ~3ull;   // every array of the arena 16-byte aligned
+    const u64 ISA_CHUNK = 1ull << 27;
+    const u64 ichunk = NL < ISA_CHUNK ? NL : ISA_CHUNK;
+    const u64 xm = dist ? (ichunk > mp ? ichunk : mp) : 0;   // items bucketed at a time
+    P *pk_a = nullptr, *pk_b = nullptr, *upos = nullptr, *upos2 = nullptr, *cvo = nullptr,
+      *k2 = nullptr, *fk2 = nullptr, *fk2s_a = nullptr, *fk2s_b = nullptr, *fpos = nullptr,
+      *cvs = nullptr, *lk_a = nullptr, *lk_b = nullptr, *xrank = nullptr, *xans = nullptr;
+    u32 *pv_a = nullptr, *pv_b = nullptr, *pres = nullptr, *prws = nullptr, *uidx0 = nullptr,
+        *uidx = nullptr, *ugrp = nullptr, *uidx2 = nullptr, *ugrp2 = nullptr, *hv = nullptr,
+        *koff = nullptr, *fgrp = nullptr, *fj = nullptr, *perm_a = nullptr, *perm_b = nullptr,
+        *gk_a = nullptr, *gk_b = nullptr, *fhv = nullptr, *lv_a = nullptr, *lv_b = nullptr,
+        *rws2 = nullptr, *scanws2 = nullptr, *xoff = nullptr, *xorder = nullptr,
+        *xbc_q = nullptr, *xbo_q = nullptr, *xbc_u = nullptr, *xbo_u = nullptr;
+    u64 *keep = nullptr;
+    u8 *flg = nullptr, *xdest_q = nullptr, *xdest_u = nullptr;
+    auto layout = [&](Bump &a) {
+      pk_a = a.take<P>(pp); pk_b = a.take<P>(pp);
+      pv_a = a.take<u32>(pp); pv_b = a.take<u32>(pp);
+      pres = a.take<u32>(pp);
+      prws = a.take<u32>(radix_workspace_words(npairs));
+      uidx0 = a.take<u32>(mp); uidx = a.take<u32>(mp); ugrp = a.take<u32>(mp);
+      uidx2 = a.take<u32>(mp); ugrp2 = a.take<u32>(mp);
+      upos = a.take<P>(mp); upos2 = a.take<P>(mp);
+      cvo = a.take<P>(mp);           // positions in the round's new order
+      hv = a.take<u32>(mp);          // head values -> new group ids
+      keep = a.take<u64>(mp / 64 + 4);   // 1 bit per slot
+      koff = a.take<u32>(mp);
+      k2 = a.take<P>(mp);            // rank of the suffix h further on
+      flg = a.take<u8>(mp / 8 + 256);    // deferred to the global path (1 bit per slot)
+      // global path of a round (groups across tile borders)
+      fk2 = a.take<P>(mp); fk2s_a = a.take<P>(mp); fk2s_b = a.take<P>(mp);
+      fpos = a.take<P>(mp); cvs = a.take<P>(mp);
+      fgrp = a.take<u32>(mp); fj = a.take<u32>(mp);
+      perm_a = a.take<u32>(mp); perm_b = a.take<u32>(mp);
+      gk_a = a.take<u32>(mp); gk_b = a.take<u32>(mp);
+      fhv = a.take<u32>(mp);
+      // LCP pairs of the tie fix
+      lk_a = a.take<P>(mp); lk_b = a.take<P>(mp);
+      lv_a = a.take<u32>(mp); lv_b = a.take<u32>(mp);
+      rws2 = a.take<u32>(radix_workspace_words(m0));   // radix + scan workspace for the rounds
+      scanws2 = a.take<u32>(scan_workspace_words(mp > dest_words(R, xm) ? mp : dest_words(R, xm)));
+      if (dist) {
+        xoff = a.take<u32>(xm + 64); xorder = a.take<u32>(xm + 64);
+        xrank = a.take<P>(xm + 64); xans = a.take<P>(xm + 64);
+        xdest_q = a.take<u8>(xm + 64); xdest_u = a.take<u8>(xm + 64);
+        xbc_q = a.take<u32>(dest_words(R, xm)); xbo_q = a.take<u32>(dest_words(R, xm));
+        xbc_u = a.take<u32>(dest_words(R, xm)); xbo_u = a.take<u32>(dest_words(R, xm));
+      }
+    };
+    {
+      Bump sz = {nullptr, 0};
+      layout(sz);
+      fail = ensure_buf(c, c->arena, sz.off + 4096, "the refinement of tied suffixes") != 0;
+      if (dist && !fail)
+        fail = ensure_buf(c, c->xrecv, (Tn + 64) * (4 + sizeof(P)) + 512,
+                          "the exchange of ranks") != 0;
+      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+      else if (fail) return -1;
+      Bump a = {c->arena.as<u8>(), 0};
+      layout(a);
+    }
+    u32 *xrecv_off = c->xrecv.as<u32>();
+    P *xrecv_val = reinterpret_cast<P *>(c->xrecv.as<u8>() + (((Tn + 64) * 4 + 255) & ~255ull));
+    const int nb = bits_for(N - 1);      // bits of a position / of a rank
+    const int nbl = bits_for(NL ? NL - 1 : 0);   // bits of an index into the slice
+    auto passes_for = [](int bits, int *ps, int *pw) -> int {
+      int cnt = 0;
+      for (int b = 0; b < bits; b += 8) {
+        ps[cnt] = b;
+        pw[cnt] = bits - b < 8 ? bits - b : 8;
+        cnt++;
+      }
+      return cnt;
+    };
+    int ps[8], pw[8];
+    const int pn = passes_for(nb, ps, pw);
+    // ---- the pairs: sorted by text position, compared, swapped
+    const u32 *pv_sorted = pv_a;
+    if (npairs > 0) {
+      k_pair_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
+          tiebits, nwords, poff, sa, pk_a, pv_a);
+      HIP_TRY(hipGetLastError());
+      TRY(radix_sort_pairs<P, u32>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
+                                   nullptr, nullptr));
+      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
+      pv_sorted = (pn & 1) ? pv_b : pv_a;
+      TRY(launch_emission());   // bandwidth-bound, beside the comparisons
+      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
+          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- unresolved list of what is left
+    if (m0 > 0) {
+      k_unres_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
+          tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- rank table and doubling rounds, if any part has a group left
+    P *rank = nullptr;       // whole table (single build) ...
+    P *isa = nullptr;        // ... or the ranks of the own text tile (part build)
+    if (anyleft > 0 && !dist) {
+      // rank table: ranks of all suffixes; (a whole-table build makes the heads
+      // inside its first partition pass)
+      TRY(ensure_buf(c, c->isa_tmp, (NL + 8) * 8, "the rank table build"));
+      u32 *rank32 = fval;
+      rank = reinterpret_cast<P *>(rank32);
       u32 *heads = reinterpret_cast<u32 *>(fkey);          // free key buffer
-      u32 *ppos = c->isa_tmp, *phead = ppos + ((NL + 3) & ~3ull);  // (skey is still being
-                                                           // read by the emission)
-      u32 *pws = scanws + scan_workspace_words(nwords) + 64;
-      // (a whole-table build makes the heads inside its first partition pass)
+      u32 *ppos = c->isa_tmp.as<u32>(), *phead = ppos + ((NL + 3) & ~3ull);  // (skey is still
+                                                           // being read by the emission)
       int wmax = RW_BITS;
       if (const char *e = getenv("GTAMD_RANK_WINDOW_BITS")) {
         const int v = atoi(e);
         if (v >= 2 && v <= RW_BITS) wmax = v;
       }
-      const bool heads_array = parts || bits_for(N - 1) <= wmax;
+      const u32 *spos = reinterpret_cast<const u32 *>(sa);
+      const bool heads_array = bits_for(N - 1) <= wmax;
       if (heads_array) {
-        k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(c->tiebits, carry, NL,
-                                                       (u32) index_offset, heads);
+        k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(tiebits2, carry, NL, 0u, heads);
         HIP_TRY(hipGetLastError());
       }
-      const GroupHeadValues headgen = {c->tiebits, carry, nwords, (u32) index_offset};
-      // one pass on the 8 leading position bits: windows of N/256 positions.
-      // (Measured at 3 Gbp: direct scatter 120 ms; 256 windows 61 ms + 23 ms
-      // for the pass; 4096 windows 53 ms + 38 ms; 4096 windows pinned to XCDs
-      // (each window written inside one L2) no better -- the gain is TLB
-      // reach, not L2 residency, so the single pass wins.  Two 8-bit passes
-      // (65 536 windows of 256 KB, each written by neighbouring workgroups):
-      // scatter 59 instead of 68 ms, but the second pass costs 17 -- the
-      // scatter is bound by the number of 4-byte store transactions, which
-      // only an LDS-staged window would remove.)
-      const int nbp = bits_for(N - 1);
-      if (!parts) {
-        // all positions are here: partition down to windows that fit the LDS
-        // (one or two passes), then k_rank_window.  GTAMD_RANK_WINDOW_BITS
-        // shrinks the window so that tests reach every shape at small N.
-        int pb = nbp > wmax ? nbp - wmax : 0;
-        if (pb > 16) pb = 16;
-        const int wb = nbp - pb;             // wmax, or wmax + 1 with two halves
-        if (wb > wmax + 1) {
-          gtamd_set_error("rank table: %d position bits do not fit two passes and a "
-                          "%d-bit window", nbp, wmax);
+      const GroupHeadValues headgen = {tiebits2, carry, nwords, 0u};
+      // Partition down to windows that fit the LDS (one or two passes), then
+      // k_rank_window.  (Measured at 3 Gbp: direct scatter 120 ms; one 8-bit
+      // pass + global scatter 84 ms; two passes + LDS window 30 ms.)
+      // GTAMD_RANK_WINDOW_BITS shrinks the window so that tests reach every
+      // shape at small N.
+      int pb = nb > wmax ? nb - wmax : 0;
+      if (pb > 16) pb = 16;
+      const int wb = nb - pb;             // wmax, or wmax + 1 with two halves
+      if (wb > wmax + 1) {
+        gtamd_set_error("rank table: %d position bits do not fit two passes and a "
+                        "%d-bit window", nb, wmax);
+        return -1;
+      }
+      const int split = wb > wmax ? 2 : 1;
+      const u32 *wpos = spos, *whead = heads;
+      if (pb > 8) {
+        const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;
+        u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
+        if (heads_array)
+          TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &w0,
+                                         1, pws, st, nullptr, nullptr));
+        else
+          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, st));
+        TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
+                                       nullptr, nullptr));
+        wpos = qpos; whead = qhead;
+      } else if (pb > 0) {
+        const int s0 = nb - pb;
+        if (heads_array)
+          TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &pb,
+                                         1, pws, st, nullptr, nullptr));
+        else
+          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, st));
+        wpos = ppos; whead = phead;
+      }
+      const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
+      const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
+      k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank32);
+      HIP_TRY(hipGetLastError());
+    }
+    std::vector<u64> qcounts(R), ucounts(R), zero(R, 0);
+    std::vector<u64> gathered((size_t) R * (2 * R + 1)), mine(2 * R + 1);
+    auto recv_of = [&](const std::vector<u64> &g, u32 which, std::vector<u64> &rc) -> u64 {
+      // counts this part receives: entry [s][which * R + part] of the gathered rows
+      u64 tot = 0;
+      for (u32 s = 0; s < R; s++) {
+        rc[s] = g[(size_t) s * (2 * R + 1) + which * R + c->part];
+        tot += rc[s];
+      }
+      return tot;
+    };
+    if (anyleft > 0 && dist) {
+      // first ranks to the owners of the positions, ICHUNK entries at a time
+      isa = WIDE ? reinterpret_cast<P *>(fkey) : reinterpret_cast<P *>(fval);
+      u64 chunks = div_up(NL, ISA_CHUNK);
+      if (R > 1) {
+        std::vector<u64> all(R);
+        TRY(comm_allgather(c, 0, &chunks, all.data(), 8));
+        for (u32 r = 0; r < R; r++) chunks = all[r] > chunks ? all[r] : chunks;
+      }
+      for (u64 ch = 0; ch < chunks; ch++) {
+        const u64 c0 = ch * ISA_CHUNK < NL ? ch * ISA_CHUNK : NL;
+        const u64 cm = NL - c0 < ISA_CHUNK ? NL - c0 : ISA_CHUNK;
+        InitialRanks<P> ir;
+        ir.sa = sa; ir.tiebits = tiebits2; ir.carry = carry; ir.c0 = c0;
+        ir.index_offset = index_offset; ir.tl = tl; ir.isa = isa; ir.soff = xoff; ir.srank = xrank;
+        TRY(dest_count(c, ir, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
+        HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
+                               hipMemcpyDeviceToHost, st));
+        TRY(dest_place(c, ir, cm, xdest_q, xbo_q));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<u64> sc(R), rc(R), mat((size_t) R * R);
+        for (u32 r = 0; r < R; r++) sc[r] = c->h_counts[r];
+        TRY(comm_allgather(c, 0, sc.data(), mat.data(), R * 8));
+        u64 nrecv = 0;
+        for (u32 s = 0; s < R; s++) { rc[s] = mat[(size_t) s * R + c->part]; nrecv += rc[s]; }
+        if (nrecv > Tn) {
+          gtamd_set_error("rank exchange: %llu ranks for a tile of %llu positions",
+                          (unsigned long long) nrecv, (unsigned long long) Tn);
           return -1;
         }
-        const int split = wb > wmax ? 2 : 1;
-        const u32 *wpos = sa32, *whead = heads;
-        if (pb > 8) {
-          const int s0 = nbp - pb, w0 = pb - 8, s1 = nbp - 8, w1 = 8;
-          u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
-          if (heads_array)
-            TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &w0, 1, pws, st,
-                                           nullptr, nullptr));
-          else
-            TRY(radix_pass_group_heads(sa32, headgen, ppos, phead, NL, s0, w0, pws, st));
-          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
-                                         nullptr, nullptr));
-          wpos = qpos; whead = qhead;
-        } else if (pb > 0) {
-          const int s0 = nbp - pb;
-          if (heads_array)
-            TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &s0, &pb, 1, pws, st,
-                                           nullptr, nullptr));
-          else
-            TRY(radix_pass_group_heads(sa32, headgen, ppos, phead, NL, s0, pb, pws, st));
-          wpos = ppos; whead = phead;
+        TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "rank offsets"));
+        TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "ranks"));
+        if (nrecv > 0) {
+          k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
+          HIP_TRY(hipGetLastError());
         }
-        const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
-        const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
-        k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank);
-        HIP_TRY(hipGetLastError());
-        TRY(launch_emission());   // beside the first (latency-bound) rounds
-      } else {
-        const int pshift = nbp > 8 ? nbp - 8 : 0, pwidth = nbp > 8 ? 8 : nbp;
-        TRY(radix_sort_pairs<u32, u32>(sa32, heads, ppos, phead, NL, &pshift,
-                                       &pwidth, 1, pws, st, nullptr, nullptr));
-        TRY(launch_emission());   // overlaps with the latency-bound scatter
-        k_rank_scatter<<<(u32) div_up(NL, 1024), 256, 0, st>>>(ppos, phead, NL, rank);
-        HIP_TRY(hipGetLastError());
       }
     }
+    TRY(launch_emission());   // (if the pair path has not started it)
     // ---- doubling rounds
-    const int nb = bits_for(N - 1);
-    int cs[16], cw[16], cnp = 0;
-    for (int part = 0; part < 2; part++)
-      for (int b = 0; b < nb; b += 8) {
-        cs[cnp] = part * 32 + b;
-        cw[cnp] = nb - b < 8 ? nb - b : 8;
-        cnp++;
-      }
+    int gs[8], gw[8];
+    const int gn = passes_for(nbl, gs, gw);
     u64 m = m0, h = (u64) K::SYMS;
+    // part builds: the queries of the coming round and the rank updates of the
+    // last one are bucketed by owner before the parts agree on the counts
+    RankQueries<P> rq;
+    RankUpdates<P> ru;
+    u64 m_upd = 0;            // slots of the last round (its updates are pending)
+    if (anyleft > 0 && dist) {
+      rq.upos = upos; rq.h = h; rq.n = n; rq.tl = tl; rq.isa = isa; rq.k2 = k2;
+      rq.sendq = xoff; rq.order = xorder;
+      TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
+      HIP_TRY(hipMemsetAsync(c->d_counts + DEST_MAXPARTS, 0, DEST_MAXPARTS * 4, st));
+    }
     for (;;) {
-      if (!parts && m == 0) break;
+      if (anyleft == 0) break;
+      if (!dist && m == 0) break;
       if (rounds >= 64) {
         gtamd_set_error("prefix doubling did not converge after 64 rounds");
         return -1;
       }
-      const u32 g = (u32) div_up(m, 256);
-      if (parts) {
-        // the query exchange doubles as the termination test: the gathered
-        // count matrix is all zero when no part has tied suffixes left
-        u64 all_queries = 0;
-        TRY(exchange_ranks<BITS>(c, upos, m, h, rank, k2, ckey_a, cval_a, ckey_b,
-                                 cval_b, sendq, rws2, &all_queries));
-        if (all_queries == 0) break;
+      if (dist) {
+        // one allgather per round: pending updates, queries, and who is left
+        HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 2 * DEST_MAXPARTS * 4,
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (u32 r = 0; r < R; r++) {
+          mine[r] = c->h_counts[r];                        // queries to r
+          mine[R + r] = c->h_counts[DEST_MAXPARTS + r];    // updates to r
+        }
+        mine[2 * R] = m;
+        TRY(comm_allgather(c, 0, mine.data(), gathered.data(), (2 * R + 1) * 8));
+        u64 left = 0, upd = 0;
+        for (u32 s = 0; s < R; s++) {
+          left += gathered[(size_t) s * (2 * R + 1) + 2 * R];
+          for (u32 r = 0; r < R; r++) upd += gathered[(size_t) s * (2 * R + 1) + R + r];
+        }
+        if (left == 0) break;   // (ranks nobody will ask for need not travel)
+        // the new ranks of the last round, before anybody looks them up
+        if (m_upd > 0) TRY(dest_place(c, ru, m_upd, xdest_u, xbo_u));
+        if (upd > 0 && R > 1) {
+          std::vector<u64> sc(R), rc(R);
+          for (u32 r = 0; r < R; r++) sc[r] = mine[R + r];
+          const u64 nrecv = recv_of(gathered, 1, rc);
+          if (nrecv > Tn) {
+            gtamd_set_error("rank exchange: %llu updates for a tile of %llu positions",
+                            (unsigned long long) nrecv, (unsigned long long) Tn);
+            return -1;
+          }
+          TRY(comm_alltoallv(c, xoff + 0, sc.data(), xrecv_off, rc.data(), 4, "update offsets"));
+          TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "updates"));
+          if (nrecv > 0) {
+            k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
+            HIP_TRY(hipGetLastError());
+          }
+        }
+        m_upd = 0;
+        // rank queries of this round: own tile answered in place, the others
+        // by the owners
+        rq.sendq = xoff; rq.order = xorder;
+        TRY(dest_place(c, rq, m, xdest_q, xbo_q));
+        if (R > 1) {
+          std::vector<u64> sc(R), rc(R);
+          u64 msent = 0;
+          for (u32 r = 0; r < R; r++) { sc[r] = mine[r]; msent += sc[r]; }
+          const u64 nrecv = recv_of(gathered, 0, rc);
+          if (nrecv > Tn) {
+            gtamd_set_error("rank exchange: %llu queries for a tile of %llu positions",
+                            (unsigned long long) nrecv, (unsigned long long) Tn);
+            return -1;
+          }
+          TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "queries"));
+          if (nrecv > 0) {
+            k_answer<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, nrecv, isa, xrecv_val);
+            HIP_TRY(hipGetLastError());
+          }
+          TRY(comm_alltoallv(c, xrecv_val, rc.data(), xans, sc.data(), sizeof(P), "answers"));
+          if (msent > 0) {
+            k_k2_scatter<P><<<(u32) div_up(msent, 256), 256, 0, st>>>(xans, xorder, msent, k2);
+            HIP_TRY(hipGetLastError());
+          }
+        }
       }
       rounds++;
-      if (getenv("GTAMD_DEBUG") != nullptr)
-        fprintf(stderr, "gtamd: round %u h=%llu tied=%llu\n", rounds, (unsigned long long) h,
-                (unsigned long long) m);
-      if (m == 0) { h *= 2; continue; }   // only serving other parts' queries
+      if (debug)
+        fprintf(stderr, "gtamd: part %u round %u h=%llu tied=%llu\n", c->part, rounds,
+                (unsigned long long) h, (unsigned long long) m);
+      if (m == 0) {   // only serving other parts' queries
+        h *= 2;
+        HIP_TRY(hipMemsetAsync(c->d_counts, 0, 2 * DEST_MAXPARTS * 4, st));
+        continue;
+      }
+      const u32 g = (u32) div_up(m, 256);
       const u32 ntiles = (u32) div_up(m, RT_TILE);
       u32 *tilecnt = koff, *tileoff = koff + ntiles + 16;   // (free until the apply step)
-      k_round_tile<<<ntiles, RT_THREADS, 0, st>>>(
-          uidx, upos, ugrp, k2, m, cvo, hv, flg, tilecnt, c->d_stats,
-          parts ? nullptr : rank, h, n);
+      k_round_tile<P><<<ntiles, RT_THREADS, 0, st>>>(
+          uidx, upos, ugrp, k2, m, cvo, hv, flg, tilecnt, dist ? nullptr : rank, h, n);
       HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, ntiles, false, scanws2, st));
       k_total<<<1, 1, 0, st>>>(tileoff, tilecnt, ntiles, c->d_stats);
@@ -2654,92 +3179,109 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
       TRY(fetch_stats(c));
       const u64 nf = c->h_stats->count;
       if (nf > 0) {
-        // groups crossing a tile border / larger than a tile: global radix sort
-        k_flag_gather<<<ntiles, RT_THREADS, 0, st>>>(flg, tileoff, ugrp, k2, upos, m,
-                                                     ckey_a, cval_a, fj);
+        // groups crossing a tile border / larger than a tile: ordered by
+        // (group, k2) through two stable sorts of an index
+        k_flag_gather<P><<<ntiles, RT_THREADS, 0, st>>>(flg, tileoff, ugrp, k2, upos, m, fk2,
+                                                       fk2s_a, fgrp, fpos, fj, perm_a);
         HIP_TRY(hipGetLastError());
-        TRY(radix_sort_pairs<u64, u32>(ckey_a, cval_a, ckey_b, cval_b, nf, cs, cw,
-                                  cnp, rws2, st, nullptr, nullptr));
-        const u64 *ck = (cnp & 1) ? ckey_b : ckey_a;
-        const u32 *cvs = (cnp & 1) ? cval_b : cval_a;
+        TRY(radix_sort_pairs<P, u32>(fk2s_a, perm_a, fk2s_b, perm_b, nf, ps, pw, pn, rws2, st,
+                                     nullptr, nullptr));
+        u32 *perm1 = (pn & 1) ? perm_b : perm_a, *permx = (pn & 1) ? perm_a : perm_b;
         const u32 gf = (u32) div_up(nf, 256);
-        k_flag_heads<<<gf, 256, 0, st>>>(ck, uidx, fj, nf, foff);
+        k_gather_u32<<<gf, 256, 0, st>>>(fgrp, perm1, nf, gk_a);
         HIP_TRY(hipGetLastError());
-        TRY(scan_u32(SCAN_MAX, foff, foff, nf, true, scanws2, st));
-        k_flag_scatter<<<gf, 256, 0, st>>>(cvs, foff, fj, nf, cvo, hv);
+        TRY(radix_sort_pairs<u32, u32>(gk_a, perm1, gk_b, permx, nf, gs, gw, gn, rws2, st,
+                                       nullptr, nullptr));
+        const u32 *perm2 = (gn & 1) ? permx : perm1;
+        k_flag_heads<P><<<gf, 256, 0, st>>>(perm2, fgrp, fk2, fpos, uidx, fj, nf, fhv, cvs);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_MAX, fhv, fhv, nf, true, scanws2, st));
+        k_flag_scatter<P><<<gf, 256, 0, st>>>(cvs, fhv, fj, nf, cvo, hv);
         HIP_TRY(hipGetLastError());
       }
-      const u32 *cv = cvo;
       // (koff doubles as the per-block survivor counts and their scan)
-      u32 *bcnt = koff, *boff = koff + g + 16;
-      k_round_apply<<<g, 256, 0, st>>>(cv, hv, uidx, ugrp, m, (u32) index_offset,
-                                       sa32, rank, keep, bcnt);
+      u32 *bcnt = koff, *boffs = koff + g + 16;
+      k_round_apply<P><<<g, 256, 0, st>>>(cvo, hv, uidx, ugrp, m, index_offset, sa,
+                                          dist ? nullptr : rank, keep, bcnt);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, bcnt, boff, g, false, scanws2, st));
-      k_round_compact<<<g, 256, 0, st>>>(keep, boff, bcnt, uidx, cv, hv, m, uidx2,
-                                         upos2, ugrp2, c->d_stats);
+      TRY(scan_u32(SCAN_SUM, bcnt, boffs, g, false, scanws2, st));
+      k_round_compact<P><<<g, 256, 0, st>>>(keep, boffs, bcnt, uidx, cvo, hv, m, uidx2,
+                                            upos2, ugrp2, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
+      const u64 m_old = m;
       m = c->h_stats->count;
+      h *= 2;
+      if (dist) {
+        // the new ranks of this round (slots of the old list) and the queries
+        // of the next (the compacted list): counted now, exchanged at the top
+        ru.cval = cvo; ru.gnew = hv; ru.ugrp = ugrp; ru.index_offset = index_offset;
+        ru.tl = tl; ru.isa = isa; ru.soff = xoff; ru.srank = xrank;
+        m_upd = m_old;
+        TRY(dest_count(c, ru, m_upd, xdest_u, xbc_u, xbo_u, scanws2, 1));
+        rq.upos = upos2; rq.h = h;
+        TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
+      }
       u32 *t;
       t = uidx; uidx = uidx2; uidx2 = t;
-      t = upos; upos = upos2; upos2 = t;
       t = ugrp; ugrp = ugrp2; ugrp2 = t;
-      h *= 2;
+      P *tp = upos; upos = upos2; upos2 = tp;
+      if (dist) ru.ugrp = ugrp2;   // (the old list's groups, after the swap)
     }
     HIP_TRY(hipEventRecord(c->ev[5], st));
     // ---- final entries of the tied suffixes (after the emission has
     // written its provisional values)
     TRY(launch_emission());
     HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
+    // 32-bit LCP values that do not fit the byte, by table index: in a buffer
+    // that has done its work (the rank table; the bucketing scratch)
+    u32 *lcpfull = nullptr;
+    if (want_lcp) {
+      if (!dist) lcpfull = fval;
+      else if (WIDE) lcpfull = fval;
+      else lcpfull = c->isa_tmp.as<u32>();
+    }
+    if (npairs > 0) {
+      k_pair_apply<BITS, P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(
+          c->text, pv_sorted, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset,
+          c->d_stats);
+      HIP_TRY(hipGetLastError());
+    }
     const u32 g0 = (u32) div_up(m0, 256);
     u32 *bcnt0 = koff, *boff0 = koff + g0 + 16;   // per-workgroup counts and their scan
-    u32 *lcpfull = rank;   // the rank table has done its work
     if (m0 > 0) {
       // .suf/.bwt of the tied entries: random accesses, on the second stream
       // (behind the emission there) while this stream sorts the LCP pairs
       HIP_TRY(hipEventRecord(c->ev_sorted, st));          // rounds are done
       HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
-      k_fix_basic<BITS><<<g0, 256, 0, c->st2>>>(
-          c->text, uidx0, m0, sa32, want_suf ? c->suf : nullptr,
-          want_bwt ? c->bwt : nullptr, c->d_stats, index_offset);
+      k_fix_basic<BITS, P><<<g0, 256, 0, c->st2>>>(c->text, uidx0, m0, sa, d_suf, d_bwt,
+                                                   c->d_stats, index_offset);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(c->ev_emitted, c->st2));
     }
     if (want_lcp && m0 > 0) {
       // entries tied with their predecessor, sorted by text position
-      k_tied_counts<<<g0, 256, 0, st>>>(uidx0, m0, c->tiebits, bcnt0);
+      k_tied_counts<<<g0, 256, 0, st>>>(uidx0, m0, tiebits2, bcnt0);
       HIP_TRY(hipGetLastError());
       TRY(scan_u32(SCAN_SUM, bcnt0, boff0, g0, false, scanws2, st));
       k_total<<<1, 1, 0, st>>>(boff0, bcnt0, g0, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 m1 = c->h_stats->count;
-      // (text position, slot) pairs, 32-bit keys
-      u32 *pkey_a = reinterpret_cast<u32 *>(ckey_a), *pkey_b = reinterpret_cast<u32 *>(ckey_b);
-      u32 *pval_b = uidx2;   // the round buffers are free now
-      k_lcp_pairs<<<g0, 256, 0, st>>>(boff0, c->tiebits, uidx0, sa32, m0, pkey_a, cval_a);
+      k_lcp_pairs<P><<<g0, 256, 0, st>>>(boff0, tiebits2, uidx0, sa, m0, lk_a, lv_a);
       HIP_TRY(hipGetLastError());
-      int ps[8], pw[8], pn = 0;
-      for (int b = 0; b < nb; b += 8) {
-        ps[pn] = b;
-        pw[pn] = nb - b < 8 ? nb - b : 8;
-        pn++;
-      }
-      TRY(radix_sort_pairs<u32, u32>(pkey_a, cval_a, pkey_b, pval_b, m1, ps, pw, pn,
-                                     rws2, st, nullptr, nullptr));
-      const u32 *pk = (pn & 1) ? pkey_b : pkey_a;
-      const u32 *pv = (pn & 1) ? pval_b : cval_a;
-      k_lcp_chunks<BITS><<<stride_grid(div_up(div_up(m1, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk, pv, m1, sa32, c->lcp, lcpfull, c->d_stats);
+      TRY(radix_sort_pairs<P, u32>(lk_a, lv_a, lk_b, lv_b, m1, ps, pw, pn, rws2, st,
+                                   nullptr, nullptr));
+      const P *pk = (pn & 1) ? lk_b : lk_a;
+      const u32 *pv = (pn & 1) ? lv_b : lv_a;
+      k_lcp_chunks<BITS, P><<<stride_grid(div_up(div_up(m1, LCP_CHUNK), 256)), 256, 0, st>>>(
+          c->text, pk, pv, m1, sa, d_lcp, lcpfull, c->d_stats);
       HIP_TRY(hipGetLastError());
-      k_large_counts<<<g0, 256, 0, st>>>(uidx0, c->lcp, m0, bcnt0);
-      HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, bcnt0, boff0, g0, false, scanws2, st));
-      k_total<<<1, 1, 0, st>>>(boff0, bcnt0, g0, c->d_stats);
-      HIP_TRY(hipGetLastError());
+    }
+    if (want_lcp) {
+      // .llv from the byte table and the side table
       TRY(fetch_stats(c));
-      const u64 pairs = c->h_stats->count;
+      const u64 pairs = c->h_stats->numlarge;
       if (pairs > c->llv_cap) {
         free_dev(c->llv);
         c->llv = nullptr;
@@ -2748,8 +3290,15 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
         c->llv_cap = pairs + pairs / 4 + 1024;
       }
       if (pairs > 0) {
-        k_llv_emit<<<g0, 256, 0, st>>>(uidx0, c->lcp, lcpfull, boff0, m0,
-                                       index_offset, c->llv);
+        const u32 gl = (u32) div_up(NL, LLV_TILE);
+        // (counts and their scan: the round buffers are free, but sized for the
+        // tied suffixes -- the per-word arrays of the radix workspace hold
+        // NL / 64 + 16 words each, more than the NL / 4096 needed here)
+        u32 *lc = cntw, *lo = offw;
+        k_large_counts<<<gl, 256, 0, st>>>(d_lcp, NL, lc);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_SUM, lc, lo, gl, false, scanws, st));
+        k_llv_emit<<<gl, 256, 0, st>>>(d_lcp, NL, lcpfull, lo, index_offset, c->llv);
         HIP_TRY(hipGetLastError());
       }
       c->llv_pairs = pairs;
@@ -2773,7 +3322,9 @@ template <int BITS> static int run_impl(gtamd_esa_ctx *c, u32 want) {
   c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum + c->h_stats->dsum : 0;
   c->stats.prefixlength = prefixlength;
   c->stats.refine_rounds = rounds;
-  c->stats.tied_suffixes = m0;
+  c->stats.tied_suffixes = m0 + 2 * npairs;
+  c->stats.pair_suffixes = 2 * npairs;
+  c->stats.device_bytes = c->alloc_bytes;
   float ms = 0;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); c->timing.total_ms = ms;
   HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->timing.keygen_ms = ms;
@@ -2799,7 +3350,21 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
   if (!c->have_text) { gtamd_set_error("no sequence set"); return -1; }
   if ((want & 15u) == 0) { gtamd_set_error("nothing requested"); return -1; }
   HIP_TRY(hipSetDevice(c->device));
-  return c->bits == 2 ? run_impl<2>(c, want) : run_impl<5>(c, want);
+  // 64-bit positions: whenever the sequence needs them; GTAMD_FORCE_WIDE=1
+  // takes that path (and the exchange machinery of a part build) at any size
+  const char *fw = getenv("GTAMD_FORCE_WIDE");
+  const bool force_wide = fw != nullptr && fw[0] == '1';
+  const bool wide = force_wide || c->N >= SINGLE_LIMIT;
+  const bool dist = c->numparts > 1 || wide;
+  if (c->numparts == 1 && c->N >= SINGLE_LIMIT) {
+    gtamd_set_error("sequence of %llu symbols exceeds the 32-bit index range of a "
+                    "single build: build it in parts (gtamd_esa_set_part)",
+                    (unsigned long long) c->n);
+    return -1;
+  }
+  if (c->bits == 2)
+    return wide ? run_impl<2, true>(c, want, dist) : run_impl<2, false>(c, want, dist);
+  return wide ? run_impl<5, true>(c, want, dist) : run_impl<5, false>(c, want, dist);
 }
 
 // ---------------------------------------------------------------------------
@@ -2831,9 +3396,9 @@ extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
                                               gtamd_table which) {
   if (c == nullptr || !c->ran) return nullptr;
   switch (which) {
-    case GTAMD_TAB_SUF: return (c->want & GTAMD_WANT_SUF) ? c->suf : nullptr;
-    case GTAMD_TAB_LCP: return (c->want & GTAMD_WANT_LCP) ? c->lcp : nullptr;
-    case GTAMD_TAB_BWT: return (c->want & GTAMD_WANT_BWT) ? c->bwt : nullptr;
+    case GTAMD_TAB_SUF: return (c->want & GTAMD_WANT_SUF) ? c->suf.p : nullptr;
+    case GTAMD_TAB_LCP: return (c->want & GTAMD_WANT_LCP) ? c->lcp.p : nullptr;
+    case GTAMD_TAB_BWT: return (c->want & GTAMD_WANT_BWT) ? c->bwt.p : nullptr;
     case GTAMD_TAB_LLV: return (c->want & GTAMD_WANT_LCP) ? c->llv : nullptr;
     case GTAMD_TAB_BCK: return (c->want & GTAMD_WANT_BCK) ? c->bck : nullptr;
   }

@@ -4,12 +4,16 @@ One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo"
 in the CPU tests).  The suffix array is cut into `world` lexicographic ranges
 of (almost) equal size -- the reference's `-parts` mechanism
 (src/match/sfx-partssuf.c:172-347) -- and rank r builds slice r of every table
-from the replicated packed sequence.  The only data-path exchange is the rank
-lookup of the prefix-doubling rounds: "what is the rank of suffix p+h" is asked
-of the part that owns that suffix (alltoallv of 4-byte queries, alltoallv of
-4-byte answers), plus a few 8/16-byte allgathers (slice border keys, round
-termination).  The engine calls back into `TorchComm` for these collectives;
-it never sees a torch type.
+from the replicated packed sequence.  Per-rank work falls with the number of
+ranks: a rank makes the sort keys of its 1/world tile of the text and sends
+the (key, position) pairs to the owners of their key ranges (alltoallv, 12 B
+per suffix); the rank table of the prefix-doubling rounds is cut by text
+position, so a round is an alltoallv of 4-byte queries to the tile owners, one
+of answers back, and one of the new ranks of refined suffixes; plus a few
+small allgathers (range cuts, counts, slice border keys, round termination).
+The engine calls back into `TorchComm` for these collectives; it never sees a
+torch type.  On the nccl backend the exchanges are enqueued on the engine's
+own HIP stream (no host synchronisation per exchange).
 """
 import ctypes
 
@@ -21,7 +25,8 @@ ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p, ctypes.c_uint32)
 ALLTOALLV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p,
-                                ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32)
+                                ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32,
+                                ctypes.c_void_p)
 
 
 class _DevMem:
@@ -98,8 +103,8 @@ class TorchComm:
         dist.all_gather(parts, mine.clone(), group=self.group)
         out.copy_(torch.cat(parts))
 
-    # device memory in, device memory out
-    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem):
+    # device memory in, device memory out; ordered on the engine's stream
+    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem, stream):
         try:
             sc = [int(sendcounts[r]) * elem for r in range(self.world)]
             rc = [int(recvcounts[r]) * elem for r in range(self.world)]
@@ -114,7 +119,9 @@ class TorchComm:
                     o.copy_(t)
             elif self.staged:
                 # device buffers, host transport (gloo): used to rehearse the
-                # multi-process path on a box with a single GPU
+                # multi-process path on a box with a single GPU.  The engine's
+                # stream is synchronised here, the data is back before return.
+                torch.cuda.ExternalStream(stream, device=self.device).synchronize()
                 t_in = _device_bytes(send, sum(sc), self.device).cpu()
                 ins = list(t_in.split(sc)) if sum(sc) else [torch.empty(0, dtype=torch.uint8) for _ in sc]
                 tmp = [torch.empty(n, dtype=torch.uint8) for n in rc]
@@ -123,12 +130,14 @@ class TorchComm:
                     _device_bytes(recv, sum(rc), self.device).copy_(torch.cat(tmp))
                 torch.cuda.synchronize(self.device)
             else:
+                # RCCL: enqueued behind the engine's kernels on the engine's own
+                # stream; the kernels the engine launches next wait for it there
                 t_in = _device_bytes(send, sum(sc), self.device)
                 t_out = _device_bytes(recv, sum(rc), self.device)
-                dist.all_to_all_single(t_out, t_in, output_split_sizes=rc,
-                                       input_split_sizes=sc, group=self.group)
-                torch.cuda.synchronize(self.device)
-            self.bytes_exchanged += sum(sc)
+                with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=self.device)):
+                    dist.all_to_all_single(t_out, t_in, output_split_sizes=rc,
+                                           input_split_sizes=sc, group=self.group)
+            self.bytes_exchanged += sum(sc) - sc[self.rank]
             self.calls += 1
             return 0
         except Exception as e:

@@ -127,6 +127,11 @@ class EsaEngine:
                 count))
         return out.reshape(-1, 2) if which == TAB_LLV else out
 
+    def set_readmode(self, readmode):
+        """GtReadmode of the sequence handed in next (0 forward, 1 reverse,
+        2 complement, 3 reverse complement; src/core/readmode.h)"""
+        check(self._lib.gtamd_esa_set_readmode(self._ctx, readmode))
+
     def set_prefixlength(self, k):
         """prefix length of .prj and of the bucket table; 0: the recommended one"""
         check(self._lib.gtamd_esa_set_prefixlength(self._ctx, k))
@@ -170,17 +175,17 @@ class Sfxiterator:
     delivers part by part), then the suffixes that start with a special in
     pages, `None` at the end (src/match/sfx-suffixer.c:2162-2198) -- and
     `longest()` is the index of suffix 0.  Arguments keep the reference's
-    names; `readmode` must be 0 (forward), `numofparts`/`maximumspace` only
-    set the page size of the special tail: the whole table is resident."""
+    names; `readmode` is the reference's GtReadmode (0 fwd, 1 rev, 2 cpl,
+    3 rcl), applied on the device while the sequence is packed;
+    `numofparts`/`maximumspace` only set the page size of the special tail:
+    the whole table is resident."""
 
     def __init__(self, encseq, readmode=0, prefixlength=0, numofparts=1,
                  maximumspace=0, numofchars=4, device=0):
-        if readmode != 0:
-            raise EsaError("readmode %d is not supported by the MI355X engine "
-                           "(only forward)" % readmode)
         enc = np.ascontiguousarray(encseq, dtype=np.uint8)
         self._eng = EsaEngine(max(int(enc.size), 1), numofchars, device)
         check(self._eng._lib.gtamd_esa_set_prefixlength(self._eng._ctx, prefixlength))
+        self._eng.set_readmode(readmode)
         self._eng.set_sequence(enc)
         self._eng.run(WANT_SUF)
         n1 = int(enc.size) + 1

@@ -70,6 +70,9 @@ typedef struct {
   uint32_t refine_rounds;              /* engine statistic: doubling rounds */
   uint64_t tied_suffixes;              /* engine statistic: suffixes that were
                                           not separated by the first sort */
+  uint64_t pair_suffixes;              /* ... of these, in tie groups of two
+                                          (settled by one text comparison) */
+  uint64_t device_bytes;               /* device memory the context holds */
 } gtamd_esa_stats;
 
 /* per-stage device time of the last run, measured with HIP events on the
@@ -100,21 +103,28 @@ uint32_t gtamd_recommended_prefixlength(uint32_t numofchars, uint64_t n);
 /* ---- context ---------------------------------------------------------- */
 /* Create an engine on HIP device `device` for sequences of up to max_n
    symbols over an alphabet of `numofchars` letters (4: 2-bit DNA path,
-   <= 31: 5-bit path).  Allocates the whole workspace once; NULL on failure. */
+   <= 28: 5-bit path).  The device workspace is allocated by the first run that
+   needs it (by the tables wanted and, in a part build, the slice size) and
+   kept for the following runs; NULL on failure. */
 gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
                                 uint32_t numofchars);
 void gtamd_esa_destroy(gtamd_esa_ctx *ctx);
 
-/* Restrict the build to the part `part` of `numparts` equal-width (by suffix
-   count) lexicographic ranges, the reference's -parts mechanism
-   (src/match/sfx-partssuf.c:172-347) used here to shard over GPUs.
-   Default 0 of 1.  Every part holds the whole sequence, builds the slice
-   [table_offset, table_offset + table_entries) of each table, and looks up
-   the ranks of other parts' suffixes through the callbacks of
-   gtamd_esa_set_comm during prefix doubling.  The statistics of a part cover
-   its slice: the caller adds lcptabsum / largelcpvalues, takes the max of
-   maxbranchdepth, and `longest` from the part whose slice holds suffix 0
-   (the others report 0). */
+/* Restrict the build to the part `part` of `numparts` (at most 128)
+   equal-width (by suffix count) lexicographic ranges, the reference's -parts
+   mechanism (src/match/sfx-partssuf.c:172-347) used here to shard over GPUs.
+   Default 0 of 1.  Every part holds the whole packed sequence and builds the
+   slice [table_offset, table_offset + table_entries) of each table.  The work
+   of a part falls with the number of parts: it makes the sort keys of ITS 1/R
+   tile of the text only and sends each (key, position) pair to the part that
+   owns the key range; the rank table of the prefix-doubling rounds is cut by
+   text position (part t holds the ranks of the suffixes starting in tile t),
+   so a round asks the tile owners for ranks and sends them the new ones -- all
+   through the callbacks of gtamd_esa_set_comm.  A part build addresses up to
+   2^40 positions (a single build: 2^32 - 4096); one slice must stay below 2^32
+   entries.  The statistics of a part cover its slice: the caller adds
+   lcptabsum / largelcpvalues, takes the max of maxbranchdepth, and `longest`
+   from the part whose slice holds suffix 0 (the others report 0). */
 int gtamd_esa_set_part(gtamd_esa_ctx *ctx, uint32_t part, uint32_t numparts);
 
 /* Collectives a part build needs; the caller supplies the transport (RCCL
@@ -122,16 +132,31 @@ int gtamd_esa_set_part(gtamd_esa_ctx *ctx, uint32_t part, uint32_t numparts);
    allgather: every part contributes `bytes` bytes of HOST memory, `recv`
    (host) receives numparts x bytes in part order.
    alltoallv: DEVICE buffers of `elem_bytes`-sized elements; the block for part
-   r has sendcounts[r] elements, blocks are laid out in part order on both
-   sides; recvcounts is known to the engine (it allgathers the count matrix). */
+   r has sendcounts[r] elements (the block for the caller itself included: it
+   is copied), blocks are laid out in part order on both sides; recvcounts is
+   known to the engine (it allgathers the count matrix).  `stream` is the
+   engine's hipStream_t: the exchange must come after the work already queued
+   on it, and work queued on it after the callback returns must see the
+   received data -- enqueue the exchange on that stream (RCCL), or synchronise
+   the stream, exchange, and return when the data has arrived.
+   If a part fails (out of memory ...) it says so in its next allgather and
+   gtamd_esa_run returns -1 on every part. */
 typedef int (*gtamd_allgather_fn)(void *user, const void *send, void *recv,
                                   uint32_t bytes);
 typedef int (*gtamd_alltoallv_fn)(void *user, const void *send,
                                   const uint64_t *sendcounts, void *recv,
                                   const uint64_t *recvcounts,
-                                  uint32_t elem_bytes);
+                                  uint32_t elem_bytes, void *stream);
 int gtamd_esa_set_comm(gtamd_esa_ctx *ctx, gtamd_allgather_fn allgather,
                        gtamd_alltoallv_fn alltoallv, void *user);
+
+/* Read mode of the sequence (the `readmode` argument of
+   gt_Sfxiterator_new_withadditionalvalues, src/match/sfx-suffixer.h:48-60;
+   GtReadmode of src/core/readmode.h: 0 forward, 1 reverse, 2 complement,
+   3 reverse complement; complementing is defined for DNA only).  Applied while
+   the next gtamd_esa_set_sequence_bytes packs the sequence: the tables are
+   those of the sequence read that way. */
+int gtamd_esa_set_readmode(gtamd_esa_ctx *ctx, int readmode);
 
 /* Prefix length to report in .prj and to mask averagelcp with (option -pl K of
    src/match/index_options.c:363; 0 = gt_recommendedprefixlength).  The device

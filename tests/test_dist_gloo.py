@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
         rc = comm.alltoallv_cb(None, send.ctypes.data,
                                sc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                recv.ctypes.data,
-                               rcnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4)
+                               rcnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4, None)
         assert rc == 0
         expect = np.concatenate([np.full(int(rcnt[s]), 100 * s + rank, dtype=np.uint32)
                                  for s in range(world)])
@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         rc = comm.alltoallv_cb(None, (recv + 7).ctypes.data,
                                rcnt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                back.ctypes.data,
-                               sc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4)
+                               sc.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4, None)
         assert rc == 0 and np.array_equal(back, send + 7)
         # --- empty blocks (a part without tied suffixes still answers queries)
         sc0 = np.zeros(world, dtype=np.uint64)
@@ -64,7 +64,7 @@ def _worker(rank, world, port, q):
         rc = comm.alltoallv_cb(None, send0.ctypes.data if rank == 0 else None,
                                sc0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                                recv0.ctypes.data if rank == world - 1 else None,
-                               rc0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4)
+                               rc0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), 4, None)
         assert rc == 0
         if rank == world - 1:
             assert recv0.tolist() == [5, 6, 7]

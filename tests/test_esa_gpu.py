@@ -167,8 +167,15 @@ def test_errors(gpu):
     with pytest.raises(esa.EsaError, match="no sequence set"):
         with esa.EsaEngine(100, 4) as eng:
             eng.run()
-    with pytest.raises(esa.EsaError, match="32-bit position"):
-        esa.EsaEngine(1 << 32, 4)
+    with pytest.raises(esa.EsaError, match="exceeds the position range"):
+        esa.EsaEngine(1 << 41, 4)
+    # beyond 2^32 positions only a part build can run (32-bit indices per slice)
+    with esa.EsaEngine(1 << 33, 4) as eng:
+        eng.set_sequence(np.zeros(10, dtype=np.uint8))
+        eng.run()
+    with pytest.raises(esa.EsaError, match="only defined for DNA"):
+        with esa.EsaEngine(100, 20) as eng:
+            eng.set_readmode(2)
 
 
 def test_sfxiterator_adapter(gpu):
@@ -191,8 +198,50 @@ def test_sfxiterator_adapter(gpu):
     assert _md5(np.concatenate(parts)) == e["tables"]["suf"]["md5"]
     assert sfi.longest() == 2529
     sfi.delete()
-    with pytest.raises(esa.EsaError, match="only forward"):
-        esa.Sfxiterator(enc, readmode=1)
+
+
+def _apply_readmode(enc, mode):
+    out = enc[::-1].copy() if mode & 1 else enc.copy()
+    if mode & 2:
+        out = np.where(out < 4, 3 - out, out).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_readmode_at_the_library_seam(gpu, mode):
+    """the `readmode` argument of gt_Sfxiterator_new_withadditionalvalues
+    (src/match/sfx-suffixer.h:48-60): reverse / complement applied on the device
+    while the sequence is packed; the tables are those of the transformed
+    sequence (tests/test_cli_gpu.py holds the reference's files for -dir)"""
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 31, 150001)
+    enc[:7] = 254          # the special prefix becomes a special suffix
+    ora = ou.esa(_apply_readmode(enc, mode), 4)
+    with esa.EsaEngine(enc.size, 4) as eng:
+        eng.set_readmode(mode)
+        eng.set_sequence(enc)
+        eng.run()
+        _assert_same_as_oracle(None, 4, eng.result(), ora)
+        eng.set_readmode(0)
+        eng.set_sequence(enc)
+        eng.run()
+        _assert_same_as_oracle(enc, 4, eng.result())
+    sfi = esa.Sfxiterator(enc, readmode=mode)
+    parts = []
+    while True:
+        r = sfi.next()
+        if r is None:
+            break
+        parts.append(r[0])
+    assert np.array_equal(np.concatenate(parts), ora["suf"])
+    assert sfi.longest() == ora["stats"]["longest"]
+    sfi.delete()
+    if mode == 1:   # protein: reverse is defined, complement is not
+        p = synth.generate(synth.MODEL_PROTEIN, 8, 30000)
+        with esa.EsaEngine(p.size, 20) as eng:
+            eng.set_readmode(1)
+            eng.set_sequence(p)
+            eng.run()
+            _assert_same_as_oracle(None, 20, eng.result(), ou.esa(p[::-1].copy(), 20))
 
 
 def test_packed_device_input(gpu):
@@ -266,6 +315,7 @@ def test_rank_table_window_shapes(gpu, monkeypatch, wbits, n):
     passes, split windows) are reached at test sizes; repeats make sure the
     doubling rounds really use the table"""
     monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", str(wbits))
+    monkeypatch.setenv("GTAMD_NO_PAIRS", "1")   # (pairs would not need the table)
     enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 77 + wbits, n)
     if n < 200_000:     # too short for the model's repeats: a tandem repeat instead
         enc = np.resize(synth.generate(synth.MODEL_UNIFORM_DNA, 5, 700), n).astype(np.uint8)
@@ -318,5 +368,87 @@ def test_keygen_first_pass_special_heavy(gpu, kind):
     else:
         enc[21::22] = 255
         enc[-1] = 0
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+# ---------------------------------------------------------------------------
+# the pair path (tie groups of two settled by one text comparison) and the
+# 64-bit position path (GTAMD_FORCE_WIDE=1: the kernels a part build of a
+# sequence with n >= 2^32 runs, and the exchange machinery with one part)
+# ---------------------------------------------------------------------------
+def _pair_cases():
+    rng = np.random.default_rng(19)
+    a = rng.integers(0, 4, 6000, dtype=np.uint8)
+    b = a.copy()
+    b[::97] = (b[::97] + 1) & 3                     # mutated copy: pairs of all depths
+    yield "copy_with_mutations", np.concatenate([a, [255], b]).astype(np.uint8)
+    yield "exact_copy_then_end", np.concatenate([a, [1], a]).astype(np.uint8)
+    yield "copy_before_wildcard", np.concatenate([a, [254], a, [254], [2] * 30]).astype(np.uint8)
+    yield "three_copies", np.concatenate([a, [255], a, [255], a]).astype(np.uint8)   # no pairs
+    c = np.concatenate([a[:3000], a[:3000][::-1]])
+    yield "pairs_next_to_triples", np.concatenate([c, [255], c[:4000], [255], c[:1500]]).astype(np.uint8)
+    yield "tandem", np.tile(a[:300], 9).astype(np.uint8)
+    yield "pair_at_the_very_end", np.concatenate([a[:100], a[:40], a[60:100]]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name,enc", list(_pair_cases()), ids=[c[0] for c in _pair_cases()])
+@pytest.mark.parametrize("pairs", ["on", "off"])
+def test_pair_path(gpu, monkeypatch, name, enc, pairs):
+    """with and without the pair path (GTAMD_NO_PAIRS=1: everything through
+    prefix doubling) the tables are the oracle's"""
+    if pairs == "off":
+        monkeypatch.setenv("GTAMD_NO_PAIRS", "1")
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+    if pairs == "off":
+        assert res.stats["pair_suffixes"] == 0
+    elif name == "three_copies":
+        assert res.stats["pair_suffixes"] < 100
+    elif name != "tandem":
+        assert res.stats["pair_suffixes"] > 0
+
+
+def test_pair_path_large(gpu):
+    """2 Mbp of the human-like model: most tied suffixes are pairs"""
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 12, 2_000_000)
+    res = esa.suffixerator_tables(enc, 4)
+    assert res.stats["pair_suffixes"] > res.stats["tied_suffixes"] // 2
+    rc, where = ou.check_suffix_array(enc, res.suf)
+    assert rc == 0, (rc, where)
+    t = ou.tables_given_sa(enc, res.suf)
+    assert np.array_equal(res.lcp, t["lcp"])
+    assert np.array_equal(res.llv, t["llv"])
+    assert np.array_equal(res.bwt, t["bwt"])
+
+
+@pytest.mark.parametrize("name", ["Atinsert.fna", "Duplicate.fna", "RandomN.fna", "TTTN.fna",
+                                  "sw100K1.fsa"])
+def test_wide_positions_reference_fixtures(gpu, monkeypatch, name):
+    monkeypatch.setenv("GTAMD_FORCE_WIDE", "1")
+    e = GOLDEN[name]
+    protein = e["alphabet"] == "protein"
+    enc = ou.encode_fasta(ou.fixture_path(name), protein)
+    res = esa.suffixerator_tables(enc, 20 if protein else 4)
+    for tab in ("suf", "lcp", "llv", "bwt"):
+        assert _md5(getattr(res, tab)) == e["tables"][tab]["md5"], tab
+
+
+@pytest.mark.parametrize("model,sigma,n,seed", [
+    (synth.MODEL_UNIFORM_DNA, 4, 300000, 21),
+    (synth.MODEL_HUMANLIKE_DNA, 4, 600000, 3),
+    (synth.MODEL_PROTEIN, 20, 200000, 5),
+])
+def test_wide_positions_synthetic(gpu, monkeypatch, model, sigma, n, seed):
+    monkeypatch.setenv("GTAMD_FORCE_WIDE", "1")
+    enc = synth.generate(model, seed, n)
+    res = esa.suffixerator_tables(enc, sigma)
+    _assert_same_as_oracle(enc, sigma, res)
+
+
+@pytest.mark.parametrize("name,enc", list(_cases()) + list(_pair_cases()),
+                         ids=[c[0] for c in _cases()] + [c[0] for c in _pair_cases()])
+def test_wide_positions_edge_cases(gpu, monkeypatch, name, enc):
+    monkeypatch.setenv("GTAMD_FORCE_WIDE", "1")
     res = esa.suffixerator_tables(enc, 4)
     _assert_same_as_oracle(enc, 4, res)

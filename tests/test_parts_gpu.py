@@ -1,19 +1,18 @@
-"""The sharded build (lexicographic range parts + distributed rank lookups):
-R engine contexts on one device must produce, slice by slice, exactly the
-tables of the single build."""
+"""The sharded build (lexicographic range parts; every part keys its own text
+tile and sends the pairs to the range owners; rank table cut by text position,
+queried and updated through alltoallv): R engine contexts on one device must
+produce, slice by slice, exactly the tables of the single build."""
 import numpy as np
 import pytest
 
 import oracle_util as ou
 from genometools_amd import synth
-from thread_comm import build_in_parts
+from thread_comm import build_in_parts, build_sequences_in_parts
 
 pytestmark = pytest.mark.gpu
 
 
-def _check(enc, sigma, parts):
-    tabs, stats, per_part = build_in_parts(enc, sigma, parts)
-    ora = ou.esa(enc, sigma)
+def _compare(tabs, stats, ora):
     assert np.array_equal(tabs["suf"], ora["suf"]), "suf"
     assert np.array_equal(tabs["bwt"], ora["bwt"]), "bwt"
     assert np.array_equal(tabs["lcp"], ora["lcp"]), "lcp"
@@ -23,6 +22,11 @@ def _check(enc, sigma, parts):
     assert stats["largelcpvalues"] == st["largelcpvalues"]
     assert stats["maxbranchdepth"] == st["maxbranchdepth"]
     assert stats["lcptabsum"] == int(st["lcptabsum"])
+
+
+def _check(enc, sigma, parts):
+    tabs, stats, per_part = build_in_parts(enc, sigma, parts)
+    _compare(tabs, stats, ou.esa(enc, sigma))
     return per_part
 
 
@@ -51,3 +55,45 @@ def test_degenerate_inputs_in_parts(gpu):
     for enc in cases:
         _check(enc, 4, 4)
         _check(enc, 4, 8)
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_wide_positions_in_parts(gpu, monkeypatch, parts):
+    """the 64-bit position / rank kernels of a build with n >= 2^32, forced at
+    oracle sizes (GTAMD_FORCE_WIDE=1)"""
+    monkeypatch.setenv("GTAMD_FORCE_WIDE", "1")
+    _check(synth.generate(synth.MODEL_HUMANLIKE_DNA, 5, 400000), 4, parts)
+    _check(synth.generate(synth.MODEL_PROTEIN, 7, 150000), 20, parts)
+    _check(np.zeros(3000, dtype=np.uint8), 4, parts)
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 4, 3000, dtype=np.uint8)
+    _check(np.concatenate([a, [255], a, [254], a]).astype(np.uint8), 4, parts)
+
+
+def test_part_contexts_are_reusable(gpu):
+    """a short sequence, a longer one and the short one again through the same
+    part contexts: every per-run buffer follows the run's own sizes"""
+    encs = [synth.generate(synth.MODEL_HUMANLIKE_DNA, 11, 70000),
+            synth.generate(synth.MODEL_HUMANLIKE_DNA, 12, 500000),
+            synth.generate(synth.MODEL_UNIFORM_DNA, 13, 1000),
+            synth.generate(synth.MODEL_HUMANLIKE_DNA, 11, 70000)]
+    for enc, (tabs, stats, _) in zip(encs, build_sequences_in_parts(encs, 4, 3)):
+        _compare(tabs, stats, ou.esa(enc, 4))
+
+
+def test_part_work_is_a_share_of_the_whole(gpu):
+    """a part keys its own text tile only: its slice, and the device memory it
+    holds, are about 1/R of the single build's"""
+    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 4, 4_000_000)
+    from genometools_amd import esa
+    whole = esa.suffixerator_tables(enc, 4)
+    tabs, stats, per_part = build_in_parts(enc, 4, 4)
+    assert np.array_equal(tabs["suf"], whole.suf)
+    for st in per_part:
+        assert st["device_bytes"] < 0.4 * whole.stats["device_bytes"]
+
+
+def test_many_parts(gpu):
+    """more parts than the ballot loops unroll for; parts with empty slices"""
+    _check(synth.generate(synth.MODEL_HUMANLIKE_DNA, 9, 120000), 4, 16)
+    _check(np.tile(np.array([0, 1, 2, 3, 3], dtype=np.uint8), 400), 4, 6)

@@ -30,14 +30,17 @@ class _View:
             print("thread allgather failed", repr(e), flush=True)
             return -1
 
-    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem):
+    def _alltoallv(self, user, send, sendcounts, recv, recvcounts, elem, stream):
         try:
             sh = self.shared
             sc = [int(sendcounts[r]) * elem for r in range(self.world)]
             rc = [int(recvcounts[r]) * elem for r in range(self.world)]
+            dev = torch.device("cuda", sh.device)
+            # everything the engine has queued on its stream must be done before
+            # another thread copies out of this part's send buffer
+            torch.cuda.ExternalStream(stream, device=dev).synchronize()
             sh.slots[self.rank] = (send, sc)
             sh.barrier.wait()
-            dev = torch.device("cuda", sh.device)
             out_off = 0
             for src in range(self.world):
                 sptr, ssc = sh.slots[src]
@@ -50,7 +53,7 @@ class _View:
                     d_t.copy_(s_t)
                 out_off += nb
             torch.cuda.synchronize(dev)
-            self.bytes_exchanged += sum(sc)
+            self.bytes_exchanged += sum(sc) - sc[self.rank]
             sh.barrier.wait()
             return 0
         except Exception as e:
@@ -69,21 +72,61 @@ class ThreadComm:
         return _View(self, rank)
 
 
+def _assemble(results, n):
+    out = {"suf": [], "lcp": [], "bwt": [], "llv": []}
+    stats = {"lcptabsum": 0, "largelcpvalues": 0, "longest": 0, "maxbranchdepth": 0,
+             "tied_suffixes": 0, "pair_suffixes": 0, "refine_rounds": 0}
+    expect = 0
+    for off, res in results:
+        assert off == expect, "slices must tile the table"
+        for tab in (res.suf, res.bwt, res.lcp):
+            if tab is not None:
+                expect += len(tab)
+                break
+        for k in out:
+            v = getattr(res, k)
+            if v is not None:
+                out[k].append(v)
+        for k in ("lcptabsum", "largelcpvalues", "longest", "tied_suffixes", "pair_suffixes"):
+            stats[k] += res.stats[k]
+        for k in ("maxbranchdepth", "refine_rounds"):
+            stats[k] = max(stats[k], res.stats[k])
+        stats["prefixlength"] = res.stats["prefixlength"]
+    assert expect == n + 1
+    tabs = {k: (np.concatenate(v) if v else None) for k, v in out.items()}
+    return tabs, stats
+
+
 def build_in_parts(enc, sigma, parts, want=7, device=0, timing=False):
     """run `parts` engines concurrently; return the assembled tables and the
     combined statistics"""
+    out = build_sequences_in_parts([enc], sigma, parts, want, device)
+    tabs, stats, results = out[0]
+    if timing:
+        return tabs, stats, [(r[1].stats, r[1].timing) for r in results]
+    return tabs, stats, [r[1].stats for r in results]
+
+
+def build_sequences_in_parts(encs, sigma, parts, want=7, device=0):
+    """the sequences of `encs`, one after the other, through the SAME `parts`
+    engine contexts (one thread per part); per sequence: assembled tables,
+    combined statistics, per-part (offset, result)"""
     from genometools_amd import esa
-    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    encs = [np.ascontiguousarray(e, dtype=np.uint8) for e in encs]
     shared = ThreadComm(parts, device)
-    results, errors = [None] * parts, []
+    results = [[None] * parts for _ in encs]
+    errors = []
+    cap = max(max(e.size for e in encs), 1)
 
     def worker(r):
         try:
-            with esa.EsaEngine(max(enc.size, 1), sigma, device) as eng:
-                eng.set_sequence(enc)
-                eng.set_part(r, parts, shared.view(r))
-                eng.run(want)
-                results[r] = (eng.table_offset(), eng.result())
+            with esa.EsaEngine(cap, sigma, device) as eng:
+                view = shared.view(r)
+                for k, enc in enumerate(encs):
+                    eng.set_sequence(enc)
+                    eng.set_part(r, parts, view)
+                    eng.run(want)
+                    results[k][r] = (eng.table_offset(), eng.result())
         except Exception as e:   # noqa: BLE001
             errors.append((r, repr(e)))
             shared.barrier.abort()
@@ -94,24 +137,8 @@ def build_in_parts(enc, sigma, parts, want=7, device=0, timing=False):
     for t in threads:
         t.join()
     assert not errors, errors
-    out = {"suf": [], "lcp": [], "bwt": [], "llv": []}
-    stats = {"lcptabsum": 0, "largelcpvalues": 0, "longest": 0, "maxbranchdepth": 0,
-             "tied_suffixes": 0, "refine_rounds": 0}
-    expect = 0
-    for off, res in results:
-        assert off == expect, "slices must tile the table"
-        expect += len(res.suf) if res.suf is not None else len(res.bwt)
-        for k in out:
-            v = getattr(res, k)
-            if v is not None:
-                out[k].append(v)
-        for k in ("lcptabsum", "largelcpvalues", "longest", "tied_suffixes"):
-            stats[k] += res.stats[k]
-        for k in ("maxbranchdepth", "refine_rounds"):
-            stats[k] = max(stats[k], res.stats[k])
-        stats["prefixlength"] = res.stats["prefixlength"]
-    assert expect == enc.size + 1
-    tabs = {k: (np.concatenate(v) if v else None) for k, v in out.items()}
-    if timing:
-        return tabs, stats, [(r[1].stats, r[1].timing) for r in results]
-    return tabs, stats, [r[1].stats for r in results]
+    out = []
+    for enc, res in zip(encs, results):
+        tabs, stats = _assemble(res, enc.size)
+        out.append((tabs, stats, res))
+    return out

@@ -1088,49 +1088,35 @@ __device__ __forceinline__ u32 group_head(const u64 *tiebits, const u32 *carry,
   return z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carry[w];
 }
 
-// one wave per 64-entry word, one lane per entry: neighbouring lanes write
-// neighbouring slots of the unresolved list
-constexpr int UE_WORDS_PER_WAVE = 16;
+// one thread per 64-entry word of the bitmap (few words have an unresolved
+// entry at all: a lane per entry left most lanes idle -- 4.6 ms for 50 M
+// entries of 3 G); the threads of a wave write neighbouring stretches of the list
 template <typename P>
 __global__ __launch_bounds__(256) void k_unres_emit(
     const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
     const u32 *__restrict__ carry, const P *__restrict__ sa,
     u32 *__restrict__ uidx0, u32 *__restrict__ uidx, P *__restrict__ upos,
     u32 *__restrict__ ugrp) {
-  const int lane = threadIdx.x & 63;
-  const u64 wave = ((u64) blockIdx.x * 256 + threadIdx.x) >> 6;
-  const u64 lt = (1ull << lane) - 1ull;
-  // lanes 0..16 fetch the wave's words (and the one behind them), offsets and
-  // carries in one go; the walk below takes them from registers, so that its
-  // only memory traffic is the list itself
-  const u64 w0 = wave * UE_WORDS_PER_WAVE;
-  u64 my_t = 0;
-  u32 my_off = 0, my_carry = 0;
-  if (lane <= UE_WORDS_PER_WAVE && w0 + lane < nwords) {
-    my_t = tiebits[w0 + lane];
-    if (lane < UE_WORDS_PER_WAVE) {
-      my_off = off[w0 + lane];
-      my_carry = carry[w0 + lane];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < UE_WORDS_PER_WAVE; k++) {
-    const u64 w = w0 + k;
-    if (w >= nwords) return;
-    const u64 t = __shfl(my_t, k, 64);
-    const u64 nx = __shfl(my_t, k + 1, 64);    // 0 behind the last word
-    const u32 offw = __shfl(my_off, k, 64), carryw = __shfl(my_carry, k, 64);
-    const u64 u = t | (t >> 1) | (nx << 63);
-    if (!((u >> lane) & 1ull)) continue;
-    const u32 j = offw + (u32) __popcll(u & lt);
-    const u64 i = w * 64 + lane;
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  u64 u = t | (t >> 1) | (nx << 63);
+  if (u == 0) return;
+  u32 j = off[w];
+  const u32 carryw = carry[w];
+  while (u) {
+    const int b = __ffsll((unsigned long long) u) - 1;
+    u &= u - 1;
+    const u64 i = w * 64 + b;
     // head of i's group: highest "not tied" entry at or below i
-    const u64 below = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const u64 below = b == 63 ? ~0ull : ((2ull << b) - 1ull);
     const u64 z = ~t & below;
     uidx0[j] = (u32) i;
     uidx[j] = (u32) i;
     upos[j] = sa[i];
     ugrp[j] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : carryw;
+    j++;
   }
 }
 
@@ -1253,34 +1239,28 @@ __global__ __launch_bounds__(256) void k_pair_words(
   tiebits2[w] = t & ~((ph << 1) | prevhead);
 }
 
-// (smaller position, index of the pair's first entry), one lane per entry
+// (smaller position, index of the pair's first entry | ordinal of the pair <<
+// 32), and the index again by ordinal; one thread per bitmap word
 template <typename P>
 __global__ __launch_bounds__(256) void k_pair_emit(
     const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
-    const P *__restrict__ sa, P *__restrict__ pkey, u32 *__restrict__ pval) {
-  const int lane = threadIdx.x & 63;
-  const u64 wave = ((u64) blockIdx.x * 256 + threadIdx.x) >> 6;
-  const u64 lt = (1ull << lane) - 1ull;
-  const u64 w0 = wave * UE_WORDS_PER_WAVE;
-  u64 my_t = 0;
-  u32 my_off = 0;
-  if (lane <= UE_WORDS_PER_WAVE && w0 + lane < nwords) {
-    my_t = tiebits[w0 + lane];
-    if (lane < UE_WORDS_PER_WAVE) my_off = off[w0 + lane];
-  }
-#pragma unroll
-  for (int k = 0; k < UE_WORDS_PER_WAVE; k++) {
-    const u64 w = w0 + k;
-    if (w >= nwords) return;
-    const u64 t = __shfl(my_t, k, 64);
-    const u64 nx = __shfl(my_t, k + 1, 64);
-    const u32 offw = __shfl(my_off, k, 64);
-    const u64 ph = pair_heads(t, nx);
-    if (!((ph >> lane) & 1ull)) continue;
-    const u32 j = offw + (u32) __popcll(ph & lt);
-    const u64 i = w * 64 + lane;
+    const P *__restrict__ sa, P *__restrict__ pkey, u64 *__restrict__ pval,
+    u32 *__restrict__ pidx) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  u64 ph = pair_heads(t, nx);
+  if (ph == 0) return;
+  u32 j = off[w];
+  while (ph) {
+    const int b = __ffsll((unsigned long long) ph) - 1;
+    ph &= ph - 1;
+    const u64 i = w * 64 + b;
     pkey[j] = sa[i];    // the stable sort left equal keys in position order
-    pval[j] = (u32) i;
+    pval[j] = i | ((u64) j << 32);
+    pidx[j] = (u32) i;
+    j++;
   }
 }
 
@@ -1289,10 +1269,12 @@ constexpr u32 PAIR_SWAP = 1u << 31;
 
 // order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
 // per thread; a pair in the wrong order is swapped in the suffix array here,
-// the tables get their entries from k_pair_apply
+// the tables get their entries from k_pair_apply (which walks the pairs in
+// TABLE order -- in text order its five accesses per pair were five random
+// lines: 18 ms for 170 M pairs)
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
-    Text t, const P *__restrict__ pkey, const u32 *__restrict__ pval, u64 np,
+    Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 np,
     P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
@@ -1307,7 +1289,8 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
       const u64 s = c * LCP_CHUNK + e;
       if (s >= np) break;
       const u64 a = pkey[s];
-      const u64 i = pval[s];
+      const u64 iv = pval[s];
+      const u64 i = iv & 0xFFFFFFFFull, j = iv >> 32;
       const u64 b = sa[i + 1];
       u64 from = (u64) Key<BITS>::SYMS;
       if (e > 0 && l > from + (a - preva)) from = l - (a - preva);
@@ -1320,7 +1303,7 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
                                         : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
       if (!a_first) { sa[i] = (P) b; sa[i + 1] = (P) a; }
       const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
-      res[s] = lv | (a_first ? 0u : PAIR_SWAP);
+      res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: k_pair_apply walks the table
       sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
       nlarge += lv >= GTAMD_LCPOVERFLOW;
       mx = lv > mx ? lv : mx;
@@ -1347,17 +1330,19 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
   }
 }
 
-// table entries of the pairs (after the emission of the other entries): the
-// LCP of the second entry; .suf and .bwt of both when they changed places
-template <int BITS, typename P>
+// table entries of the pairs (after the emission of the other entries), pair by
+// pair in table order: the LCP of the second entry; .suf and .bwt of both
+// change places with the suffixes (the emission wrote the BWT symbols of the
+// keys, in key order)
+template <typename P>
 __global__ __launch_bounds__(256) void k_pair_apply(
-    Text t, const u32 *__restrict__ pval, const u32 *__restrict__ res, u64 np,
+    const u32 *__restrict__ pidx, const u32 *__restrict__ res, u64 np,
     const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
     u8 *__restrict__ bwt, u32 *__restrict__ lcpfull, u64 index_offset, Stats *stats) {
-  const u64 s = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (s >= np) return;
-  const u64 i = pval[s];
-  const u32 r = res[s], lv = r & ~PAIR_SWAP;
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= np) return;
+  const u64 i = pidx[j];
+  const u32 r = res[j], lv = r & ~PAIR_SWAP;
   if (lcp != nullptr) {
     lcp[i + 1] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
     if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + 1] = lv;
@@ -1368,8 +1353,9 @@ __global__ __launch_bounds__(256) void k_pair_apply(
   if (r & PAIR_SWAP) {
     if (suf != nullptr) { suf[i] = x; suf[i + 1] = y; }
     if (bwt != nullptr) {
-      bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, x));
-      bwt[i + 1] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, y));
+      const u8 b0 = bwt[i], b1 = bwt[i + 1];
+      bwt[i] = b1;
+      bwt[i + 1] = b0;
     }
   }
 }
@@ -2803,7 +2789,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           u32 *uidx0 = a.take<u32>(mp), *uidx = a.take<u32>(mp), *ugrp = a.take<u32>(mp);
           P *upos = a.take<P>(mp);
           if (m0 > 0) {
-            k_unres_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
+            k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
                 tiebits, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
             HIP_TRY(hipGetLastError());
           }
@@ -2837,7 +2823,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     // ---- pairs leave the bitmap; what is left goes through prefix doubling
     TRY(ensure_buf(c, c->tiebits2, (nwords + 2) * 8, "the tie bitmap"));
     u64 *tiebits2 = c->tiebits2.as<u64>();
-    const bool no_pairs = getenv("GTAMD_NO_PAIRS") != nullptr;   // A/B switch
+    const char *np_env = getenv("GTAMD_NO_PAIRS");                // A/B switch
+    const bool no_pairs = np_env != nullptr && np_env[0] == '1';
     if (NL > 0) {
       if (no_pairs) {
         HIP_TRY(hipMemcpyAsync(tiebits2, tiebits, nwords * 8, hipMemcpyDeviceToDevice, st));
@@ -2870,7 +2857,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     P *pk_a = nullptr, *pk_b = nullptr, *upos = nullptr, *upos2 = nullptr, *cvo = nullptr,
       *k2 = nullptr, *fk2 = nullptr, *fk2s_a = nullptr, *fk2s_b = nullptr, *fpos = nullptr,
       *cvs = nullptr, *lk_a = nullptr, *lk_b = nullptr, *xrank = nullptr, *xans = nullptr;
-    u32 *pv_a = nullptr, *pv_b = nullptr, *pres = nullptr, *prws = nullptr, *uidx0 = nullptr,
+    u64 *pv_a = nullptr, *pv_b = nullptr;
+    u32 *pidx = nullptr, *pres = nullptr, *prws = nullptr, *uidx0 = nullptr,
         *uidx = nullptr, *ugrp = nullptr, *uidx2 = nullptr, *ugrp2 = nullptr, *hv = nullptr,
         *koff = nullptr, *fgrp = nullptr, *fj = nullptr, *perm_a = nullptr, *perm_b = nullptr,
         *gk_a = nullptr, *gk_b = nullptr, *fhv = nullptr, *lv_a = nullptr, *lv_b = nullptr,
@@ -2880,8 +2868,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u8 *flg = nullptr, *xdest_q = nullptr, *xdest_u = nullptr;
     auto layout = [&](Bump &a) {
       pk_a = a.take<P>(pp); pk_b = a.take<P>(pp);
-      pv_a = a.take<u32>(pp); pv_b = a.take<u32>(pp);
-      pres = a.take<u32>(pp);
+      pv_a = a.take<u64>(pp); pv_b = a.take<u64>(pp);
+      pidx = a.take<u32>(pp); pres = a.take<u32>(pp);
       prws = a.take<u32>(radix_workspace_words(npairs));
       uidx0 = a.take<u32>(mp); uidx = a.take<u32>(mp); ugrp = a.take<u32>(mp);
       uidx2 = a.take<u32>(mp); ugrp2 = a.take<u32>(mp);
@@ -2940,15 +2928,14 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     int ps[8], pw[8];
     const int pn = passes_for(nb, ps, pw);
     // ---- the pairs: sorted by text position, compared, swapped
-    const u32 *pv_sorted = pv_a;
     if (npairs > 0) {
-      k_pair_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
-          tiebits, nwords, poff, sa, pk_a, pv_a);
+      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
+                                                               pv_a, pidx);
       HIP_TRY(hipGetLastError());
-      TRY(radix_sort_pairs<P, u32>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
+      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
                                    nullptr, nullptr));
       const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
-      pv_sorted = (pn & 1) ? pv_b : pv_a;
+      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
       TRY(launch_emission());   // bandwidth-bound, beside the comparisons
       k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
           c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
@@ -2956,7 +2943,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     }
     // ---- unresolved list of what is left
     if (m0 > 0) {
-      k_unres_emit<P><<<(u32) div_up(nwords, 4 * UE_WORDS_PER_WAVE), 256, 0, st>>>(
+      k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
           tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
       HIP_TRY(hipGetLastError());
     }
@@ -3242,9 +3229,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       else lcpfull = c->isa_tmp.as<u32>();
     }
     if (npairs > 0) {
-      k_pair_apply<BITS, P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(
-          c->text, pv_sorted, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset,
-          c->d_stats);
+      k_pair_apply<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(
+          pidx, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
       HIP_TRY(hipGetLastError());
     }
     const u32 g0 = (u32) div_up(m0, 256);

@@ -929,3 +929,11 @@ template int radix_sort_pairs<u32, u32>(u32 *, u32 *, u32 *, u32 *, u64,
                                         const int *, const int *, int, u32 *,
                                         hipStream_t, hipEvent_t *, int *, u8 *,
                                         u8 *);
+template int radix_sort_pairs<u32, u64>(u32 *, u64 *, u32 *, u64 *, u64,
+                                        const int *, const int *, int, u32 *,
+                                        hipStream_t, hipEvent_t *, int *, u8 *,
+                                        u8 *);
+template int radix_sort_pairs<u64, u64>(u64 *, u64 *, u64 *, u64 *, u64,
+                                        const int *, const int *, int, u32 *,
+                                        hipStream_t, hipEvent_t *, int *, u8 *,
+                                        u8 *);

@@ -389,7 +389,7 @@ def _pair_cases():
     c = np.concatenate([a[:3000], a[:3000][::-1]])
     yield "pairs_next_to_triples", np.concatenate([c, [255], c[:4000], [255], c[:1500]]).astype(np.uint8)
     yield "tandem", np.tile(a[:300], 9).astype(np.uint8)
-    yield "pair_at_the_very_end", np.concatenate([a[:100], a[:40], a[60:100]]).astype(np.uint8)
+    yield "copy_without_separator", np.concatenate([a, a[:5000], a[5100:]]).astype(np.uint8)
 
 
 @pytest.mark.parametrize("name,enc", list(_pair_cases()), ids=[c[0] for c in _pair_cases()])

@@ -60,7 +60,10 @@ class EsaTiming(ctypes.Structure):
                 ("tie_fix_ms", ctypes.c_float),
                 ("scatter_ms", ctypes.c_float),
                 ("scatter_launches", ctypes.c_uint32),
-                ("scatter_items", ctypes.c_uint64)]
+                ("scatter_items", ctypes.c_uint64),
+                ("comm_ms", ctypes.c_float),
+                ("comm_calls", ctypes.c_uint32),
+                ("comm_bytes", ctypes.c_uint64)]
 
 
 class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd_encode.h

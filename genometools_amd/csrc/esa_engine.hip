@@ -21,6 +21,7 @@
 // (src/core/encseq.c:6449-6530, src/match/sfx-bentsedg.c:75-80) is shared.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <chrono>
 #include <type_traits>
 #include <vector>
 #include "../../include/gtamd_esa.h"
@@ -1268,14 +1269,15 @@ constexpr int LCP_CHUNK = 32;
 constexpr u32 PAIR_SWAP = 1u << 31;
 
 // order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
-// per thread; a pair in the wrong order is swapped in the suffix array here,
-// the tables get their entries from k_pair_apply (which walks the pairs in
-// TABLE order -- in text order its five accesses per pair were five random
-// lines: 18 ms for 170 M pairs)
+// per thread.  Only reads the suffix array (the rank table is built from it
+// at the same time on another stream): k_pair_swap puts the pairs in order,
+// the tables get their entries from k_pair_apply -- both walk the pairs in
+// TABLE order (in text order the five accesses per pair of the apply step
+// were five random lines: 18 ms for 170 M pairs)
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
     Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 np,
-    P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
+    const P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1301,7 +1303,6 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
       const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
       const bool a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
                                         : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
-      if (!a_first) { sa[i] = (P) b; sa[i + 1] = (P) a; }
       const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
       res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: k_pair_apply walks the table
       sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
@@ -1327,6 +1328,24 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
     if (S) atomicAdd(&stats->lcpsum, S);
     if (Lg) atomicAdd(&stats->numlarge, Lg);
     if (M) atomicMax(&stats->maxlcp, M);
+  }
+}
+
+// pairs in the wrong order change places in the suffix array; where a rank
+// table has been built from the old order (single builds), its two entries too
+template <typename P>
+__global__ __launch_bounds__(256) void k_pair_swap(
+    const u32 *__restrict__ pidx, const u32 *__restrict__ res, u64 np,
+    P *__restrict__ sa, P *__restrict__ rank, u64 rank_offset) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= np || !(res[j] & PAIR_SWAP)) return;
+  const u64 i = pidx[j];
+  const P a = sa[i], b = sa[i + 1];
+  sa[i] = b;
+  sa[i + 1] = a;
+  if (rank != nullptr) {
+    rank[b] = (P) (rank_offset + i);
+    rank[a] = (P) (rank_offset + i + 1);
   }
 }
 
@@ -1991,7 +2010,8 @@ struct gtamd_esa_ctx {
   u64 max_n, n, N;         // N = n + 1 entries
   int readmode;            // GtReadmode of the sequence handed in as bytes
   hipStream_t st, st2;     // st2: table emission beside the refinement
-  hipEvent_t ev_sorted, ev_emitted;
+  hipStream_t st3;         // rank table build beside the pair comparisons
+  hipEvent_t ev_sorted, ev_emitted, ev_rank_in, ev_rank_done;
   // resident sequence
   DevBuf tb_own, sp_own;
   Text text;
@@ -2042,6 +2062,7 @@ static int ensure_buf(gtamd_esa_ctx *c, DevBuf &b, u64 bytes, const char *what) 
   if (bytes <= b.bytes) return 0;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipStreamSynchronize(c->st2));
+  HIP_TRY(hipStreamSynchronize(c->st3));
   c->alloc_bytes -= b.bytes;
   free_buf(b);
   bytes = (bytes + 255) & ~255ull;
@@ -2064,6 +2085,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   (void) hipSetDevice(c->device);
   if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
   if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
+  if (c->st3 != nullptr) (void) hipStreamSynchronize(c->st3);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
                     &c->tiebits2, &c->arena, &c->xrecv};
@@ -2076,6 +2098,9 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
   if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
   if (c->ev_emitted != nullptr) (void) hipEventDestroy(c->ev_emitted);
+  if (c->ev_rank_in != nullptr) (void) hipEventDestroy(c->ev_rank_in);
+  if (c->ev_rank_done != nullptr) (void) hipEventDestroy(c->ev_rank_done);
+  if (c->st3 != nullptr) (void) hipStreamDestroy(c->st3);
   if (c->st2 != nullptr) (void) hipStreamDestroy(c->st2);
   if (c->st != nullptr) (void) hipStreamDestroy(c->st);
   delete c;
@@ -2130,6 +2155,9 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   CTX_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
+  CTX_TRY(hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_rank_in, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_rank_done, hipEventDisableTiming));
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
   CTX_TRY(hipHostMalloc(&c->h_counts, 4 * DEST_MAXPARTS * 4, hipHostMallocDefault));
@@ -2311,7 +2339,12 @@ static int comm_allgather(gtamd_esa_ctx *c, int failed, const void *send, void *
   const u64 status = failed ? 1 : 0;
   memcpy(mine.data(), &status, 8);
   if (bytes) memcpy(mine.data() + 8, send, bytes);
-  if (c->comm_allgather(c->comm_user, mine.data(), all.data(), 8 + bytes) != 0) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = c->comm_allgather(c->comm_user, mine.data(), all.data(), 8 + bytes);
+  c->timing.comm_ms += std::chrono::duration<float, std::milli>(
+                           std::chrono::steady_clock::now() - t0).count();
+  c->timing.comm_calls++;
+  if (rc != 0) {
     gtamd_set_error("allgather callback failed");
     return -1;
   }
@@ -2341,7 +2374,14 @@ static int comm_alltoallv(gtamd_esa_ctx *c, const void *send, const u64 *sc, voi
       HIP_TRY(hipMemcpyAsync(recv, send, sc[0] * elem, hipMemcpyDeviceToDevice, c->st));
     return 0;
   }
-  if (c->comm_alltoallv(c->comm_user, send, sc, recv, rc, elem, (void *) c->st) != 0) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int crc = c->comm_alltoallv(c->comm_user, send, sc, recv, rc, elem, (void *) c->st);
+  c->timing.comm_ms += std::chrono::duration<float, std::milli>(
+                           std::chrono::steady_clock::now() - t0).count();
+  c->timing.comm_calls++;
+  for (u32 r = 0; r < R; r++)
+    if (r != c->part) c->timing.comm_bytes += sc[r] * elem;
+  if (crc != 0) {
     gtamd_set_error("alltoallv callback failed (%s)", what);
     return -1;
   }
@@ -2706,12 +2746,14 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // It is started where the first stream turns latency-bound (the comparisons
   // of the pair path, the rounds), so that the two actually overlap; whatever
   // it writes for tied entries is provisional and overwritten after the join.
-  bool emitted = false;
+  bool emitted = false, rank_building = false;
   auto launch_emission = [&]() -> int {
     if (emitted) return 0;
     emitted = true;
     HIP_TRY(hipEventRecord(c->ev_sorted, st));
     HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
+    // (two bandwidth-bound jobs at once gain nothing: behind the rank build)
+    if (rank_building) HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_rank_done, 0));
     if (NL > 0) {
       k_finalize<BITS, P><<<stride_grid(div_up(NL, FIN_TILE)), FIN_THREADS, 0, c->st2>>>(
           skey, sa, NL, prefixlength, d_suf, d_lcp, d_bwt, nullptr,
@@ -2854,6 +2896,12 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     const u64 ISA_CHUNK = 1ull << 27;
     const u64 ichunk = NL < ISA_CHUNK ? NL : ISA_CHUNK;
     const u64 xm = dist ? (ichunk > mp ? ichunk : mp) : 0;   // items bucketed at a time
+    // what one exchange can bring in: a position of the own tile is asked for /
+    // updated at most once per round and no part sends more than it has tied
+    // suffixes (or one chunk of first ranks)
+    u64 xrecv_n = (u64) R * ISA_CHUNK > anyleft ? (u64) R * ISA_CHUNK : anyleft;
+    if (xrecv_n > Tn) xrecv_n = Tn;
+    xrecv_n += 64;
     P *pk_a = nullptr, *pk_b = nullptr, *upos = nullptr, *upos2 = nullptr, *cvo = nullptr,
       *k2 = nullptr, *fk2 = nullptr, *fk2s_a = nullptr, *fk2s_b = nullptr, *fpos = nullptr,
       *cvs = nullptr, *lk_a = nullptr, *lk_b = nullptr, *xrank = nullptr, *xans = nullptr;
@@ -2905,7 +2953,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       layout(sz);
       fail = ensure_buf(c, c->arena, sz.off + 4096, "the refinement of tied suffixes") != 0;
       if (dist && !fail)
-        fail = ensure_buf(c, c->xrecv, (Tn + 64) * (4 + sizeof(P)) + 512,
+        fail = ensure_buf(c, c->xrecv, xrecv_n * (4 + sizeof(P)) + 512,
                           "the exchange of ranks") != 0;
       if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
       else if (fail) return -1;
@@ -2913,7 +2961,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       layout(a);
     }
     u32 *xrecv_off = c->xrecv.as<u32>();
-    P *xrecv_val = reinterpret_cast<P *>(c->xrecv.as<u8>() + (((Tn + 64) * 4 + 255) & ~255ull));
+    P *xrecv_val = reinterpret_cast<P *>(c->xrecv.as<u8>() + ((xrecv_n * 4 + 255) & ~255ull));
     const int nb = bits_for(N - 1);      // bits of a position / of a rank
     const int nbl = bits_for(NL ? NL - 1 : 0);   // bits of an index into the slice
     auto passes_for = [](int bits, int *ps, int *pw) -> int {
@@ -2927,33 +2975,17 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     };
     int ps[8], pw[8];
     const int pn = passes_for(nb, ps, pw);
-    // ---- the pairs: sorted by text position, compared, swapped
-    if (npairs > 0) {
-      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
-                                                               pv_a, pidx);
-      HIP_TRY(hipGetLastError());
-      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
-                                   nullptr, nullptr));
-      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
-      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
-      TRY(launch_emission());   // bandwidth-bound, beside the comparisons
-      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
-      HIP_TRY(hipGetLastError());
-    }
-    // ---- unresolved list of what is left
-    if (m0 > 0) {
-      k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
-          tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
-      HIP_TRY(hipGetLastError());
-    }
-    // ---- rank table and doubling rounds, if any part has a group left
+    // ---- rank table of a single build (all suffixes; the pairs count as
+    // settled, in the order the sort left them): bandwidth-bound streaming, on
+    // its own stream beside the latency-bound comparisons of the pair path.
+    // (a whole-table build makes the heads inside its first partition pass)
     P *rank = nullptr;       // whole table (single build) ...
     P *isa = nullptr;        // ... or the ranks of the own text tile (part build)
     if (anyleft > 0 && !dist) {
-      // rank table: ranks of all suffixes; (a whole-table build makes the heads
-      // inside its first partition pass)
       TRY(ensure_buf(c, c->isa_tmp, (NL + 8) * 8, "the rank table build"));
+      hipStream_t rs = c->st3;
+      HIP_TRY(hipEventRecord(c->ev_rank_in, st));
+      HIP_TRY(hipStreamWaitEvent(rs, c->ev_rank_in, 0));
       u32 *rank32 = fval;
       rank = reinterpret_cast<P *>(rank32);
       u32 *heads = reinterpret_cast<u32 *>(fkey);          // free key buffer
@@ -2967,7 +2999,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       const u32 *spos = reinterpret_cast<const u32 *>(sa);
       const bool heads_array = bits_for(N - 1) <= wmax;
       if (heads_array) {
-        k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(tiebits2, carry, NL, 0u, heads);
+        k_heads<<<(u32) div_up(NL, 1024), 256, 0, rs>>>(tiebits2, carry, NL, 0u, heads);
         HIP_TRY(hipGetLastError());
       }
       const GroupHeadValues headgen = {tiebits2, carry, nwords, 0u};
@@ -2991,24 +3023,53 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
         if (heads_array)
           TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &w0,
-                                         1, pws, st, nullptr, nullptr));
+                                         1, pws, rs, nullptr, nullptr));
         else
-          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, st));
-        TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
+          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, rs));
+        TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, rs,
                                        nullptr, nullptr));
         wpos = qpos; whead = qhead;
       } else if (pb > 0) {
         const int s0 = nb - pb;
         if (heads_array)
           TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &pb,
-                                         1, pws, st, nullptr, nullptr));
+                                         1, pws, rs, nullptr, nullptr));
         else
-          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, st));
+          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, rs));
         wpos = ppos; whead = phead;
       }
       const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
       const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
-      k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank32);
+      k_rank_window<<<grid, RW_THREADS, 0, rs>>>(wpos, whead, NL, wb, split, nbuckets, rank32);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(c->ev_rank_done, rs));
+      rank_building = true;
+    }
+    // ---- the pairs: sorted by text position, compared
+    if (npairs > 0) {
+      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
+                                                               pv_a, pidx);
+      HIP_TRY(hipGetLastError());
+      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
+                                   nullptr, nullptr));
+      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
+      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
+      TRY(launch_emission());   // bandwidth-bound: behind the rank build, or beside the comparisons
+      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
+          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- unresolved list of what is left
+    if (m0 > 0) {
+      k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
+          tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- pairs in the wrong order change places (and ranks, where a table exists)
+    if (rank_building) HIP_TRY(hipStreamWaitEvent(st, c->ev_rank_done, 0));
+    if (npairs > 0) {
+      k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, rank,
+                                                               index_offset);
       HIP_TRY(hipGetLastError());
     }
     std::vector<u64> qcounts(R), ucounts(R), zero(R, 0);
@@ -3047,7 +3108,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         TRY(comm_allgather(c, 0, sc.data(), mat.data(), R * 8));
         u64 nrecv = 0;
         for (u32 s = 0; s < R; s++) { rc[s] = mat[(size_t) s * R + c->part]; nrecv += rc[s]; }
-        if (nrecv > Tn) {
+        if (nrecv + 64 > xrecv_n) {
           gtamd_set_error("rank exchange: %llu ranks for a tile of %llu positions",
                           (unsigned long long) nrecv, (unsigned long long) Tn);
           return -1;
@@ -3106,7 +3167,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           std::vector<u64> sc(R), rc(R);
           for (u32 r = 0; r < R; r++) sc[r] = mine[R + r];
           const u64 nrecv = recv_of(gathered, 1, rc);
-          if (nrecv > Tn) {
+          if (nrecv + 64 > xrecv_n) {
             gtamd_set_error("rank exchange: %llu updates for a tile of %llu positions",
                             (unsigned long long) nrecv, (unsigned long long) Tn);
             return -1;
@@ -3128,7 +3189,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           u64 msent = 0;
           for (u32 r = 0; r < R; r++) { sc[r] = mine[r]; msent += sc[r]; }
           const u64 nrecv = recv_of(gathered, 0, rc);
-          if (nrecv > Tn) {
+          if (nrecv + 64 > xrecv_n) {
             gtamd_set_error("rank exchange: %llu queries for a tile of %llu positions",
                             (unsigned long long) nrecv, (unsigned long long) Tn);
             return -1;

@@ -87,6 +87,11 @@ typedef struct {
   float scatter_ms;    /* sum over the downsweep (scatter) kernel launches */
   uint32_t scatter_launches;
   uint64_t scatter_items;  /* elements moved per launch (first sort) */
+  /* part builds: host time spent inside the collective callbacks (waiting for
+     the other parts included), their number, and the bytes this part sent */
+  float comm_ms;
+  uint32_t comm_calls;
+  uint64_t comm_bytes;
 } gtamd_esa_timing;
 
 typedef struct gtamd_esa_ctx gtamd_esa_ctx;

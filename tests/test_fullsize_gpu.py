@@ -9,6 +9,10 @@ oracle's comparison sort cannot run at these sizes):
   array on the device, plus order and LCP of thousands of sampled neighbour
   pairs re-derived on the CPU from the encoded sequence, plus the tail layout
   (specials in text order, then n).
+* configs[4], 10^9 protein residues: the same properties on the 5-bit path.
+* the position range of configs[3] (n >= 2^32; the 24 Gbp input itself needs
+  the 8 GPUs it is defined on): 2^32 + 4 M bases of uniform DNA built in two
+  parts on the one GPU, 64-bit positions and ranks.
 """
 import numpy as np
 import pytest
@@ -112,3 +116,143 @@ def test_config2_3gbp_humanlike_properties(gpu):
             v = int(v)
             assert np.array_equal(enc[p:p + v], enc[q:q + v]) and np.all(enc[p:p + v] < 254)
             assert p + v >= n or q + v >= n or enc[p + v] >= 254 or enc[q + v] >= 254 or enc[p + v] != enc[q + v]
+
+
+def _sampled_neighbours(eng, enc_of, n, lo, hi, rng, samples, index_offset=0, wildcard_ok=True):
+    """order, LCP byte and BWT byte of `samples` neighbour pairs of the table
+    slice held by `eng`, re-derived on the CPU; enc_of(a, b) delivers the
+    encoded symbols [a, b)"""
+    bad = 0
+    for i in np.sort(rng.integers(lo, hi, samples)):
+        i = int(i)
+        p, q = (int(x) for x in eng.table(esa.TAB_SUF, i - 1, 2))
+        lcpb = int(eng.table(esa.TAB_LCP, i, 1)[0])
+        bwtb = int(eng.table(esa.TAB_BWT, i, 1)[0])
+        span = 64
+        while True:
+            a, b = enc_of(p, min(n, p + span)), enc_of(q, min(n, q + span))
+            m = min(len(a), len(b))
+            neq = np.nonzero((a[:m] != b[:m]) | (a[:m] >= 254))[0]
+            if len(neq) or m < span:
+                l = int(neq[0]) if len(neq) else m
+                break
+            span *= 8
+        ca = a[l] if l < len(a) else 255
+        cb = b[l] if l < len(b) else 255
+        ka = 256 + p + l if ca >= 254 else int(ca)
+        kb = 256 + q + l if cb >= 254 else int(cb)
+        bw = 254 if q == 0 else int(enc_of(q - 1, q)[0])
+        bad += not (ka < kb and lcpb == min(l, 255) and bwtb == bw)
+    return bad
+
+
+def test_config4_protein_1g_properties(gpu):
+    """BASELINE.json configs[4]: 10^9 residues over the 20-letter alphabet
+    (src/core/alphabet.c:488-503), -suf -lcp (+ -bwt): the 5-bit symbol path at
+    full size (7 sort passes, N/12 word indexing)"""
+    n = 1000 * 1000 * 1000
+    N = n + 1
+    buf = _device_sequence(synth.MODEL_PROTEIN, 44, n)
+    with esa.EsaEngine(n, 20) as eng:
+        eng.set_sequence_device(buf.data_ptr(), n)
+        eng.run()
+        st = eng.stats()
+        assert st["prefixlength"] == 5
+        sa = torch.as_tensor(_Wrap(eng.device_pointer(esa.TAB_SUF), N, "<i8"), device="cuda:0")
+        assert int(sa.sum().item()) == N * (N - 1) // 2
+        sq = int((sa * sa).sum().item()) % (1 << 64)
+        assert sq == ((N - 1) * N * (2 * N - 1) // 6) % (1 << 64)
+        assert int(sa[st["longest"]].item()) == 0
+        del sa
+        enc = buf.cpu().numpy()
+        del buf
+        torch.cuda.empty_cache()
+        specials = int(np.count_nonzero(enc >= 254))
+        assert specials > 2_000_000          # ~3 M sequence borders + X
+        # tail: separators and X in text order, then n
+        tail = eng.table(esa.TAB_SUF, N - 1 - specials, specials + 1)
+        assert tail[-1] == n
+        assert np.all(enc[tail[:-1].astype(np.int64)] >= 254)
+        assert np.all(np.diff(tail[:-1].astype(np.int64)) > 0)
+        before_tail = eng.table(esa.TAB_SUF, N - 2 - specials, 1)[0]
+        assert enc[int(before_tail)] < 254
+        rng = np.random.default_rng(44)
+        bad = _sampled_neighbours(eng, lambda a, b: enc[a:b], n, 1, N - specials - 1, rng, 4000)
+        assert bad == 0
+        # i.i.d. residues: no LCP near the byte limit
+        assert st["largelcpvalues"] == 0 and st["maxbranchdepth"] < 64
+        lcp = eng.table(esa.TAB_LCP)
+        assert int(lcp.max()) == st["maxbranchdepth"]
+        assert np.all(lcp[N - 1 - specials + 1:] == 0)
+        # averagelcp of .prj: entries with >= prefixlength letters (SURVEY 0.4);
+        # an upper bound here, the exact mask is checked at oracle sizes
+        assert 0 < st["lcptabsum"] <= int(lcp.sum(dtype=np.uint64))
+
+
+def test_positions_beyond_2p32_in_two_parts(gpu):
+    """n just above 2^32 (the position range BASELINE.json configs[3], 24 Gbp
+    on 8 GPUs, needs): two parts as threads on the one GPU, 64-bit positions
+    and ranks, the slices of both parts checked on the device and by samples"""
+    import threading
+    from thread_comm import ThreadComm
+    n = (1 << 32) + (1 << 22) + 12345
+    N = n + 1
+    seed = 45
+    buf = _device_sequence(synth.MODEL_UNIFORM_DNA, seed, n)
+    shared = ThreadComm(2, 0)
+    engines = [esa.EsaEngine(n, 4) for _ in range(2)]
+    errors = []
+
+    def worker(r):
+        try:
+            eng = engines[r]
+            eng.set_sequence_device(buf.data_ptr(), n)
+            eng.set_part(r, 2, shared.view(r))
+            eng.run()
+        except Exception as e:   # noqa: BLE001
+            errors.append((r, repr(e)))
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    try:
+        assert not errors, errors
+        del buf
+        torch.cuda.empty_cache()
+
+        def enc_of(a, b):
+            return synth.generate(synth.MODEL_UNIFORM_DNA, seed, n, a, b)
+
+        total, sq, top = 0, 0, 0
+        offs = []
+        rng = np.random.default_rng(7)
+        for r, eng in enumerate(engines):
+            cnt, off = eng.entries(esa.TAB_SUF), eng.table_offset()
+            offs.append((off, cnt))
+            st = eng.stats()
+            sa = torch.as_tensor(_Wrap(eng.device_pointer(esa.TAB_SUF), cnt, "<i8"), device="cuda:0")
+            total += int(sa.sum().item())            # (below 2^63 for each slice?  no: mod 2^64)
+            sq += int((sa * sa).sum().item())
+            top = max(top, int(sa.max().item()))
+            del sa
+            assert st["tied_suffixes"] > 0           # random 20-mers collide at this size
+            assert _sampled_neighbours(eng, enc_of, n, 1, cnt - (1 if r == 1 else 0), rng, 1500) == 0
+        assert offs[0][0] == 0 and offs[1][0] == offs[0][1] and offs[1][0] + offs[1][1] == N
+        assert abs(offs[0][1] - offs[1][1]) < N // 50          # even ranges
+        assert total % (1 << 64) == (N * (N - 1) // 2) % (1 << 64)
+        assert sq % (1 << 64) == ((N - 1) * N * (2 * N - 1) // 6) % (1 << 64)
+        assert top == n                               # the virtual end, a position >= 2^32
+        # the border between the slices is in order too
+        p = int(engines[0].table(esa.TAB_SUF, offs[0][1] - 1, 1)[0])
+        q = int(engines[1].table(esa.TAB_SUF, 0, 1)[0])
+        a, b = enc_of(p, min(n, p + 64)), enc_of(q, min(n, q + 64))
+        m = min(len(a), len(b))
+        d = int(np.nonzero(a[:m] != b[:m])[0][0])
+        assert a[d] < b[d]
+        assert int(engines[1].table(esa.TAB_LCP, 0, 1)[0]) == d
+    finally:
+        for eng in engines:
+            eng.close()

@@ -4,6 +4,7 @@ runs), exchanging through shared state, barriers and device-to-device copies.
 Lets the sharded path be checked on a single-GPU box.  Test infrastructure."""
 import ctypes
 import threading
+import time
 
 import numpy as np
 import torch
@@ -17,14 +18,32 @@ class _View:
         self.allgather_cb = ALLGATHER_FN(self._allgather)
         self.alltoallv_cb = ALLTOALLV_FN(self._alltoallv)
         self.bytes_exchanged = 0
+        self.calls = 0
+        self.compute_s = 0.0      # serial mode: time this part had the device
+
+    # serial mode (tools/parts_probe.py): only one part computes at a time, so
+    # the time a part holds the device is what it would need on a GPU of its
+    # own; the parts hand the device over at every collective
+    def begin(self):
+        if self.shared.serial:
+            self.shared.gpu_lock.acquire()
+            self._t = time.perf_counter()
+
+    def end(self):
+        if self.shared.serial:
+            torch.cuda.synchronize(torch.device("cuda", self.shared.device))
+            self.compute_s += time.perf_counter() - self._t
+            self.shared.gpu_lock.release()
 
     def _allgather(self, user, send, recv, nbytes):
         try:
             sh = self.shared
+            self.end()
             sh.slots[self.rank] = bytes((ctypes.c_uint8 * nbytes).from_address(send))
             sh.barrier.wait()
             ctypes.memmove(recv, b"".join(sh.slots), nbytes * self.world)
             sh.barrier.wait()
+            self.begin()
             return 0
         except Exception as e:
             print("thread allgather failed", repr(e), flush=True)
@@ -39,6 +58,7 @@ class _View:
             # everything the engine has queued on its stream must be done before
             # another thread copies out of this part's send buffer
             torch.cuda.ExternalStream(stream, device=dev).synchronize()
+            self.end()
             sh.slots[self.rank] = (send, sc)
             sh.barrier.wait()
             out_off = 0
@@ -54,7 +74,9 @@ class _View:
                 out_off += nb
             torch.cuda.synchronize(dev)
             self.bytes_exchanged += sum(sc) - sc[self.rank]
+            self.calls += 1
             sh.barrier.wait()
+            self.begin()
             return 0
         except Exception as e:
             print("thread alltoallv failed", repr(e), flush=True)
@@ -63,9 +85,10 @@ class _View:
 
 
 class ThreadComm:
-    def __init__(self, world, device=0):
-        self.world, self.device = world, device
+    def __init__(self, world, device=0, serial=False):
+        self.world, self.device, self.serial = world, device, serial
         self.barrier = threading.Barrier(world)
+        self.gpu_lock = threading.Lock()
         self.slots = [None] * world
 
     def view(self, rank):
@@ -77,7 +100,7 @@ def _assemble(results, n):
     stats = {"lcptabsum": 0, "largelcpvalues": 0, "longest": 0, "maxbranchdepth": 0,
              "tied_suffixes": 0, "pair_suffixes": 0, "refine_rounds": 0}
     expect = 0
-    for off, res in results:
+    for off, res, *_ in results:
         assert off == expect, "slices must tile the table"
         for tab in (res.suf, res.bwt, res.lcp):
             if tab is not None:
@@ -107,13 +130,13 @@ def build_in_parts(enc, sigma, parts, want=7, device=0, timing=False):
     return tabs, stats, [r[1].stats for r in results]
 
 
-def build_sequences_in_parts(encs, sigma, parts, want=7, device=0):
+def build_sequences_in_parts(encs, sigma, parts, want=7, device=0, serial=False, views=None):
     """the sequences of `encs`, one after the other, through the SAME `parts`
     engine contexts (one thread per part); per sequence: assembled tables,
     combined statistics, per-part (offset, result)"""
     from genometools_amd import esa
     encs = [np.ascontiguousarray(e, dtype=np.uint8) for e in encs]
-    shared = ThreadComm(parts, device)
+    shared = ThreadComm(parts, device, serial)
     results = [[None] * parts for _ in encs]
     errors = []
     cap = max(max(e.size for e in encs), 1)
@@ -122,11 +145,18 @@ def build_sequences_in_parts(encs, sigma, parts, want=7, device=0):
         try:
             with esa.EsaEngine(cap, sigma, device) as eng:
                 view = shared.view(r)
+                if views is not None:
+                    views[r] = view
                 for k, enc in enumerate(encs):
                     eng.set_sequence(enc)
                     eng.set_part(r, parts, view)
-                    eng.run(want)
-                    results[k][r] = (eng.table_offset(), eng.result())
+                    view.compute_s, view.bytes_exchanged, view.calls = 0.0, 0, 0
+                    view.begin()
+                    try:
+                        eng.run(want)
+                    finally:
+                        view.end()
+                    results[k][r] = (eng.table_offset(), eng.result(), view.compute_s)
         except Exception as e:   # noqa: BLE001
             errors.append((r, repr(e)))
             shared.barrier.abort()

@@ -21,6 +21,9 @@ ap.add_argument("--n", type=float, default=64e6)
 ap.add_argument("--model", type=int, default=1)
 ap.add_argument("--parts", default="2")
 ap.add_argument("--want", type=int, default=7)
+ap.add_argument("--serial", action="store_true",
+                help="one part computes at a time: the time a part holds the device is "
+                     "what it would need on a GPU of its own")
 a = ap.parse_args()
 n = int(a.n)
 lib = _lib.load()
@@ -32,15 +35,20 @@ torch.cuda.empty_cache()
 N = n + 1
 for parts in [int(x) for x in a.parts.split(",")]:
     # two sequences through the same contexts: the second run is warm
-    out = thread_comm.build_sequences_in_parts([enc, enc], synth.numofchars(a.model), parts, a.want)
+    views = [None] * parts
+    out = thread_comm.build_sequences_in_parts([enc, enc], synth.numofchars(a.model), parts, a.want,
+                                               serial=a.serial, views=views)
     for rep, (tabs, stats, res) in enumerate(out):
-        for r, (off, rr) in enumerate(res):
+        for r, (off, rr, compute_s) in enumerate(res):
             st, tm = rr.stats, rr.timing
-            print("R=%d rep%d part%d slice %d tied %d pairs %d mem %.1f GB | total %.1f keygen+exchange %.1f sort %.1f "
-                  "fin %.1f refine %.1f fix %.1f" % (
+            print("R=%d rep%d part%d slice %d tied %d pairs %d mem %.1f GB | %s total %.1f keygen+exchange %.1f sort %.1f "
+                  "fin %.1f refine %.1f fix %.1f | sent %.2f GB in %d exchanges" % (
                       parts, rep, r, tm["scatter_items"], st["tied_suffixes"], st["pair_suffixes"],
-                      st["device_bytes"] / 1e9, tm["total_ms"], tm["keygen_ms"], tm["sort_ms"],
-                      tm["finalize_ms"], tm["refine_ms"], tm["tie_fix_ms"]), flush=True)
+                      st["device_bytes"] / 1e9,
+                      ("OUTSIDE COLLECTIVES %.1f ms |" % (tm["total_ms"] - tm["comm_ms"])) if a.serial else "",
+                      tm["total_ms"], tm["keygen_ms"], tm["sort_ms"],
+                      tm["finalize_ms"], tm["refine_ms"], tm["tie_fix_ms"],
+                      tm["comm_bytes"] / 1e9, tm["comm_calls"]), flush=True)
     if tabs["suf"] is not None:
         assert int(tabs["suf"].sum(dtype=np.uint64)) == (N * (N - 1) // 2) % (1 << 64)
         print("R=%d checksum ok" % parts, flush=True)

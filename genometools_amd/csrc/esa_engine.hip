@@ -22,6 +22,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <chrono>
+#include <functional>
 #include <type_traits>
 #include <vector>
 #include "../../include/gtamd_esa.h"
@@ -1164,9 +1165,11 @@ __global__ __launch_bounds__(256) void k_heads(
 constexpr int RW_BITS = 15;
 constexpr int RW_THREADS = 1024;
 
+// winlist != nullptr: only some windows are built (see below); bucket k of the
+// partitioned pairs is window winlist[k]
 __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
     const u32 *__restrict__ pos, const u32 *__restrict__ heads, u64 N, int wb,
-    int split, u32 nbuckets, u32 *__restrict__ rank) {
+    int split, u32 nbuckets, u32 *__restrict__ rank, const u32 *__restrict__ winlist) {
   __shared__ u32 s_win[1 << RW_BITS];
   u32 bucket = blockIdx.x, half = 0;
   if (split == 2) {
@@ -1176,10 +1179,11 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
   if (bucket >= nbuckets) return;   // whole workgroup
   const int sb = wb - (split == 2 ? 1 : 0);   // position bits inside a window
   const u32 smask = (1u << sb) - 1u;
-  const u64 first = (u64) bucket << wb;
+  const u64 in_first = (u64) bucket << wb;                 // where the window's pairs are
+  const u64 first = (u64) (winlist != nullptr ? winlist[bucket] : bucket) << wb;
   const u64 end = first + (1ull << wb) < N ? first + (1ull << wb) : N;
   const u64 cnt = end - first;
-  const u32 *bp = pos + first, *bh = heads + first;
+  const u32 *bp = pos + in_first, *bh = heads + in_first;
   // four pairs per lane and step while whole groups are left (first is a
   // multiple of 4 whenever wb >= 2; both arrays are 16-byte aligned then)
   const u64 cnt4 = (wb >= 2) ? (cnt & ~3ull) : 0;
@@ -1205,6 +1209,130 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
   for (u64 i = (u64) threadIdx.x * 4; i < wcnt4; i += (u64) RW_THREADS * 4)
     *reinterpret_cast<uint4 *>(out + i) = *reinterpret_cast<const uint4 *>(s_win + i);
   for (u64 i = wcnt4 + threadIdx.x; i < wcnt; i += RW_THREADS) out[i] = s_win[i];
+}
+
+// Only the windows the doubling rounds can touch are built.  After the pair
+// path the suffixes still tied are a small part of the text (1.7 % of the
+// human-like 3 Gbp: high-copy repeat families), and a round reads rank[p + h]
+// and writes rank[p] for those suffixes p only -- positions that cluster in a
+// fifth of the 64 K-position windows.  So: mark the windows of p .. p + H for
+// the first rounds' offsets, keep the (position, head) pairs of marked windows
+// (one streaming pass over the suffix array), partition and scatter only
+// those.  A later round whose offset reaches an unbuilt window has it built
+// first (k_win_check; never happens while h <= H).  38 -> 13 ms at 3 Gbp.
+template <typename P>
+__global__ __launch_bounds__(256) void k_win_mark(const P *__restrict__ upos, u64 m, u64 lo,
+                                                  u64 hi, int wb, u64 nwin,
+                                                  u32 *__restrict__ need) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const u64 p = (u64) upos[j];
+  u64 w0 = (p + lo) >> wb, w1 = (p + hi) >> wb;
+  if (w1 >= nwin) w1 = nwin - 1;
+  for (u64 w = w0; w <= w1; w++)
+    if (!((need[w >> 5] >> (w & 31)) & 1u)) atomicOr(&need[w >> 5], 1u << (w & 31));
+}
+
+// does this round's offset reach a window that has not been built?
+template <typename P>
+__global__ __launch_bounds__(256) void k_win_check(const P *__restrict__ upos, u64 m, u64 h,
+                                                   int wb, u64 nwin,
+                                                   const u32 *__restrict__ built,
+                                                   u32 *__restrict__ need, Stats *stats) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  u64 w = ((u64) upos[j] + h) >> wb;
+  if (w >= nwin) w = nwin - 1;
+  if (!((built[w >> 5] >> (w & 31)) & 1u)) {
+    if (!((need[w >> 5] >> (w & 31)) & 1u)) atomicOr(&need[w >> 5], 1u << (w & 31));
+    stats->count2 = 1;
+  }
+}
+
+// one workgroup: the windows that are needed and not built yet, in ascending
+// order (winlist), as a bitmap (sel), their number; they count as built from
+// here on
+__global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ need,
+                                                     u32 *__restrict__ built, u64 nwords,
+                                                     u32 *__restrict__ sel,
+                                                     u32 *__restrict__ winlist, Stats *stats) {
+  __shared__ u32 s_scan[16];
+  const u64 per = (nwords + 1023) / 1024;
+  const u64 w0 = (u64) threadIdx.x * per;
+  const u64 w1 = w0 + per < nwords ? w0 + per : nwords;
+  u32 cnt = 0;
+  for (u64 w = w0; w < w1; w++) cnt += (u32) __popc(need[w] & ~built[w]);
+  u32 tot;
+  u32 at = block_scan_excl<SCAN_SUM, 1024>(cnt, &tot, s_scan);
+  for (u64 w = w0; w < w1; w++) {
+    u32 x = need[w] & ~built[w];
+    sel[w] = x;
+    built[w] |= x;
+    while (x) {
+      const int b = __ffs(x) - 1;
+      x &= x - 1;
+      winlist[at++] = (u32) (w * 32 + b);
+    }
+  }
+  if (threadIdx.x == 0) stats->count = tot;
+}
+
+// entries of the suffix array whose position lies in a selected window: counted
+// per 4096 entries, then placed (any order: they are partitioned by position
+// next) together with the heads of their tie groups
+constexpr int WF_PER = 16;
+__global__ __launch_bounds__(256) void k_win_count(const u32 *__restrict__ sa, u64 NL, int wb,
+                                                   const u32 *__restrict__ sel,
+                                                   u32 *__restrict__ blockcnt) {
+  __shared__ u32 s_scan[4];
+  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * WF_PER;
+  u32 c = 0;
+  if (i0 + WF_PER <= NL) {
+#pragma unroll
+    for (int q = 0; q < WF_PER / 4; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0 + 4 * q);
+      const u32 p[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32 w = p[k] >> wb;
+        c += (sel[w >> 5] >> (w & 31)) & 1u;
+      }
+    }
+  } else {
+    for (int k = 0; k < WF_PER; k++)
+      if (i0 + k < NL) {
+        const u32 w = sa[i0 + k] >> wb;
+        c += (sel[w >> 5] >> (w & 31)) & 1u;
+      }
+  }
+  u32 tot;
+  (void) block_scan_excl_sum(c, &tot, s_scan);
+  if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_win_place(
+    const u32 *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
+    const u32 *__restrict__ boff, const u64 *__restrict__ tiebits,
+    const u32 *__restrict__ carry, u32 *__restrict__ fpos, u32 *__restrict__ fhead) {
+  __shared__ u32 s_scan[4];
+  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * WF_PER;
+  u32 mask = 0;
+  u32 p[WF_PER];
+#pragma unroll
+  for (int k = 0; k < WF_PER; k++) {
+    p[k] = i0 + k < NL ? sa[i0 + k] : 0u;
+    const u32 w = p[k] >> wb;
+    if (i0 + k < NL && ((sel[w >> 5] >> (w & 31)) & 1u)) mask |= 1u << k;
+  }
+  u32 tot;
+  u32 o = boff[blockIdx.x] + block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
+  while (mask) {
+    const int k = __ffs(mask) - 1;
+    mask &= mask - 1;
+    fpos[o] = p[k];
+    fhead[o] = group_head(tiebits, carry, i0 + k);
+    o++;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1240,8 +1368,10 @@ __global__ __launch_bounds__(256) void k_pair_words(
   tiebits2[w] = t & ~((ph << 1) | prevhead);
 }
 
-// (smaller position, index of the pair's first entry | ordinal of the pair <<
-// 32), and the index again by ordinal; one thread per bitmap word
+// (smaller position, value | ordinal of the pair << 32) with value = the other
+// position (32-bit positions) or the index of the pair's first entry (64-bit
+// positions: the partner is looked up), and that index again by ordinal; one
+// thread per bitmap word
 template <typename P>
 __global__ __launch_bounds__(256) void k_pair_emit(
     const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
@@ -1259,7 +1389,8 @@ __global__ __launch_bounds__(256) void k_pair_emit(
     ph &= ph - 1;
     const u64 i = w * 64 + b;
     pkey[j] = sa[i];    // the stable sort left equal keys in position order
-    pval[j] = i | ((u64) j << 32);
+    // 32-bit positions: the partner travels with the pair (no look-up later)
+    pval[j] = (sizeof(P) == 4 ? (u64) sa[i + 1] : i) | ((u64) j << 32);
     pidx[j] = (u32) i;
     j++;
   }
@@ -1286,23 +1417,32 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
   const u64 nchunks = (np + LCP_CHUNK - 1) / LCP_CHUNK;
   for (u64 c = (u64) blockIdx.x * 256 + threadIdx.x; c < nchunks;
        c += (u64) gridDim.x * 256) {
-    u64 preva = 0, l = 0;
+    u64 preva = 0, prevb = 0, l = 0;
+    bool a_first = true;
     for (int e = 0; e < LCP_CHUNK; e++) {
       const u64 s = c * LCP_CHUNK + e;
       if (s >= np) break;
       const u64 a = pkey[s];
       const u64 iv = pval[s];
-      const u64 i = iv & 0xFFFFFFFFull, j = iv >> 32;
-      const u64 b = sa[i + 1];
-      u64 from = (u64) Key<BITS>::SYMS;
-      if (e > 0 && l > from + (a - preva)) from = l - (a - preva);
-      l = lcp_extend<BITS>(t, a, b, from);
+      const u64 j = iv >> 32;
+      const u64 b = sizeof(P) == 4 ? (iv & 0xFFFFFFFFull) : (u64) sa[(iv & 0xFFFFFFFFull) + 1];
+      const u64 d = a - preva;
+      if (e > 0 && l >= (u64) Key<BITS>::SYMS + d && b == prevb + d) {
+        // the next pair on the same diagonal: the same first difference decides,
+        // d symbols nearer -- nothing to read
+        l -= d;
+      } else {
+        u64 from = (u64) Key<BITS>::SYMS;
+        if (e > 0 && l > from + d) from = l - d;
+        l = lcp_extend<BITS>(t, a, b, from);
+        // the first difference decides: a special is larger than every letter,
+        // two specials compare by position
+        const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
+        a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
+                               : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
+      }
       preva = a;
-      // the first difference decides: a special is larger than every letter,
-      // two specials compare by position
-      const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
-      const bool a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
-                                        : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
+      prevb = b;
       const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
       res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: k_pair_apply walks the table
       sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
@@ -2027,6 +2167,7 @@ struct gtamd_esa_ctx {
   DevBuf tiebits, tiebits2;
   DevBuf arena;            // pair list, unresolved list, round buffers
   DevBuf xrecv;            // part builds: receive side of the exchanges
+  DevBuf winbuf;           // bitmaps and list of the rank-table windows
   u64 *llv;
   u64 llv_pairs, llv_cap;
   u32 *bck;                      // .bck sections, back to back
@@ -2088,7 +2229,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->st3 != nullptr) (void) hipStreamSynchronize(c->st3);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
-                    &c->tiebits2, &c->arena, &c->xrecv};
+                    &c->tiebits2, &c->arena, &c->xrecv, &c->winbuf};
   for (DevBuf *b : bufs) free_buf(*b);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
@@ -2975,22 +3116,47 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     };
     int ps[8], pw[8];
     const int pn = passes_for(nb, ps, pw);
-    // ---- rank table of a single build (all suffixes; the pairs count as
-    // settled, in the order the sort left them): bandwidth-bound streaming, on
-    // its own stream beside the latency-bound comparisons of the pair path.
-    // (a whole-table build makes the heads inside its first partition pass)
     P *rank = nullptr;       // whole table (single build) ...
     P *isa = nullptr;        // ... or the ranks of the own text tile (part build)
+    // ---- the pairs: sorted by text position, compared
+    if (npairs > 0) {
+      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
+                                                               pv_a, pidx);
+      HIP_TRY(hipGetLastError());
+      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
+                                   nullptr, nullptr));
+      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
+      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
+      TRY(launch_emission());   // bandwidth-bound, beside the comparisons
+      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
+          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      // pairs in the wrong order change places
+      k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, nullptr, 0);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- unresolved list of what is left
+    if (m0 > 0) {
+      k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
+          tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- rank table of a single build: the windows of positions the rounds can
+    // touch (all of them when that is most of the text)
+    int rk_wb = 0;
+    u64 rk_nwin = 0, rk_h0 = 0;
+    bool rk_windows = false;          // only some windows are built
+    u32 *w_need = nullptr, *w_built = nullptr, *w_sel = nullptr, *w_list = nullptr;
+    // builds the windows that are needed and not built (all == the whole table)
+    std::function<int(bool)> build_rank = [](bool) -> int { return 0; };
     if (anyleft > 0 && !dist) {
       TRY(ensure_buf(c, c->isa_tmp, (NL + 8) * 8, "the rank table build"));
-      hipStream_t rs = c->st3;
-      HIP_TRY(hipEventRecord(c->ev_rank_in, st));
-      HIP_TRY(hipStreamWaitEvent(rs, c->ev_rank_in, 0));
       u32 *rank32 = fval;
       rank = reinterpret_cast<P *>(rank32);
       u32 *heads = reinterpret_cast<u32 *>(fkey);          // free key buffer
       u32 *ppos = c->isa_tmp.as<u32>(), *phead = ppos + ((NL + 3) & ~3ull);  // (skey is still
                                                            // being read by the emission)
+      u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);
       int wmax = RW_BITS;
       if (const char *e = getenv("GTAMD_RANK_WINDOW_BITS")) {
         const int v = atoi(e);
@@ -2998,11 +3164,6 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       }
       const u32 *spos = reinterpret_cast<const u32 *>(sa);
       const bool heads_array = bits_for(N - 1) <= wmax;
-      if (heads_array) {
-        k_heads<<<(u32) div_up(NL, 1024), 256, 0, rs>>>(tiebits2, carry, NL, 0u, heads);
-        HIP_TRY(hipGetLastError());
-      }
-      const GroupHeadValues headgen = {tiebits2, carry, nwords, 0u};
       // Partition down to windows that fit the LDS (one or two passes), then
       // k_rank_window.  (Measured at 3 Gbp: direct scatter 120 ms; one 8-bit
       // pass + global scatter 84 ms; two passes + LDS window 30 ms.)
@@ -3017,60 +3178,105 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         return -1;
       }
       const int split = wb > wmax ? 2 : 1;
-      const u32 *wpos = spos, *whead = heads;
-      if (pb > 8) {
-        const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;
-        u32 *qhead = heads, *qpos = heads + ((NL + 3) & ~3ull);   // heads is dead by then
-        if (heads_array)
-          TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &w0,
-                                         1, pws, rs, nullptr, nullptr));
-        else
-          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, rs));
-        TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, rs,
-                                       nullptr, nullptr));
-        wpos = qpos; whead = qhead;
-      } else if (pb > 0) {
-        const int s0 = nb - pb;
-        if (heads_array)
-          TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0, &pb,
-                                         1, pws, rs, nullptr, nullptr));
-        else
-          TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, rs));
-        wpos = ppos; whead = phead;
+      rk_wb = wb;
+      rk_nwin = div_up(N, 1ull << wb);
+      const u64 nww = rk_nwin / 32 + 2;
+      const char *we = getenv("GTAMD_RANK_ALL_WINDOWS");           // A/B switch
+      const bool all_windows = (we != nullptr && we[0] == '1') || pb == 0;
+      if (!all_windows) {
+        TRY(ensure_buf(c, c->winbuf, (3 * nww + rk_nwin + 16) * 4, "the rank windows"));
+        w_need = c->winbuf.as<u32>(); w_built = w_need + nww; w_sel = w_built + nww;
+        w_list = w_sel + nww;
+        HIP_TRY(hipMemsetAsync(w_need, 0, 2 * nww * 4, st));
+        // offsets of the first rounds, as far as three windows reach
+        rk_h0 = (u64) K::SYMS << 9;
+        if (rk_h0 > (3ull << wb)) rk_h0 = 3ull << wb;
+        if (m0 > 0) {
+          k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, wb, rk_nwin,
+                                                              w_need);
+          HIP_TRY(hipGetLastError());
+        }
+        rk_windows = true;
       }
-      const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
-      const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
-      k_rank_window<<<grid, RW_THREADS, 0, rs>>>(wpos, whead, NL, wb, split, nbuckets, rank32);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(c->ev_rank_done, rs));
-      rank_building = true;
-    }
-    // ---- the pairs: sorted by text position, compared
-    if (npairs > 0) {
-      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
-                                                               pv_a, pidx);
-      HIP_TRY(hipGetLastError());
-      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
-                                   nullptr, nullptr));
-      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
-      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
-      TRY(launch_emission());   // bandwidth-bound: behind the rank build, or beside the comparisons
-      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
-      HIP_TRY(hipGetLastError());
-    }
-    // ---- unresolved list of what is left
-    if (m0 > 0) {
-      k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
-          tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
-      HIP_TRY(hipGetLastError());
-    }
-    // ---- pairs in the wrong order change places (and ranks, where a table exists)
-    if (rank_building) HIP_TRY(hipStreamWaitEvent(st, c->ev_rank_done, 0));
-    if (npairs > 0) {
-      k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, rank,
-                                                               index_offset);
-      HIP_TRY(hipGetLastError());
+      const GroupHeadValues headgen = {tiebits2, carry, nwords, 0u};
+      build_rank = [=, &rk_windows](bool first) -> int {
+        u64 nsel = 0;
+        if (rk_windows) {
+          k_win_select<<<1, 1024, 0, st>>>(w_need, w_built, nww, w_sel, w_list, c->d_stats);
+          HIP_TRY(hipGetLastError());
+          TRY(fetch_stats(c));
+          nsel = c->h_stats->count;
+          if (nsel == 0) return 0;
+          if (first && nsel * 2 > rk_nwin) rk_windows = false;   // most of the text: all of it
+          if (debug)
+            fprintf(stderr, "gtamd: rank table: %llu of %llu windows of 2^%d positions%s\n",
+                    (unsigned long long) nsel, (unsigned long long) rk_nwin, wb,
+                    rk_windows ? "" : " -> whole table");
+        }
+        if (!rk_windows) {
+          if (heads_array) {
+            k_heads<<<(u32) div_up(NL, 1024), 256, 0, st>>>(tiebits2, carry, NL, 0u, heads);
+            HIP_TRY(hipGetLastError());
+          }
+          const u32 *wpos = spos, *whead = heads;
+          if (pb > 8) {
+            const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;   // heads is dead by then
+            if (heads_array)
+              TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0,
+                                             &w0, 1, pws, st, nullptr, nullptr));
+            else
+              TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, st));
+            TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
+                                           nullptr, nullptr));
+            wpos = qpos; whead = qhead;
+          } else if (pb > 0) {
+            const int s0 = nb - pb, w0 = pb;
+            if (heads_array)
+              TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0,
+                                             &w0, 1, pws, st, nullptr, nullptr));
+            else
+              TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, st));
+            wpos = ppos; whead = phead;
+          }
+          const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
+          const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
+          k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank32,
+                                                     nullptr);
+          HIP_TRY(hipGetLastError());
+          return 0;
+        }
+        // the pairs of the selected windows, partitioned by window
+        const u32 nblk = (u32) div_up(NL, 256 * WF_PER);
+        u32 *fcnt = pcnt, *foff = poff;     // (the pair heads per word have been used)
+        k_win_count<<<nblk, 256, 0, st>>>(spos, NL, wb, w_sel, fcnt);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_SUM, fcnt, foff, nblk, false, scanws, st));
+        k_win_place<<<nblk, 256, 0, st>>>(spos, NL, wb, w_sel, foff, tiebits2, carry, ppos, phead);
+        HIP_TRY(hipGetLastError());
+        k_total<<<1, 1, 0, st>>>(foff, fcnt, nblk, c->d_stats);
+        HIP_TRY(hipGetLastError());
+        TRY(fetch_stats(c));
+        const u64 M = c->h_stats->count;   // nsel windows (the last one of the text is short)
+        const u32 *wpos = ppos, *whead = phead;
+        if (pb > 8) {
+          const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;
+          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, M, &s0, &w0, 1, pws, st,
+                                         nullptr, nullptr));
+          TRY(radix_sort_pairs<u32, u32>(qpos, qhead, ppos, phead, M, &s1, &w1, 1, pws, st,
+                                         nullptr, nullptr));
+        } else {
+          const int s0 = nb - pb, w0 = pb;
+          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, M, &s0, &w0, 1, pws, st,
+                                         nullptr, nullptr));
+          wpos = qpos; whead = qhead;
+        }
+        const u32 grid = split == 2 ? (((u32) nsel + 7u) / 8u) * 16u : (u32) nsel;
+        k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, N, wb, split, (u32) nsel, rank32,
+                                                   w_list);
+        HIP_TRY(hipGetLastError());
+        return 0;
+      };
+      TRY(build_rank(true));
     }
     std::vector<u64> qcounts(R), ucounts(R), zero(R, 0);
     std::vector<u64> gathered((size_t) R * (2 * R + 1)), mine(2 * R + 1);
@@ -3214,6 +3420,15 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         h *= 2;
         HIP_TRY(hipMemsetAsync(c->d_counts, 0, 2 * DEST_MAXPARTS * 4, st));
         continue;
+      }
+      if (rk_windows && h > rk_h0) {
+        // an offset beyond the windows built so far?  then build what it reaches
+        HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, 4, st));
+        k_win_check<P><<<(u32) div_up(m, 256), 256, 0, st>>>(upos, m, h, rk_wb, rk_nwin, w_built,
+                                                           w_need, c->d_stats);
+        HIP_TRY(hipGetLastError());
+        TRY(fetch_stats(c));
+        if (c->h_stats->count2 != 0) TRY(build_rank(false));
       }
       const u32 g = (u32) div_up(m, 256);
       const u32 ntiles = (u32) div_up(m, RT_TILE);

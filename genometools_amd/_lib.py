@@ -127,12 +127,12 @@ ABI = {
     "gtamd_encoder_file_lengths": (_INT, [_P, ctypes.c_size_t, ctypes.POINTER(_U64),
                                           ctypes.POINTER(_U64)]),
     "gtamd_encoder_num_descriptions": (_U64, [_P]),
-    "gtamd_encoder_get_descriptions": (_INT, [_P, _P, _P, _P]),
-    "gtamd_encoder_pack_twobit": (_INT, [_P, _INT, ctypes.c_uint, _P]),
-    "gtamd_encoder_pack_specialbits": (_INT, [_P, _P]),
-    "gtamd_encoder_pack_bytecompress": (_INT, [_P, _P]),
-    "gtamd_encoder_get_wildcard_runs": (_INT, [_P, _P, _P]),
-    "gtamd_encoder_get_separators": (_INT, [_P, _P]),
+    "gtamd_encoder_get_descriptions": (_INT, [_P, _P, _P, _P, _U64]),
+    "gtamd_encoder_pack_twobit": (_INT, [_P, _INT, ctypes.c_uint, _P, _U64]),
+    "gtamd_encoder_pack_specialbits": (_INT, [_P, _P, _U64]),
+    "gtamd_encoder_pack_bytecompress": (_INT, [_P, _P, _U64]),
+    "gtamd_encoder_get_wildcard_runs": (_INT, [_P, _P, _P, _U64]),
+    "gtamd_encoder_get_separators": (_INT, [_P, _P, _U64]),
     "gtamd_encoder_get_timing": (_INT, [_P, ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_float),

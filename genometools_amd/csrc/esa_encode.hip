@@ -602,12 +602,13 @@ static int encode_files(gtamd_encoder *e, u8 *d_raw, u8 *d_lut, u32 *d_tile,
     TRY(scan_u32(SCAN_SUM, t_descs, t_doff, ntiles, false, d_ws, e->st));
     FaGlobals got;
     u32 last[4];   // last tile: offsets and counts
-    HIP_TRY(hipMemcpyAsync(&got, d_glob, sizeof got, hipMemcpyDeviceToHost, e->st));
-    HIP_TRY(hipMemcpyAsync(&last[0], t_soff + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
-    HIP_TRY(hipMemcpyAsync(&last[1], t_syms + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
-    HIP_TRY(hipMemcpyAsync(&last[2], t_doff + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
-    HIP_TRY(hipMemcpyAsync(&last[3], t_descs + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st));
+    // (blocking copies: the destinations are on this stack frame)
     HIP_TRY(hipStreamSynchronize(e->st));
+    HIP_TRY(hipMemcpy(&got, d_glob, sizeof got, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last[0], t_soff + ntiles - 1, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last[1], t_syms + ntiles - 1, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last[2], t_doff + ntiles - 1, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&last[3], t_descs + ntiles - 1, 4, hipMemcpyDeviceToHost));
     if (got.first_illegal != NONE64) {
       // wording of src/core/sequence_buffer_inline.h:37-41
       gtamd_set_error("illegal character '%c': file \"%s\", line %llu",
@@ -667,11 +668,14 @@ static int summarise(gtamd_encoder *e) {
     k_empty_sequence<<<(u32) div_up(n, 256), 256, 0, e->st>>>(e->d_enc, n, d_small + 32);
     k_run_summary<<<(u32) ntiles, EN_THREADS, 0, e->st>>>(e->d_enc, n, d_tiles, d_small);
     if (hipGetLastError() != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(tiles.data(), d_tiles, tiles.size() * sizeof(RunSum<u32>),
-                       hipMemcpyDeviceToHost, e->st) != hipSuccess) { rc = -1; break; }
-    if (hipMemcpyAsync(small, d_small, sizeof small, hipMemcpyDeviceToHost, e->st) != hipSuccess) { rc = -1; break; }
+    // blocking copies: the destinations are pageable (a vector, the stack) and
+    // gone when this function returns
     if (hipStreamSynchronize(e->st) != hipSuccess) { rc = -1; break; }
+    if (hipMemcpy(tiles.data(), d_tiles, tiles.size() * sizeof(RunSum<u32>),
+                  hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
+    if (hipMemcpy(small, d_small, sizeof small, hipMemcpyDeviceToHost) != hipSuccess) { rc = -1; break; }
   } while (0);
+  (void) hipStreamSynchronize(e->st);   // on every exit: nothing in flight behind this frame
   (void) hipFree(d_tiles);
   (void) hipFree(d_small);
   if (rc != 0) { gtamd_set_error("device statistics of the encoded sequence failed"); return -1; }
@@ -869,9 +873,19 @@ extern "C" uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *e) {
   return e != nullptr && e->finished ? e->ndesc : 0;
 }
 
+// the caller's arrays hold `capacity` entries: more would be written -> error
+static int check_capacity(const char *what, u64 needed, u64 capacity) {
+  if (needed <= capacity) return 0;
+  gtamd_set_error("%s: %llu entries do not fit the caller's %llu", what,
+                  (unsigned long long) needed, (unsigned long long) capacity);
+  return -1;
+}
+
 extern "C" int gtamd_encoder_get_descriptions(const gtamd_encoder *e, uint32_t *file,
-                                              uint64_t *start, uint64_t *end) {
+                                              uint64_t *start, uint64_t *end,
+                                              uint64_t capacity) {
   TRY(need_finished(e));
+  TRY(check_capacity("descriptions", e->ndesc, capacity));
   HIP_TRY(hipSetDevice(e->device));
   if (e->ndesc == 0) return 0;
   HIP_TRY(hipMemcpy(start, e->d_desc_start, e->ndesc * 8, hipMemcpyDeviceToHost));
@@ -907,10 +921,12 @@ static int launch_1d(u64 items, u32 *blocks) {
 }
 
 extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
-                                         unsigned fillcode, uint64_t *words) {
+                                         unsigned fillcode, uint64_t *words,
+                                         uint64_t capacity) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 units = e->n < 32 ? 2 : 2 + (e->n - 1) / 32;
+  TRY(check_capacity("two-bit encoding", units, capacity));
   u64 *d;
   u32 blocks;
   TRY(dev_alloc(&d, units));
@@ -918,8 +934,8 @@ extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
   if (rc == 0) {
     k_esq_twobit<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, units, bitaccess, fillcode & 3, d);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(words, d, units * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipStreamSynchronize(e->st) != hipSuccess) {
+        hipStreamSynchronize(e->st) != hipSuccess ||
+        hipMemcpy(words, d, units * 8, hipMemcpyDeviceToHost) != hipSuccess) {
       gtamd_set_error("packing the two-bit encoding on the device failed");
       rc = -1;
     }
@@ -928,10 +944,12 @@ extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
   return rc;
 }
 
-extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *words) {
+extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *words,
+                                              uint64_t capacity) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 units = 1 + (e->n + 63) / 64;
+  TRY(check_capacity("special bits", units, capacity));
   u64 *d;
   u32 blocks;
   TRY(dev_alloc(&d, units));
@@ -939,8 +957,8 @@ extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *
   if (rc == 0) {
     k_esq_specialbits<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, units, d);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(words, d, units * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipStreamSynchronize(e->st) != hipSuccess) {
+        hipStreamSynchronize(e->st) != hipSuccess ||
+        hipMemcpy(words, d, units * 8, hipMemcpyDeviceToHost) != hipSuccess) {
       gtamd_set_error("packing the special bits on the device failed");
       rc = -1;
     }
@@ -949,11 +967,13 @@ extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *
   return rc;
 }
 
-extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *bytes) {
+extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *bytes,
+                                               uint64_t capacity) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u32 sigma = e->sigma, bits = e->packbits;
   const u64 nbytes = ((u64) bits * e->n + 7) / 8;
+  TRY(check_capacity("bit-packed symbols", nbytes, capacity));
   u8 *d;
   u32 blocks;
   TRY(dev_alloc(&d, nbytes));
@@ -961,8 +981,8 @@ extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *
   if (rc == 0) {
     k_esq_bitpack<<<blocks, 256, 0, e->st>>>(e->d_enc, e->n, sigma, bits, nbytes, d);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(bytes, d, nbytes, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipStreamSynchronize(e->st) != hipSuccess) {
+        hipStreamSynchronize(e->st) != hipSuccess ||
+        hipMemcpy(bytes, d, nbytes, hipMemcpyDeviceToHost) != hipSuccess) {
       gtamd_set_error("bit-packing the symbols on the device failed");
       rc = -1;
     }
@@ -987,9 +1007,9 @@ static int positions_to_host(const gtamd_encoder *e, int kind, u64 expected, u64
     if (hipGetLastError() != hipSuccess) { gtamd_set_error("k_positions launch failed"); break; }
     if (scan_u32(SCAN_SUM, d_cnt, d_cnt + ntiles, ntiles, false, d_ws, e->st) != 0) break;
     u32 last[2];
-    if (hipMemcpyAsync(&last[0], d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipMemcpyAsync(&last[1], d_cnt + 2 * ntiles - 1, 4, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipStreamSynchronize(e->st) != hipSuccess) {
+    if (hipStreamSynchronize(e->st) != hipSuccess ||
+        hipMemcpy(&last[0], d_cnt + ntiles - 1, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&last[1], d_cnt + 2 * ntiles - 1, 4, hipMemcpyDeviceToHost) != hipSuccess) {
       gtamd_set_error("reading position counts from the device failed");
       break;
     }
@@ -1001,8 +1021,8 @@ static int positions_to_host(const gtamd_encoder *e, int kind, u64 expected, u64
     k_positions<1><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(e->d_enc, e->n, kind, nullptr,
                                                           d_cnt + ntiles, d_out);
     if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(out, d_out, expected * 8, hipMemcpyDeviceToHost, e->st) != hipSuccess ||
-        hipStreamSynchronize(e->st) != hipSuccess) {
+        hipStreamSynchronize(e->st) != hipSuccess ||
+        hipMemcpy(out, d_out, expected * 8, hipMemcpyDeviceToHost) != hipSuccess) {
       gtamd_set_error("collecting positions on the device failed");
       break;
     }
@@ -1015,18 +1035,21 @@ static int positions_to_host(const gtamd_encoder *e, int kind, u64 expected, u64
 }
 
 extern "C" int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *e, uint64_t *start,
-                                               uint64_t *length) {
+                                               uint64_t *length, uint64_t capacity) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 runs = e->sum.realwildcardranges;
+  TRY(check_capacity("wildcard runs", runs, capacity));
   TRY(positions_to_host(e, POS_WILDCARD_START, runs, start));
   TRY(positions_to_host(e, POS_WILDCARD_END, runs, length));
   for (u64 r = 0; r < runs; r++) length[r] = length[r] - start[r] + 1;
   return 0;
 }
 
-extern "C" int gtamd_encoder_get_separators(const gtamd_encoder *e, uint64_t *pos) {
+extern "C" int gtamd_encoder_get_separators(const gtamd_encoder *e, uint64_t *pos,
+                                            uint64_t capacity) {
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
+  TRY(check_capacity("separators", e->sum.numofsequences - 1, capacity));
   return positions_to_host(e, POS_SEPARATOR, e->sum.numofsequences - 1, pos);
 }

@@ -2174,6 +2174,9 @@ struct gtamd_esa_ctx {
   u64 bck_codes, bck_special, bck_dist;
   Stats *d_stats, *h_stats;   // h_stats: pinned host mirror
   u32 *h_counts;              // pinned: per-part counters read back per round
+  u32 *h_hist;                // pinned: key-bin histogram of the own tile
+  // (every asynchronous device-to-host copy of the engine lands in pinned memory
+  // the context owns, never on a stack frame or in a container that goes away)
   u32 user_prefixlength;   // 0 = automatic
   // part build (lexicographic range `part` of `numparts`)
   u32 part, numparts;
@@ -2235,6 +2238,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
   if (c->h_stats != nullptr) (void) hipHostFree(c->h_stats);
   if (c->h_counts != nullptr) (void) hipHostFree(c->h_counts);
+  if (c->h_hist != nullptr) (void) hipHostFree(c->h_hist);
   for (auto &e : c->ev) if (e != nullptr) (void) hipEventDestroy(e);
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
   if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
@@ -2302,6 +2306,7 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
   CTX_TRY(hipHostMalloc(&c->h_counts, 4 * DEST_MAXPARTS * 4, hipHostMallocDefault));
+  CTX_TRY(hipHostMalloc(&c->h_hist, PART_BINS * 4, hipHostMallocDefault));
   CTX_TRY(hipMalloc(&c->d_parthist, PART_BINS * 4));
   CTX_TRY(hipMalloc(&c->d_owner, PART_BINS));
   CTX_TRY(hipMalloc(&c->d_counts, 4 * DEST_MAXPARTS * 4));
@@ -2709,7 +2714,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     }
     // range cuts from a histogram of the key bins over every 16th suffix: every
     // part counts its own tile, the sum is the same on every part
-    std::vector<u32> hist(PART_BINS, 0u), allhist((size_t) PART_BINS * R);
+    std::vector<u32> allhist((size_t) PART_BINS * R);
+    u32 *hist = c->h_hist;
+    memset(hist, 0, PART_BINS * 4);
     if (!fail) {
       const u64 stride = N > (1u << 24) ? 16 : 1;
       HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
@@ -2717,8 +2724,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, first, end, stride, c->d_parthist);
         HIP_TRY(hipGetLastError());
       }
-      HIP_TRY(hipMemcpyAsync(hist.data(), c->d_parthist, PART_BINS * 4,
-                             hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(hist, c->d_parthist, PART_BINS * 4, hipMemcpyDeviceToHost, st));
       // the keys of the tile, meanwhile
       if (Tn > 0) {
         if (BITS == 2)
@@ -2731,7 +2737,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       }
       HIP_TRY(hipStreamSynchronize(st));
     }
-    TRY(comm_allgather(c, fail, hist.data(), allhist.data(), PART_BINS * 4));
+    TRY(comm_allgather(c, fail, hist, allhist.data(), PART_BINS * 4));
     std::vector<u64> start(PART_BINS + 1);
     start[0] = 0;
     for (int b = 0; b < PART_BINS; b++) {
@@ -2875,9 +2881,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   int has_prev = 0;
   if (R > 1) {
     u64 mine[2] = {NL, 0};
-    if (NL > 0)
-      HIP_TRY(hipMemcpyAsync(&mine[1], skey + (NL - 1), 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (NL > 0)   // (blocking copy: the destination is on this stack frame)
+      HIP_TRY(hipMemcpy(&mine[1], skey + (NL - 1), 8, hipMemcpyDeviceToHost));
     std::vector<u64> all(2 * (size_t) R);
     TRY(comm_allgather(c, 0, mine, all.data(), 16));
     for (u32 r = 0; r < c->part; r++)

@@ -90,7 +90,7 @@ int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
     dfile = malloc(4 * (ndesc + 1)); dstart = malloc(8 * (ndesc + 1));
     dend = malloc(8 * (ndesc + 1));
     if (dfile == NULL || dstart == NULL || dend == NULL) goto nomem;
-    if (gtamd_encoder_get_descriptions(de, dfile, dstart, dend) != 0) goto deverr;
+    if (gtamd_encoder_get_descriptions(de, dfile, dstart, dend, ndesc + 1) != 0) goto deverr;
     for (uint64_t k = 0; k < ndesc; k++) total += dend[k] - dstart[k] + 1;
     if ((dbuf = malloc(total + 1)) == NULL) goto nomem;
     for (uint64_t k = 0; k < ndesc; k++) {
@@ -155,26 +155,27 @@ int gtamd_write_esq_device_alpha(const char *indexname, const char *const *paths
   }
   if (need_pk) {
     if ((packed = malloc((a->bitspersymbol * n + 7) / 8 + 1)) == NULL) goto nomem;
-    if (gtamd_encoder_pack_bytecompress(enc, packed) != 0) goto deverr;
+    if (gtamd_encoder_pack_bytecompress(enc, packed, (a->bitspersymbol * n + 7) / 8 + 1) != 0) goto deverr;
   }
   if (need_tb) {
     if ((twobit = malloc(8 * (n < 32 ? 2 : 2 + (n - 1) / 32))) == NULL) goto nomem;
     if (gtamd_encoder_pack_twobit(enc, an.sat == GTAMD_SAT_BITACCESS,
-                                  gtamd_least_probable(&an), twobit) != 0) goto deverr;
+                                  gtamd_least_probable(&an), twobit,
+                                  n < 32 ? 2 : 2 + (n - 1) / 32) != 0) goto deverr;
   }
   if (need_sb) {
     if ((specialbits = malloc(8 * (1 + (n + 63) / 64))) == NULL) goto nomem;
-    if (gtamd_encoder_pack_specialbits(enc, specialbits) != 0) goto deverr;
+    if (gtamd_encoder_pack_specialbits(enc, specialbits, 1 + (n + 63) / 64) != 0) goto deverr;
   }
   if (need_wc) {
     wc_start = malloc(8 * (sum.realwildcardranges + 1));
     wc_len = malloc(8 * (sum.realwildcardranges + 1));
     if (wc_start == NULL || wc_len == NULL) goto nomem;
-    if (gtamd_encoder_get_wildcard_runs(enc, wc_start, wc_len) != 0) goto deverr;
+    if (gtamd_encoder_get_wildcard_runs(enc, wc_start, wc_len, sum.realwildcardranges + 1) != 0) goto deverr;
   }
   if (need_sep) {
     if ((seppos = malloc(8 * sum.numofsequences)) == NULL) goto nomem;
-    if (gtamd_encoder_get_separators(enc, seppos) != 0) goto deverr;
+    if (gtamd_encoder_get_separators(enc, seppos, sum.numofsequences) != 0) goto deverr;
   }
   sec.twobit = twobit; sec.specialbits = specialbits; sec.packed = packed;
   sec.plain = plain;

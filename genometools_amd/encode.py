@@ -113,7 +113,7 @@ class DeviceEncoder:
         start = np.empty(k, dtype=np.uint64)
         end = np.empty(k, dtype=np.uint64)
         self._check(self._lib.gtamd_encoder_get_descriptions(
-            self._enc, file.ctypes.data, start.ctypes.data, end.ctypes.data))
+            self._enc, file.ctypes.data, start.ctypes.data, end.ctypes.data, k))
         return [self._buffers[f][1][int(a):int(b)].tobytes().replace(b"\r", b"")
                 for f, a, b in zip(file, start, end)]
 

@@ -90,10 +90,12 @@ int gtamd_encoder_file_lengths(const gtamd_encoder *enc, size_t file,
 /* Descriptions: one per sequence, as byte ranges [start, end) of the file they
    came from (start is behind the '>', end is the terminating newline or the
    end of the file; a carriage return inside is the caller's to drop, as the
-   reference does).  Arrays of gtamd_encoder_num_descriptions() entries. */
+   reference does).  The arrays hold `capacity` entries each;
+   gtamd_encoder_num_descriptions() are written, -1 if that is more. */
 uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *enc);
 int gtamd_encoder_get_descriptions(const gtamd_encoder *enc, uint32_t *file,
-                                   uint64_t *start, uint64_t *end);
+                                   uint64_t *start, uint64_t *end,
+                                   uint64_t capacity);
 
 /* The sections of INDEX.esq behind its header, built from the symbols in HBM
    and delivered to host memory (layouts: src/core/encseq.c:85-99, 2594-2607,
@@ -108,14 +110,21 @@ int gtamd_encoder_get_descriptions(const gtamd_encoder *enc, uint32_t *file,
                         creation (5 protein, 3 DNA), wildcard = sigma,
                         separator = sigma + 1
      wildcard_runs      the realwildcardranges maximal runs (start, length)
-     separators         the numofsequences - 1 separator positions */
+     separators         the numofsequences - 1 separator positions
+   `capacity` is the size of the caller's array(s) in entries (words, bytes,
+   runs, positions): nothing is written and -1 returned if the section is
+   larger. */
 int gtamd_encoder_pack_twobit(const gtamd_encoder *enc, int bitaccess,
-                              unsigned fillcode, uint64_t *words);
-int gtamd_encoder_pack_specialbits(const gtamd_encoder *enc, uint64_t *words);
-int gtamd_encoder_pack_bytecompress(const gtamd_encoder *enc, uint8_t *bytes);
+                              unsigned fillcode, uint64_t *words,
+                              uint64_t capacity);
+int gtamd_encoder_pack_specialbits(const gtamd_encoder *enc, uint64_t *words,
+                                   uint64_t capacity);
+int gtamd_encoder_pack_bytecompress(const gtamd_encoder *enc, uint8_t *bytes,
+                                    uint64_t capacity);
 int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *enc, uint64_t *start,
-                                    uint64_t *length);
-int gtamd_encoder_get_separators(const gtamd_encoder *enc, uint64_t *pos);
+                                    uint64_t *length, uint64_t capacity);
+int gtamd_encoder_get_separators(const gtamd_encoder *enc, uint64_t *pos,
+                                 uint64_t capacity);
 
 /* device time of the last finish (ms, HIP events) and the bytes it read */
 int gtamd_encoder_get_timing(const gtamd_encoder *enc, float *total_ms,

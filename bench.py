@@ -9,24 +9,30 @@ its packed form.  N=1 workload: BASELINE.json configs[2], 3 Gbp human-like DNA
 (genometools_amd.synth MODEL_HUMANLIKE_DNA, seed 43), -suf -lcp -bwt.
 
 N>1 (one process per GPU, torch.distributed / RCCL): the SAME sequence is
-replicated on every GPU and the suffix array is sharded into N lexicographic
-ranges (the reference's -parts idea); rank r builds slice r of every table.
-The only data-path exchange is the rank lookup of the prefix-doubling rounds
-(alltoallv of 4-byte queries and answers over xGMI).  Total work is fixed, so
-the line says "scaling": "strong" and value = n / (max over ranks of the step
-time).
+replicated on every GPU (750 MB packed) and the suffix array is sharded into N
+lexicographic ranges (the reference's -parts idea); rank r builds slice r of
+every table.  Per-rank work falls with N: a rank makes the keys of its 1/N text
+tile and alltoallv's the (key, position) pairs to the range owners; the rank
+table of the doubling rounds is cut by text position (queries, answers and new
+ranks by alltoallv over xGMI, enqueued on the engine's stream).  Total work is
+fixed, so the line says "scaling": "strong" and value = n / (max over ranks of
+the step time).
 
 The JSON line carries, besides the contract fields:
   roofline      the dominant kernel (radix scatter pass): algorithmic bytes per
                 launch (24 B per (key,position) pair moved: 12 in + 12 out)
                 / average launch duration measured with HIP events on the
-                engine's stream; `job` = whole-build bytes (10.25 B/bp,
-                SURVEY.md 8d) / step time.
+                engine's stream; `traffic` = HBM bytes per launch from the PMC
+                counters (profiles/traffic.json, only if it was measured on
+                this revision of the kernel source, else null).
+  job_frac      SURVEY.md 8d's own figure: whole-build compulsory bytes
+                (10.25 B/bp) / step time / (8 TB/s x GPUs).
   cpu_baseline  the reference's own engine (oracle/_ref/gt_ref_sfx, kind
                 "reference") or the CPU restatement (kind "port") timed on
                 this host's cores on a bounded sample of the same model.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -168,12 +174,17 @@ def main():
         value = n / (dt / a.steps) / 1e9
         sc_avg_s = sc_ms / max(sc_launches, 1) / 1e3
         achieved = SCATTER_BYTES_PER_PAIR * pairs_per_launch / sc_avg_s / 1e9
+        # PMC traffic of the scatter kernel: only a measurement of THIS kernel
+        # source counts (tools/pmc_summary.py stamps the file with its hash)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and world == 1:
             with open(tf) as f:
                 tj = json.load(f)
-            if tj.get("n") == n and tj.get("model") == a.model:
+            with open(os.path.join(ROOT, "genometools_amd", "csrc", "esa_prims.hip"), "rb") as f:
+                src = hashlib.sha256(f.read()).hexdigest()
+            if (tj.get("n") == n and tj.get("model") == a.model
+                    and tj.get("kernel_source_sha256") == src):
                 traffic = tj.get("scatter_hbm_bytes_per_launch")
         line = {
             "metric": "Gbp/s ESA build (suf+lcp+bwt), 3 Gbp DNA, 1/2/4/8 MI355X; bit-exact vs CPU",
@@ -181,12 +192,17 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "%s n=%d seed=%d -suf -lcp -bwt (BASELINE.json configs[2])"
+            "config": {"workload": "%s n=%d seed=%d -suf -lcp -bwt (BASELINE.json %s)"
                                    % ({0: "uniform DNA", 1: "human-like DNA (2% N, 24 seqs, repeats)",
-                                       2: "protein"}[a.model], n, a.seed),
+                                       2: "protein"}[a.model], n, a.seed,
+                                      {0: "configs[1] shape", 1: "configs[2]",
+                                       2: "configs[4] shape"}[a.model]),
                        "parallelism": "1 device" if world == 1 else
-                                      "%d lexicographic range parts, sequence replicated, "
-                                      "rank lookups by alltoallv" % world,
+                                      "%d lexicographic range parts: each rank keys its text "
+                                      "tile, alltoallv of pairs to the range owners, rank "
+                                      "table cut by position (alltoallv queries/answers/"
+                                      "updates)" % world,
+                       "pair_suffixes": st.get("pair_suffixes", 0),
                        "xgmi_bytes_per_step": exchanged / max(a.steps + a.warmup, 1),
                        "tied_suffixes": st["tied_suffixes"],
                        "refine_rounds": st["refine_rounds"],
@@ -197,11 +213,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": sc_avg_s * 1e3,
                          "launches_per_step": sc_launches // max(a.steps, 1),
+                         "job_frac": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world),
                          "job": {"achieved": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9,
                                  "frac": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world),
                                  "bytes_per_bp": JOB_BYTES_PER_BP,
                                  "device_ms_per_step": total_dev_ms / a.steps}},
         }
+        line["job_frac"] = line["roofline"]["job_frac"]
         if not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.model, a.seed, int(a.cpu_sample))
         print(json.dumps(line), flush=True)

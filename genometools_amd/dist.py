@@ -156,13 +156,14 @@ def combine_stats(stats, device, group=None):
     if dev.type != "cpu" and dist.get_backend(group) == "gloo":
         dev = torch.device("cpu")
     s = torch.tensor([stats["lcptabsum"], stats["largelcpvalues"], stats["longest"],
-                      stats["tied_suffixes"]], dtype=torch.int64, device=dev)
+                      stats["tied_suffixes"], stats.get("pair_suffixes", 0)],
+                     dtype=torch.int64, device=dev)
     m = torch.tensor([stats["maxbranchdepth"], stats["refine_rounds"]],
                      dtype=torch.int64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
     dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
     out = dict(stats)
-    out["lcptabsum"], out["largelcpvalues"], out["longest"], out["tied_suffixes"] = \
-        [int(x) for x in s.tolist()]
+    (out["lcptabsum"], out["largelcpvalues"], out["longest"], out["tied_suffixes"],
+     out["pair_suffixes"]) = [int(x) for x in s.tolist()]
     out["maxbranchdepth"], out["refine_rounds"] = [int(x) for x in m.tolist()]
     return out

@@ -2213,10 +2213,14 @@ static int ensure_buf(gtamd_esa_ctx *c, DevBuf &b, u64 bytes, const char *what) 
   if (hipMalloc(&b.p, bytes) != hipSuccess) {
     (void) hipGetLastError();
     b.p = nullptr;
-    gtamd_set_error("cannot allocate %llu bytes of device memory for %s (the "
-                    "context holds %llu bytes already)",
+    size_t mfree = 0, mtotal = 0;
+    (void) hipMemGetInfo(&mfree, &mtotal);
+    gtamd_set_error("cannot allocate %llu bytes of device memory for %s: the "
+                    "context holds %llu bytes already, %llu of the device's %llu "
+                    "are free",
                     (unsigned long long) bytes, what,
-                    (unsigned long long) c->alloc_bytes);
+                    (unsigned long long) c->alloc_bytes, (unsigned long long) mfree,
+                    (unsigned long long) mtotal);
     return -1;
   }
   b.bytes = bytes;
@@ -3228,18 +3232,17 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           if (pb > 8) {
             const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;   // heads is dead by then
             if (heads_array)
-              TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0,
-                                             &w0, 1, pws, st, nullptr, nullptr));
+              TRY(radix_partition_u32(spos, heads, ppos, phead, NL, s0, w0, pws, st));
             else
               TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, w0, pws, st));
+            // (the second pass has to keep the first one's grouping: the sort's stable pass)
             TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, NL, &s1, &w1, 1, pws, st,
                                            nullptr, nullptr));
             wpos = qpos; whead = qhead;
           } else if (pb > 0) {
             const int s0 = nb - pb, w0 = pb;
             if (heads_array)
-              TRY(radix_sort_pairs<u32, u32>(const_cast<u32 *>(spos), heads, ppos, phead, NL, &s0,
-                                             &w0, 1, pws, st, nullptr, nullptr));
+              TRY(radix_partition_u32(spos, heads, ppos, phead, NL, s0, w0, pws, st));
             else
               TRY(radix_pass_group_heads(spos, headgen, ppos, phead, NL, s0, pb, pws, st));
             wpos = ppos; whead = phead;
@@ -3266,14 +3269,12 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         const u32 *wpos = ppos, *whead = phead;
         if (pb > 8) {
           const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;
-          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, M, &s0, &w0, 1, pws, st,
-                                         nullptr, nullptr));
+          TRY(radix_partition_u32(ppos, phead, qpos, qhead, M, s0, w0, pws, st));
           TRY(radix_sort_pairs<u32, u32>(qpos, qhead, ppos, phead, M, &s1, &w1, 1, pws, st,
                                          nullptr, nullptr));
         } else {
           const int s0 = nb - pb, w0 = pb;
-          TRY(radix_sort_pairs<u32, u32>(ppos, phead, qpos, qhead, M, &s0, &w0, 1, pws, st,
-                                         nullptr, nullptr));
+          TRY(radix_partition_u32(ppos, phead, qpos, qhead, M, s0, w0, pws, st));
           wpos = qpos; whead = qhead;
         }
         const u32 grid = split == 2 ? (((u32) nsel + 7u) / 8u) * 16u : (u32) nsel;

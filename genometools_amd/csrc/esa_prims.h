@@ -50,3 +50,12 @@ struct GroupHeadValues {
 int radix_pass_group_heads(const u32 *keys_a, GroupHeadValues gen, u32 *keys_b,
                            u32 *vals_b, u64 n, int shift, int width, u32 *ws,
                            hipStream_t st);
+
+// One UNSTABLE partition pass of (u32, u32) pairs on (key >> shift) & ((1 <<
+// width) - 1): pairs of one digit end up together, in any order (LDS atomics
+// instead of the ballot ranking: bound by bandwidth, not by instructions).  For
+// the FIRST partition pass of the rank-table build, whose keys are positions
+// in no order that matters (a second pass on higher bits has to be a stable
+// one).  radix_pass_group_heads partitions this way too.
+int radix_partition_u32(const u32 *keys_a, const u32 *vals_a, u32 *keys_b, u32 *vals_b, u64 n,
+                        int shift, int width, u32 *ws, hipStream_t st);

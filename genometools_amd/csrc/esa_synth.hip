@@ -30,6 +30,10 @@ struct SynthParams {
   u64 n, nblocks;
   u64 sep[23];
   int nsep;
+  // MODEL_REPEAT_HEAVY: share of duplicated blocks (of 65536), satellite arrays
+  u32 dup_t;
+  int nsat;
+  u64 sat_start[4], sat_len[4], sat_per[4];
 };
 
 __constant__ u32 c_mut_thr[4] = {0u, 4294967u, 42949673u, 214748365u};
@@ -58,8 +62,11 @@ __device__ u8 sym_humanlike(const SynthParams &P, u64 p) {
     const u64 ns = (hn >> 16) & 8191ull, nl = c_nrun_len[(hn >> 32) & 15];
     if (o >= ns && o < ns + nl) return (u8) GTAMD_WILDCARD;
   }
+  for (int k = 0; k < P.nsat; k++)
+    if (p >= P.sat_start[k] && p < P.sat_start[k] + P.sat_len[k])
+      return (u8) bg(P.key[0], (1ull << 40) + 4096ull * k + (p - P.sat_start[k]) % P.sat_per[k]);
   const u32 kind = (u32) (hx(P.key[1], b) & 0xFFFFull);
-  if (kind < 6554u) {
+  if (kind < P.dup_t) {
     const u64 h2 = hx(P.key[2], b);
     const u64 src = (h2 & 7) == 0 ? ((h2 >> 8) & 15) : ((h2 >> 8) % P.nblocks);
     const u32 thr = c_mut_thr[(h2 >> 3) & 3];
@@ -68,7 +75,7 @@ __device__ u8 sym_humanlike(const SynthParams &P, u64 p) {
     if ((u32) (hm & 0xFFFFFFFFull) < thr) c = (c + 1 + (u32) ((hm >> 32) % 3)) & 3u;
     return (u8) c;
   }
-  if (kind < 6554u + 64u) {
+  if (kind < P.dup_t + 64u) {
     const u64 h2 = hx(P.key[2], b);
     const u64 per = 1 + ((h2 >> 40) % 6), so = (h2 >> 8) & 4095,
               tl = 64 + ((h2 >> 20) & 2047);
@@ -104,7 +111,8 @@ __global__ __launch_bounds__(256) void k_synth(SynthParams P, u8 *__restrict__ d
     u8 s = 0;
     if (p < P.n)
       s = MODEL == 0 ? sym_uniform(P, p)
-                     : (MODEL == 1 ? sym_humanlike(P, p) : sym_protein(P, p));
+                     : (MODEL == 1 ? sym_humanlike(P, p) : sym_protein(P, p));   // (1: also the
+                                                      // repeat-heavy parameters)
     word |= (u32) s << (8 * c);
   }
   if (p0 + 4 <= P.n) *reinterpret_cast<u32 *>(dst + p0) = word;
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(256) void k_synth(SynthParams P, u8 *__restrict__ d
 
 extern "C" int gtamd_synth_bytes(int device, int model, uint64_t seed,
                                  uint64_t n, uint8_t *dst_device) {
-  if (model < 0 || model > 2) {
+  if (model < 0 || model > 3) {
     gtamd_set_error("unknown synthetic model %d", model);
     return -1;
   }
@@ -128,14 +136,25 @@ extern "C" int gtamd_synth_bytes(int device, int model, uint64_t seed,
   P.n = n;
   P.nblocks = (n + 8191) >> 13;
   P.nsep = 0;
-  if (model == 1 && n >= 65536) {
+  P.dup_t = model == 3 ? 32768u : 6554u;
+  if (model == 3) {
+    const u64 sat_len[4] = {100000, 250000, 500000, 1000000};
+    const u64 sat_per[4] = {171, 5, 42, 68};
+    P.nsat = n >= (1ull << 24) ? 4 : (n >= (1ull << 16) ? 2 : 0);
+    for (int k = 0; k < P.nsat; k++) {
+      P.sat_start[k] = (u64) (((unsigned __int128) n * (2 * k + 1)) / 9);
+      P.sat_len[k] = n / 40 < sat_len[k] ? n / 40 : sat_len[k];
+      P.sat_per[k] = sat_per[k];
+    }
+  }
+  if ((model == 1 || model == 3) && n >= 65536) {
     for (int i = 0; i < 23; i++)
       P.sep[i] = (u64) (((unsigned __int128) n * h_chrom_cum[i]) >> 16);
     P.nsep = 23;
   }
   const u32 grid = (u32) div_up(div_up(n, 4), 256);
   if (model == 0) k_synth<0><<<grid, 256>>>(P, dst_device);
-  else if (model == 1) k_synth<1><<<grid, 256>>>(P, dst_device);
+  else if (model == 1 || model == 3) k_synth<1><<<grid, 256>>>(P, dst_device);
   else k_synth<2><<<grid, 256>>>(P, dst_device);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());

@@ -19,6 +19,13 @@ Models:
                          isolated IUPAC wildcards at rate 2^-18; 24 sequences
                          (23 separators) with the length proportions of the
                          human chromosomes when n >= 65536.
+  MODEL_REPEAT_HEAVY (3) the hard case for prefix doubling: the human-like model
+                         with HALF of the 8192-base blocks copies of other
+                         blocks (same family share and mutation levels) and up
+                         to four satellite arrays -- exact tandem repeats of
+                         period 171 / 5 / 42 / 68 over 100 000 to 1 000 000
+                         bases (capped at n/40) -- so that LCP values reach
+                         10^5..10^6 and the refinement needs 14-16 rounds.
   MODEL_PROTEIN (2)      i.i.d. residues with Swiss-Prot-like frequencies over
                          LVIFKREDAGSTNQYWPHMC (codes 0..19), sequences of mean
                          length ~330 (separator probability 1/331, never two
@@ -29,6 +36,7 @@ import numpy as np
 MODEL_UNIFORM_DNA = 0
 MODEL_HUMANLIKE_DNA = 1
 MODEL_PROTEIN = 2
+MODEL_REPEAT_HEAVY = 3
 
 WILDCARD = 254
 SEPARATOR = 255
@@ -40,6 +48,10 @@ _M2 = np.uint64(0x94D049BB133111EB)
 BLK_SHIFT = 13
 BLK = 1 << BLK_SHIFT
 DUP_T = 6554
+DUP_T_HEAVY = 32768
+SAT_LEN = (100000, 250000, 500000, 1000000)
+SAT_PER = (171, 5, 42, 68)
+SAT_BASE = 1 << 40
 TANDEM_T = 64
 NRUN_T = 10748
 MUT_THR = (0, 4294967, 42949673, 214748365)
@@ -81,7 +93,7 @@ def _bg(k0, q):
 
 
 def separators(n):
-    """positions of the 23 separators of the human-like model"""
+    """positions of the 23 separators of the human-like models"""
     if n < 65536:
         return np.zeros(0, dtype=np.uint64)
     return np.array([(n * c) >> 16 for c in CHROM_CUM], dtype=np.uint64)
@@ -91,7 +103,17 @@ def _uniform(seed, n, lo, hi):
     return _bg(_stream_key(seed, 0), np.arange(lo, hi, dtype=np.uint64))
 
 
-def _humanlike(seed, n, lo, hi):
+def satellites(n):
+    """(start, length, period) of the satellite arrays of MODEL_REPEAT_HEAVY"""
+    nsat = 4 if n >= (1 << 24) else (2 if n >= (1 << 16) else 0)
+    return [((n * (2 * k + 1)) // 9, min(n // 40, SAT_LEN[k]), SAT_PER[k]) for k in range(nsat)]
+
+
+def _repeatheavy(seed, n, lo, hi):
+    return _humanlike(seed, n, lo, hi, DUP_T_HEAVY, satellites(n))
+
+
+def _humanlike(seed, n, lo, hi, dup_t=DUP_T, sats=()):
     p = np.arange(lo, hi, dtype=np.uint64)
     k = [_stream_key(seed, s) for s in range(6)]
     nblocks = np.uint64((n + BLK - 1) >> BLK_SHIFT)
@@ -103,8 +125,8 @@ def _humanlike(seed, n, lo, hi):
     kind = (_h(k[1], ub) & np.uint64(0xFFFF)).astype(np.int64)
     hb2 = _h(k[2], ub)
     hn = _h(k[4], ub)
-    is_dup = (kind < DUP_T)[inv]
-    is_tan = ((kind >= DUP_T) & (kind < DUP_T + TANDEM_T))[inv]
+    is_dup = (kind < dup_t)[inv]
+    is_tan = ((kind >= dup_t) & (kind < dup_t + TANDEM_T))[inv]
     hb2p = hb2[inv]
     out = _bg(k[0], p)
     # duplicated blocks
@@ -133,6 +155,13 @@ def _humanlike(seed, n, lo, hi):
         q = (b[d] << np.uint64(BLK_SHIFT)) + so + ((od - so) % per)
         c = _bg(k[0], np.where(inside, q, p[d]))
         out[d] = c
+    # satellite arrays (exact tandem repeats over 10^5..10^6 bases)
+    for si, (st, ln, per) in enumerate(sats):
+        a, b = max(lo, st), min(hi, st + ln)
+        if a < b:
+            q = np.uint64(SAT_BASE + 4096 * si) + \
+                (np.arange(a, b, dtype=np.uint64) - np.uint64(st)) % np.uint64(per)
+            out[a - lo:b - lo] = _bg(k[0], q)
     # N runs
     hnp = hn[inv]
     has = (hnp & np.uint64(0xFFFF)) < np.uint64(NRUN_T)
@@ -172,7 +201,7 @@ def generate(model, seed, n, lo=0, hi=None):
     if hi <= lo:
         return np.zeros(0, dtype=np.uint8)
     fn = {MODEL_UNIFORM_DNA: _uniform, MODEL_HUMANLIKE_DNA: _humanlike,
-          MODEL_PROTEIN: _protein}[model]
+          MODEL_PROTEIN: _protein, MODEL_REPEAT_HEAVY: _repeatheavy}[model]
     chunks = []
     step = 1 << 22
     for a in range(lo, hi, step):

@@ -76,6 +76,7 @@ def test_uniform_dna_small(gpu, n):
     (synth.MODEL_HUMANLIKE_DNA, 4, 600000, 3),
     (synth.MODEL_PROTEIN, 20, 50000, 4),
     (synth.MODEL_PROTEIN, 20, 400000, 5),
+    (synth.MODEL_REPEAT_HEAVY, 4, 300000, 6),     # half the blocks copies, satellite arrays
 ])
 def test_synthetic_models(gpu, model, sigma, n, seed):
     enc = synth.generate(model, seed, n)
@@ -452,3 +453,29 @@ def test_wide_positions_edge_cases(gpu, monkeypatch, name, enc):
     monkeypatch.setenv("GTAMD_FORCE_WIDE", "1")
     res = esa.suffixerator_tables(enc, 4)
     _assert_same_as_oracle(enc, 4, res)
+
+
+def test_repeat_heavy_model_device_equals_numpy(gpu):
+    """the hard-case model (50 % copied blocks, satellite arrays of 10^5..10^6
+    bases) on the device and in numpy, and its build at 20 Mbp checked with the
+    linear-time checker (LCP values beyond 100 000: a dozen doubling rounds)"""
+    import torch
+    from genometools_amd import _lib
+    n = 20_000_000
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    _lib.check(_lib.load().gtamd_synth_bytes(0, synth.MODEL_REPEAT_HEAVY, 9, n, buf.data_ptr()))
+    enc = buf.cpu().numpy()
+    for lo, hi in ((0, 300000), (2_200_000, 2_800_000), (n - 100000, n)):
+        assert np.array_equal(enc[lo:hi], synth.generate(synth.MODEL_REPEAT_HEAVY, 9, n, lo, hi))
+    assert len(synth.satellites(n)) == 4
+    with esa.EsaEngine(n, 4) as eng:
+        eng.set_sequence_device(buf.data_ptr(), n)
+        eng.run()
+        res = eng.result()
+    assert res.stats["refine_rounds"] >= 12 and res.stats["maxbranchdepth"] > 100000
+    rc, where = ou.check_suffix_array(enc, res.suf)
+    assert rc == 0, (rc, where)
+    t = ou.tables_given_sa(enc, res.suf)
+    assert np.array_equal(res.lcp, t["lcp"])
+    assert np.array_equal(res.llv, t["llv"])
+    assert np.array_equal(res.bwt, t["bwt"])

@@ -876,7 +876,8 @@ struct Stats {          // device-side accumulators
   u32 dmax;                       // direct tie path: max lcp
   unsigned long long dsum;        // direct tie path: lcp sum
   u32 dfallback;                  // direct tie path gave up on some group
-  u32 pad;
+  u32 count3;                     // third counter (small groups)
+  unsigned long long smalldone;   // entries of the small groups settled directly
 };
 
 constexpr int FIN_THREADS = 256;
@@ -1277,61 +1278,63 @@ __global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ nee
   if (threadIdx.x == 0) stats->count = tot;
 }
 
-// entries of the suffix array whose position lies in a selected window: counted
-// per 4096 entries, then placed (any order: they are partitioned by position
-// next) together with the heads of their tie groups
+// entries of the suffix array whose position lies in a selected window, together
+// with the heads of their tie groups, in any order (they are partitioned by
+// position next): a workgroup walks WF_TILES tiles of 4096 entries and reserves
+// room for each tile's entries with one atomic on the list's cursor
 constexpr int WF_PER = 16;
-__global__ __launch_bounds__(256) void k_win_count(const u32 *__restrict__ sa, u64 NL, int wb,
-                                                   const u32 *__restrict__ sel,
-                                                   u32 *__restrict__ blockcnt) {
+constexpr int WF_TILES = 8;
+__global__ __launch_bounds__(256) void k_win_filter(
+    const u32 *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
+    const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
+    u32 *__restrict__ fpos, u32 *__restrict__ fhead, Stats *stats) {
   __shared__ u32 s_scan[4];
-  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * WF_PER;
-  u32 c = 0;
-  if (i0 + WF_PER <= NL) {
+  __shared__ u32 s_base;
+  for (int tl = 0; tl < WF_TILES; tl++) {
+    const u64 i0 = (((u64) blockIdx.x * WF_TILES + tl) * 256 + threadIdx.x) * WF_PER;
+    if ((u64) (blockIdx.x * (u64) WF_TILES + tl) * 256 * WF_PER >= NL) break;   // whole workgroup
+    u32 mask = 0;
+    u32 p[WF_PER];
+    if (i0 + WF_PER <= NL) {
 #pragma unroll
-    for (int q = 0; q < WF_PER / 4; q++) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0 + 4 * q);
-      const u32 p[4] = {v.x, v.y, v.z, v.w};
+      for (int q = 0; q < WF_PER / 4; q++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0 + 4 * q);
+        p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
+      }
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < WF_PER; k++) {
         const u32 w = p[k] >> wb;
-        c += (sel[w >> 5] >> (w & 31)) & 1u;
+        mask |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < WF_PER; k++) {
+        p[k] = i0 + k < NL ? sa[i0 + k] : 0u;
+        const u32 w = p[k] >> wb;
+        if (i0 + k < NL && ((sel[w >> 5] >> (w & 31)) & 1u)) mask |= 1u << k;
       }
     }
-  } else {
-    for (int k = 0; k < WF_PER; k++)
-      if (i0 + k < NL) {
-        const u32 w = sa[i0 + k] >> wb;
-        c += (sel[w >> 5] >> (w & 31)) & 1u;
-      }
-  }
-  u32 tot;
-  (void) block_scan_excl_sum(c, &tot, s_scan);
-  if (threadIdx.x == 0) blockcnt[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(256) void k_win_place(
-    const u32 *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
-    const u32 *__restrict__ boff, const u64 *__restrict__ tiebits,
-    const u32 *__restrict__ carry, u32 *__restrict__ fpos, u32 *__restrict__ fhead) {
-  __shared__ u32 s_scan[4];
-  const u64 i0 = ((u64) blockIdx.x * 256 + threadIdx.x) * WF_PER;
-  u32 mask = 0;
-  u32 p[WF_PER];
+    u32 tot;
+    u32 o = block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&stats->count, tot) : 0u;
+    __syncthreads();
+    o += s_base;
+    if (mask) {
+      // the heads of the tie groups: the entries of a thread share a bitmap word
+      // (16 | 64); head of an entry = head of the one before unless it starts a group
+      const u64 t = tiebits[i0 >> 6];
+      u32 h = group_head(tiebits, carry, i0);
 #pragma unroll
-  for (int k = 0; k < WF_PER; k++) {
-    p[k] = i0 + k < NL ? sa[i0 + k] : 0u;
-    const u32 w = p[k] >> wb;
-    if (i0 + k < NL && ((sel[w >> 5] >> (w & 31)) & 1u)) mask |= 1u << k;
-  }
-  u32 tot;
-  u32 o = boff[blockIdx.x] + block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
-  while (mask) {
-    const int k = __ffs(mask) - 1;
-    mask &= mask - 1;
-    fpos[o] = p[k];
-    fhead[o] = group_head(tiebits, carry, i0 + k);
-    o++;
+      for (int k = 0; k < WF_PER; k++) {
+        if (k > 0 && !((t >> ((i0 + k) & 63)) & 1ull)) h = (u32) (i0 + k);
+        if ((mask >> k) & 1u) {
+          fpos[o] = p[k];
+          fhead[o] = h;
+          o++;
+        }
+      }
+    }
+    __syncthreads();   // s_base / s_scan are written again in the next turn
   }
 }
 
@@ -1347,15 +1350,26 @@ __global__ __launch_bounds__(256) void k_win_place(
 // unresolved list and the rank table are built: everything behind sees them
 // as settled suffixes.
 // ---------------------------------------------------------------------------
+constexpr int LCP_CHUNK = 32;
+constexpr u32 PAIR_SWAP = 1u << 31;
+
 // pair heads of a bitmap word: entry i not tied, i+1 tied, i+2 not tied
 __device__ __forceinline__ u64 pair_heads(u64 t, u64 nx) {
   return ~t & ((t >> 1) | (nx << 63)) & ~((t >> 2) | (nx << 62));
 }
 
-// per word: number of pair heads, and the bitmap without the pairs
+// heads of the tie groups of exactly g = 3 or 4 entries ("small groups")
+__device__ __forceinline__ u64 small_heads(u64 t, u64 nx, int g) {
+  u64 m = ~t & ~((t >> g) | (nx << (64 - g)));
+  for (int k = 1; k < g; k++) m &= (t >> k) | (nx << (64 - k));
+  return m;
+}
+
+// per word: number of pair heads and of small-group heads, and the bitmap
+// without the pairs
 __global__ __launch_bounds__(256) void k_pair_words(
     const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
-    u64 *__restrict__ tiebits2) {
+    u32 *__restrict__ scnt, u32 *__restrict__ rcnt, u64 *__restrict__ tiebits2) {
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
   if (w >= nwords) return;
   const u64 t = tiebits[w];
@@ -1365,7 +1379,179 @@ __global__ __launch_bounds__(256) void k_pair_words(
   u64 prevhead = 0;
   if (w > 0) prevhead = pair_heads(tiebits[w - 1], t) >> 63;
   cnt[w] = (u32) __popcll(ph);
+  const u32 n3 = (u32) __popcll(small_heads(t, nx, 3)), n4 = (u32) __popcll(small_heads(t, nx, 4));
+  scnt[w] = n3 + n4;              // small groups ...
+  rcnt[w] = 3u * n3 + 6u * n4;    // ... and their pairs of members
   tiebits2[w] = t & ~((ph << 1) | prevhead);
+}
+
+// ---------------------------------------------------------------------------
+// tie groups of three or four suffixes.  Most of them are a repeat pair that a
+// third suffix happens to share 20 symbols with (n / 4^20 = 0.3 % of all
+// 20-mers at 3 Gbp): spread over the whole text, they alone would make the
+// rounds need every window of the rank table.  Every pair of members of such a
+// group joins the list of the pair path (3 or 6 records per group), where the
+// comparisons are amortised along the text; k_small_combine then sorts the
+// group from the pairwise results.  (Comparing inside the group directly, one
+// thread per group, cost 29 ms at 3 Gbp: every deep pair paid its full LCP.)
+// ---------------------------------------------------------------------------
+// members (x, y) of record q of a group: (0,1) (0,2) (1,2) (0,3) (1,3) (2,3)
+__device__ __forceinline__ void small_pair(int q, int *x, int *y) {
+  const int xs = (0x210100 >> (4 * q)) & 15, ys = (0x333221 >> (4 * q)) & 15;
+  *x = xs; *y = ys;
+}
+
+// per group: index of its first entry, size, ordinal of its first record; per
+// record: (smaller position, other position | ordinal << 32) appended to the
+// pair list behind the np pairs; one thread per bitmap word
+template <typename P>
+__global__ __launch_bounds__(256) void k_small_emit(
+    const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ soff,
+    const u32 *__restrict__ roff, const P *__restrict__ sa, u64 np,
+    u32 *__restrict__ sidx, u8 *__restrict__ ssize, u32 *__restrict__ srec,
+    P *__restrict__ pkey, u64 *__restrict__ pval) {
+  const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (w >= nwords) return;
+  const u64 t = tiebits[w];
+  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+  const u64 h3 = small_heads(t, nx, 3), h4 = small_heads(t, nx, 4);
+  u64 h = h3 | h4;
+  if (h == 0) return;
+  u32 j = soff[w];
+  u64 r = np + roff[w];
+  while (h) {
+    const int b = __ffsll((unsigned long long) h) - 1;
+    h &= h - 1;
+    const u64 i = w * 64 + b;
+    const int g = ((h4 >> b) & 1ull) ? 4 : 3;
+    sidx[j] = (u32) i;
+    ssize[j] = (u8) g;
+    srec[j] = (u32) r;
+    u64 m[4];
+    for (int k = 0; k < g; k++) m[k] = sa[i + k];   // position order (stable sort)
+    const int nrec = g == 3 ? 3 : 6;
+    for (int q = 0; q < nrec; q++) {
+      int x, y;
+      small_pair(q, &x, &y);
+      pkey[r] = (P) m[x];
+      // (64-bit positions: the value is the index of member x | y << 30 ... not
+      // needed: the partner is looked up through sidx, see k_pair_resolve)
+      pval[r] = (sizeof(P) == 4 ? m[y] : (i + y - 1)) | (r << 32);
+      r++;
+    }
+    j++;
+  }
+}
+
+// sorts the group from the pairwise results (res[ordinal]: LCP | PAIR_SWAP if
+// the member with the larger position is the smaller suffix), writes it back
+// to the suffix array, takes it out of the bitmap; per group: the permutation
+// (2 bits per place: which member went there) and the LCPs of places 1 .. g-1
+template <typename P>
+__global__ __launch_bounds__(256) void k_small_combine(
+    const u32 *__restrict__ sidx, const u8 *__restrict__ ssize, const u32 *__restrict__ srec,
+    const u32 *__restrict__ res, u64 ns, P *__restrict__ sa, u64 *__restrict__ tiebits2,
+    u32 *__restrict__ sres, u32 *__restrict__ slcp, Stats *stats) {
+  __shared__ unsigned long long s_sum[4], s_large[4];
+  __shared__ u32 s_max[4], s_cnt[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  unsigned long long sum = 0, nlarge = 0;
+  u32 mx = 0, done = 0;
+  if (j < ns) {
+    const u64 i = sidx[j];
+    const int g = ssize[j];
+    const u32 r0 = srec[j];
+    // less[x][y] for x < y: member x is the smaller suffix; lc: their LCP
+    u32 lc[4][4];
+    bool xfirst[4][4];
+    const int nrec = g == 3 ? 3 : 6;
+    for (int q = 0; q < nrec; q++) {
+      int x, y;
+      small_pair(q, &x, &y);
+      const u32 r = res[r0 + q];
+      lc[x][y] = lc[y][x] = r & ~PAIR_SWAP;
+      xfirst[x][y] = !(r & PAIR_SWAP);
+      xfirst[y][x] = (r & PAIR_SWAP) != 0;
+    }
+    // place of a member = number of members that are smaller suffixes
+    u64 pos[4];
+    int who[4] = {0, 0, 0, 0};
+    for (int k = 0; k < g; k++) pos[k] = sa[i + k];
+    for (int k = 0; k < g; k++) {
+      int place = 0;
+      for (int o = 0; o < g; o++)
+        if (o != k && xfirst[o][k]) place++;
+      who[place] = k;
+    }
+    u32 perm = 0;
+    for (int k = 0; k < g; k++) {
+      sa[i + k] = (P) pos[who[k]];
+      perm |= (u32) who[k] << (2 * k);
+      if (k > 0) {
+        const u32 lv = lc[who[k - 1]][who[k]];
+        slcp[3 * j + (k - 1)] = lv;
+        sum += lv;
+        nlarge += lv >= GTAMD_LCPOVERFLOW;
+        mx = lv > mx ? lv : mx;
+      }
+    }
+    sres[j] = perm | ((u32) g << 8);
+    // entries i+1 .. i+g-1 are no longer tied with their predecessor
+    for (int k = 1; k < g; k++) {
+      const u64 e = i + k;
+      atomicAnd(reinterpret_cast<unsigned long long *>(&tiebits2[e >> 6]), ~(1ull << (e & 63)));
+    }
+    done = (u32) g;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sum += __shfl_xor(sum, d, 64);
+    nlarge += __shfl_xor(nlarge, d, 64);
+    done += __shfl_xor(done, d, 64);
+    const u32 o = __shfl_xor(mx, d, 64);
+    mx = o > mx ? o : mx;
+  }
+  if (lane == 0) { s_sum[w] = sum; s_large[w] = nlarge; s_max[w] = mx; s_cnt[w] = done; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long S = 0, Lg = 0;
+    u32 M = 0, D = 0;
+    for (int x = 0; x < 4; x++) {
+      S += s_sum[x]; Lg += s_large[x]; D += s_cnt[x]; M = s_max[x] > M ? s_max[x] : M;
+    }
+    if (S) atomicAdd(&stats->lcpsum, S);
+    if (Lg) atomicAdd(&stats->numlarge, Lg);
+    if (M) atomicMax(&stats->maxlcp, M);
+    if (D) atomicAdd(&stats->smalldone, (unsigned long long) D);
+  }
+}
+
+// table entries of the small groups (after the emission of the other entries)
+template <typename P>
+__global__ __launch_bounds__(256) void k_small_apply(
+    const u32 *__restrict__ sidx, const u32 *__restrict__ sres, const u32 *__restrict__ slcp,
+    u64 ns, const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
+    u8 *__restrict__ bwt, u32 *__restrict__ lcpfull, u64 index_offset, Stats *stats) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j >= ns) return;
+  const u32 r = sres[j];
+  const u64 i = sidx[j];
+  const int g = (int) (r >> 8) & 7;
+  u8 old[4] = {0, 0, 0, 0};
+  if (bwt != nullptr)
+    for (int k = 0; k < g; k++) old[k] = bwt[i + k];
+  for (int k = 0; k < g; k++) {
+    const u64 p = sa[i + k];
+    if (suf != nullptr) suf[i + k] = p;
+    if (bwt != nullptr) bwt[i + k] = old[(r >> (2 * k)) & 3u];   // (the symbols of the keys, in key order)
+    if (p == 0) stats->longest = index_offset + i + k;
+    if (k > 0 && lcp != nullptr) {
+      const u32 lv = slcp[3 * j + (k - 1)];
+      lcp[i + k] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+      if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + k] = lv;
+    }
+  }
 }
 
 // (smaller position, value | ordinal of the pair << 32) with value = the other
@@ -1396,8 +1582,6 @@ __global__ __launch_bounds__(256) void k_pair_emit(
   }
 }
 
-constexpr int LCP_CHUNK = 32;
-constexpr u32 PAIR_SWAP = 1u << 31;
 
 // order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
 // per thread.  Only reads the suffix array (the rank table is built from it
@@ -1407,47 +1591,66 @@ constexpr u32 PAIR_SWAP = 1u << 31;
 // were five random lines: 18 ms for 170 M pairs)
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
-    Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 np,
+    Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 nrec, u64 np,
     const P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
+  // records with ordinal < np are pairs (their LCP is a table entry: counted in
+  // the statistics); the others are pairs of members of small groups
   __shared__ unsigned long long s_sum[4], s_large[4];
   __shared__ u32 s_max[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, nlarge = 0;
   u32 mx = 0;
-  const u64 nchunks = (np + LCP_CHUNK - 1) / LCP_CHUNK;
+  const u64 nchunks = (nrec + LCP_CHUNK - 1) / LCP_CHUNK;
   for (u64 c = (u64) blockIdx.x * 256 + threadIdx.x; c < nchunks;
        c += (u64) gridDim.x * 256) {
-    u64 preva = 0, prevb = 0, l = 0;
-    bool a_first = true;
+    // the last records of this chunk: the pairs of a small group's members share
+    // their smaller position, so the record one diagonal step back is up to
+    // three records back
+    constexpr int RING = 4;
+    u64 ra[RING] = {0, 0, 0, 0}, rb[RING] = {0, 0, 0, 0}, rl[RING] = {0, 0, 0, 0};
+    bool rf[RING] = {true, true, true, true};
+    int filled = 0;
     for (int e = 0; e < LCP_CHUNK; e++) {
       const u64 s = c * LCP_CHUNK + e;
-      if (s >= np) break;
+      if (s >= nrec) break;
       const u64 a = pkey[s];
       const u64 iv = pval[s];
       const u64 j = iv >> 32;
       const u64 b = sizeof(P) == 4 ? (iv & 0xFFFFFFFFull) : (u64) sa[(iv & 0xFFFFFFFFull) + 1];
-      const u64 d = a - preva;
-      if (e > 0 && l >= (u64) Key<BITS>::SYMS + d && b == prevb + d) {
-        // the next pair on the same diagonal: the same first difference decides,
-        // d symbols nearer -- nothing to read
-        l -= d;
-      } else {
-        u64 from = (u64) Key<BITS>::SYMS;
-        if (e > 0 && l > from + d) from = l - d;
-        l = lcp_extend<BITS>(t, a, b, from);
+      u64 l = 0;
+      bool a_first = true, known = false;
+#pragma unroll
+      for (int k = 0; k < RING; k++) {
+        if (k < filled && !known) {
+          const u64 d = a - ra[k];
+          if (b >= rb[k] && b - rb[k] == d && rl[k] >= (u64) Key<BITS>::SYMS + d) {
+            // a record on the same diagonal: the same first difference decides,
+            // d symbols nearer -- nothing to read
+            l = rl[k] - d;
+            a_first = rf[k];
+            known = true;
+          }
+        }
+      }
+      if (!known) {
+        l = lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::SYMS);
         // the first difference decides: a special is larger than every letter,
         // two specials compare by position
         const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
         a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
                                : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
       }
-      preva = a;
-      prevb = b;
+#pragma unroll
+      for (int k = RING - 1; k > 0; k--) { ra[k] = ra[k - 1]; rb[k] = rb[k - 1]; rl[k] = rl[k - 1]; rf[k] = rf[k - 1]; }
+      ra[0] = a; rb[0] = b; rl[0] = l; rf[0] = a_first;
+      if (filled < RING) filled++;
       const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
-      res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: k_pair_apply walks the table
-      sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
-      nlarge += lv >= GTAMD_LCPOVERFLOW;
-      mx = lv > mx ? lv : mx;
+      res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: the later steps walk the table
+      if (j < np) {
+        sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
+        nlarge += lv >= GTAMD_LCPOVERFLOW;
+        mx = lv > mx ? lv : mx;
+      }
     }
   }
 #pragma unroll
@@ -1890,6 +2093,10 @@ __global__ void k_total2(const u32 *__restrict__ off, const u32 *__restrict__ cn
                          u64 n, Stats *stats) {
   stats->count2 = n ? off[n - 1] + cnt[n - 1] : 0u;
 }
+__global__ void k_total3(const u32 *__restrict__ off, const u32 *__restrict__ cnt,
+                         u64 n, Stats *stats) {
+  stats->count3 = n ? off[n - 1] + cnt[n - 1] : 0u;
+}
 
 // ---------------------------------------------------------------------------
 // few, shallow ties (random coincidences on non-repetitive input): resolve
@@ -2165,7 +2372,8 @@ struct gtamd_esa_ctx {
   DevBuf dig0, dig1;       // digit side arrays of the first sort (experiment)
   DevBuf suf, lcp, bwt;    // outputs at on-disk width
   DevBuf tiebits, tiebits2;
-  DevBuf arena;            // pair list, unresolved list, round buffers
+  DevBuf arena;            // unresolved list, round buffers
+  DevBuf arena_p;          // lists of the pairs and of the small groups
   DevBuf xrecv;            // part builds: receive side of the exchanges
   DevBuf winbuf;           // bitmaps and list of the rank-table windows
   u64 *llv;
@@ -2236,7 +2444,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->st3 != nullptr) (void) hipStreamSynchronize(c->st3);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
-                    &c->tiebits2, &c->arena, &c->xrecv, &c->winbuf};
+                    &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf};
   for (DevBuf *b : bufs) free_buf(*b);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
@@ -2609,7 +2817,7 @@ static int build_bcktab(gtamd_esa_ctx *c, const u64 *skey, u64 NL, u32 k,
 
 // workspace of a run over `cap` entries
 static u64 rws_words_for(u64 cap) {
-  return radix_workspace_words(cap) + 6 * (div_up(cap, 64) + 64) +
+  return radix_workspace_words(cap) + 10 * (div_up(cap, 64) + 64) +
          scan_workspace_words(div_up(cap, 64)) + 64;
 }
 static int ensure_workspace(gtamd_esa_ctx *c, u64 cap, u32 want, bool dist) {
@@ -2943,26 +3151,25 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u32 *carry = offw + nwords + 16;
     u32 *pcnt = carry + nwords + 16;       // pair heads per word, and their scan
     u32 *poff = pcnt + nwords + 16;
-    u32 *scanws = poff + nwords + 16;
+    u32 *scnt = poff + nwords + 16;        // small-group heads per word, and their scan
+    u32 *soff = scnt + nwords + 16;
+    u32 *rcnt = soff + nwords + 16;        // pairs of members of the small groups per word
+    u32 *roff = rcnt + nwords + 16;
+    u32 *scanws = roff + nwords + 16;
     u32 *pws = scanws + scan_workspace_words(nwords) + 64;   // radix workspace (NL pairs)
-    auto tie_words = [&](const u64 *bits, bool with_pairs) -> int {
+    auto tie_words = [&](const u64 *bits) -> int {
       if (NL > 0) {
         k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(bits, nwords, cntw, headw);
         HIP_TRY(hipGetLastError());
         TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
         TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
-        if (with_pairs) TRY(scan_u32(SCAN_SUM, pcnt, poff, nwords, false, scanws, st));
       }
       k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
       HIP_TRY(hipGetLastError());
-      if (with_pairs) {
-        k_total2<<<1, 1, 0, st>>>(poff, pcnt, nwords, c->d_stats);
-        HIP_TRY(hipGetLastError());
-      }
       TRY(fetch_stats(c));
       return 0;
     };
-    TRY(tie_words(tiebits, false));
+    TRY(tie_words(tiebits));
     m0 = c->h_stats->count;
     // few shallow ties: settle them by direct comparison, no rank table
     bool settled = false;
@@ -3013,23 +3220,113 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       }
     }
     if (!settled) {
-    // ---- pairs leave the bitmap; what is left goes through prefix doubling
+    // ---- pairs and small groups leave the bitmap; what is left goes through
+    // prefix doubling
     TRY(ensure_buf(c, c->tiebits2, (nwords + 2) * 8, "the tie bitmap"));
     u64 *tiebits2 = c->tiebits2.as<u64>();
-    const char *np_env = getenv("GTAMD_NO_PAIRS");                // A/B switch
+    const char *np_env = getenv("GTAMD_NO_PAIRS");                // A/B switches
     const bool no_pairs = np_env != nullptr && np_env[0] == '1';
+    const char *ns_env = getenv("GTAMD_NO_SMALL_GROUPS");
+    const bool no_small = no_pairs || (ns_env != nullptr && ns_env[0] == '1');
+    u64 nsmall = 0, nsrec = 0;
     if (NL > 0) {
       if (no_pairs) {
         HIP_TRY(hipMemcpyAsync(tiebits2, tiebits, nwords * 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemsetAsync(pcnt, 0, nwords * 4, st));
       } else {
-        k_pair_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, pcnt, tiebits2);
+        k_pair_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, pcnt, scnt,
+                                                               rcnt, tiebits2);
+        HIP_TRY(hipGetLastError());
+        TRY(scan_u32(SCAN_SUM, pcnt, poff, nwords, false, scanws, st));
+        TRY(scan_u32(SCAN_SUM, scnt, soff, nwords, false, scanws, st));
+        TRY(scan_u32(SCAN_SUM, rcnt, roff, nwords, false, scanws, st));
+        k_total2<<<1, 1, 0, st>>>(poff, pcnt, nwords, c->d_stats);
+        k_total3<<<1, 1, 0, st>>>(soff, scnt, nwords, c->d_stats);
+        k_total<<<1, 1, 0, st>>>(roff, rcnt, nwords, c->d_stats);
+        HIP_TRY(hipGetLastError());
+        TRY(fetch_stats(c));
+        npairs = c->h_stats->count2;
+        nsmall = c->h_stats->count3;
+        nsrec = c->h_stats->count;
+      }
+    }
+    // small groups cost three or six records each: only while that stays a
+    // small part of the table (a sequence set with three or four near-identical
+    // members has them everywhere: prefix doubling is the better tool then)
+    if (no_small || nsrec > NL / 8 || npairs + nsrec >= SINGLE_LIMIT) { nsmall = 0; nsrec = 0; }
+    const u64 nrec = npairs + nsrec;          // records of the pair list
+    const u64 pp = (nrec + 64 + 3) & ~3ull;
+    const u64 sp = (nsmall + 64 + 3) & ~3ull;
+    P *pk_a = nullptr, *pk_b = nullptr;
+    u64 *pv_a = nullptr, *pv_b = nullptr;
+    u32 *pidx = nullptr, *pres = nullptr, *prws = nullptr, *sidx = nullptr, *sres = nullptr,
+        *slcp = nullptr, *srec = nullptr;
+    u8 *ssize = nullptr;
+    auto layout_p = [&](Bump &a) {
+      pk_a = a.take<P>(pp); pk_b = a.take<P>(pp);
+      pv_a = a.take<u64>(pp); pv_b = a.take<u64>(pp);
+      pidx = a.take<u32>(pp); pres = a.take<u32>(pp);
+      prws = a.take<u32>(radix_workspace_words(nrec));
+      sidx = a.take<u32>(sp); sres = a.take<u32>(sp); slcp = a.take<u32>(3 * sp);
+      srec = a.take<u32>(sp);
+      ssize = a.take<u8>(sp);
+    };
+    {
+      Bump sz = {nullptr, 0};
+      layout_p(sz);
+      fail = ensure_buf(c, c->arena_p, sz.off + 4096, "the pairs of tied suffixes") != 0;
+      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+      else if (fail) return -1;
+      Bump a = {c->arena_p.as<u8>(), 0};
+      layout_p(a);
+    }
+    const int nb = bits_for(N - 1);      // bits of a position / of a rank
+    const int nbl = bits_for(NL ? NL - 1 : 0);   // bits of an index into the slice
+    auto passes_for = [](int bits, int *ps, int *pw) -> int {
+      int cnt = 0;
+      for (int b = 0; b < bits; b += 8) {
+        ps[cnt] = b;
+        pw[cnt] = bits - b < 8 ? bits - b : 8;
+        cnt++;
+      }
+      return cnt;
+    };
+    int ps[8], pw[8];
+    const int pn = passes_for(nb, ps, pw);
+    // ---- the pairs (and the pairs of members of the small groups): sorted by
+    // text position, compared
+    if (nrec > 0) {
+      if (npairs > 0) {
+        k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
+                                                                 pv_a, pidx);
+        HIP_TRY(hipGetLastError());
+      }
+      if (nsmall > 0) {
+        k_small_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
+            tiebits, nwords, soff, roff, sa, npairs, sidx, ssize, srec, pk_a, pv_a);
+        HIP_TRY(hipGetLastError());
+      }
+      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, nrec, ps, pw, pn, prws, st,
+                                   nullptr, nullptr));
+      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
+      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
+      TRY(launch_emission());   // bandwidth-bound, beside the comparisons
+      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, LCP_CHUNK), 256)), 256, 0, st>>>(
+          c->text, pk_sorted, pv_sorted, nrec, npairs, sa, pres, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      // pairs in the wrong order change places; the small groups are sorted
+      if (npairs > 0) {
+        k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, nullptr, 0);
+        HIP_TRY(hipGetLastError());
+      }
+      if (nsmall > 0) {
+        k_small_combine<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(
+            sidx, ssize, srec, pres, nsmall, sa, tiebits2, sres, slcp, c->d_stats);
         HIP_TRY(hipGetLastError());
       }
     }
-    TRY(tie_words(tiebits2, true));
+    TRY(tie_words(tiebits2));
     m0 = c->h_stats->count;
-    npairs = c->h_stats->count2;
+    const u64 smalldone = c->h_stats->smalldone;
     u64 anyleft = m0;
     if (R > 1) {
       std::vector<u64> all(R);
@@ -3038,11 +3335,12 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       for (u32 r = 0; r < R; r++) anyleft += all[r];
     }
     if (debug)
-      fprintf(stderr, "gtamd: part %u: %llu tied with a neighbour, %llu pairs, %llu left\n",
+      fprintf(stderr, "gtamd: part %u: %llu tied with a neighbour, %llu pairs, %llu small groups "
+              "(%llu entries settled), %llu left\n",
               c->part, (unsigned long long) numties, (unsigned long long) npairs,
+              (unsigned long long) nsmall, (unsigned long long) smalldone,
               (unsigned long long) m0);
-    // arena: pair list | unresolved list and round buffers | exchange buffers
-    const u64 pp = (npairs + 64 + 3) & ~3ull;
+    // arena: unresolved list and round buffers | exchange buffers
     const u64 mp = (m0 + 64 + 3) & ~3ull;   // every array of the arena 16-byte aligned
     const u64 ISA_CHUNK = 1ull << 27;
     const u64 ichunk = NL < ISA_CHUNK ? NL : ISA_CHUNK;
@@ -3053,11 +3351,10 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u64 xrecv_n = (u64) R * ISA_CHUNK > anyleft ? (u64) R * ISA_CHUNK : anyleft;
     if (xrecv_n > Tn) xrecv_n = Tn;
     xrecv_n += 64;
-    P *pk_a = nullptr, *pk_b = nullptr, *upos = nullptr, *upos2 = nullptr, *cvo = nullptr,
+    P *upos = nullptr, *upos2 = nullptr, *cvo = nullptr,
       *k2 = nullptr, *fk2 = nullptr, *fk2s_a = nullptr, *fk2s_b = nullptr, *fpos = nullptr,
       *cvs = nullptr, *lk_a = nullptr, *lk_b = nullptr, *xrank = nullptr, *xans = nullptr;
-    u64 *pv_a = nullptr, *pv_b = nullptr;
-    u32 *pidx = nullptr, *pres = nullptr, *prws = nullptr, *uidx0 = nullptr,
+    u32 *uidx0 = nullptr,
         *uidx = nullptr, *ugrp = nullptr, *uidx2 = nullptr, *ugrp2 = nullptr, *hv = nullptr,
         *koff = nullptr, *fgrp = nullptr, *fj = nullptr, *perm_a = nullptr, *perm_b = nullptr,
         *gk_a = nullptr, *gk_b = nullptr, *fhv = nullptr, *lv_a = nullptr, *lv_b = nullptr,
@@ -3066,10 +3363,6 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u64 *keep = nullptr;
     u8 *flg = nullptr, *xdest_q = nullptr, *xdest_u = nullptr;
     auto layout = [&](Bump &a) {
-      pk_a = a.take<P>(pp); pk_b = a.take<P>(pp);
-      pv_a = a.take<u64>(pp); pv_b = a.take<u64>(pp);
-      pidx = a.take<u32>(pp); pres = a.take<u32>(pp);
-      prws = a.take<u32>(radix_workspace_words(npairs));
       uidx0 = a.take<u32>(mp); uidx = a.take<u32>(mp); ugrp = a.take<u32>(mp);
       uidx2 = a.take<u32>(mp); ugrp2 = a.take<u32>(mp);
       upos = a.take<P>(mp); upos2 = a.take<P>(mp);
@@ -3113,38 +3406,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     }
     u32 *xrecv_off = c->xrecv.as<u32>();
     P *xrecv_val = reinterpret_cast<P *>(c->xrecv.as<u8>() + ((xrecv_n * 4 + 255) & ~255ull));
-    const int nb = bits_for(N - 1);      // bits of a position / of a rank
-    const int nbl = bits_for(NL ? NL - 1 : 0);   // bits of an index into the slice
-    auto passes_for = [](int bits, int *ps, int *pw) -> int {
-      int cnt = 0;
-      for (int b = 0; b < bits; b += 8) {
-        ps[cnt] = b;
-        pw[cnt] = bits - b < 8 ? bits - b : 8;
-        cnt++;
-      }
-      return cnt;
-    };
-    int ps[8], pw[8];
-    const int pn = passes_for(nb, ps, pw);
     P *rank = nullptr;       // whole table (single build) ...
     P *isa = nullptr;        // ... or the ranks of the own text tile (part build)
-    // ---- the pairs: sorted by text position, compared
-    if (npairs > 0) {
-      k_pair_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, poff, sa, pk_a,
-                                                               pv_a, pidx);
-      HIP_TRY(hipGetLastError());
-      TRY(radix_sort_pairs<P, u64>(pk_a, pv_a, pk_b, pv_b, npairs, ps, pw, pn, prws, st,
-                                   nullptr, nullptr));
-      const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
-      const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
-      TRY(launch_emission());   // bandwidth-bound, beside the comparisons
-      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(npairs, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, npairs, sa, pres, c->d_stats);
-      HIP_TRY(hipGetLastError());
-      // pairs in the wrong order change places
-      k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, nullptr, 0);
-      HIP_TRY(hipGetLastError());
-    }
     // ---- unresolved list of what is left
     if (m0 > 0) {
       k_unres_emit<P><<<(u32) div_up(nwords, 256), 256, 0, st>>>(
@@ -3255,14 +3518,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           return 0;
         }
         // the pairs of the selected windows, partitioned by window
-        const u32 nblk = (u32) div_up(NL, 256 * WF_PER);
-        u32 *fcnt = pcnt, *foff = poff;     // (the pair heads per word have been used)
-        k_win_count<<<nblk, 256, 0, st>>>(spos, NL, wb, w_sel, fcnt);
-        HIP_TRY(hipGetLastError());
-        TRY(scan_u32(SCAN_SUM, fcnt, foff, nblk, false, scanws, st));
-        k_win_place<<<nblk, 256, 0, st>>>(spos, NL, wb, w_sel, foff, tiebits2, carry, ppos, phead);
-        HIP_TRY(hipGetLastError());
-        k_total<<<1, 1, 0, st>>>(foff, fcnt, nblk, c->d_stats);
+        HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 4, st));
+        k_win_filter<<<(u32) div_up(NL, (u64) 256 * WF_PER * WF_TILES), 256, 0, st>>>(
+            spos, NL, wb, w_sel, tiebits2, carry, ppos, phead, c->d_stats);
         HIP_TRY(hipGetLastError());
         TRY(fetch_stats(c));
         const u64 M = c->h_stats->count;   // nsel windows (the last one of the text is short)
@@ -3516,6 +3774,11 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           pidx, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
       HIP_TRY(hipGetLastError());
     }
+    if (nsmall > 0) {
+      k_small_apply<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(
+          sidx, sres, slcp, nsmall, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
+      HIP_TRY(hipGetLastError());
+    }
     const u32 g0 = (u32) div_up(m0, 256);
     u32 *bcnt0 = koff, *boff0 = koff + g0 + 16;   // per-workgroup counts and their scan
     if (m0 > 0) {
@@ -3591,7 +3854,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum + c->h_stats->dsum : 0;
   c->stats.prefixlength = prefixlength;
   c->stats.refine_rounds = rounds;
-  c->stats.tied_suffixes = m0 + 2 * npairs;
+  c->stats.tied_suffixes = m0 + 2 * npairs + c->h_stats->smalldone;
   c->stats.pair_suffixes = 2 * npairs;
   c->stats.device_bytes = c->alloc_bytes;
   float ms = 0;

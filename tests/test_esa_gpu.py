@@ -479,3 +479,36 @@ def test_repeat_heavy_model_device_equals_numpy(gpu):
     assert np.array_equal(res.lcp, t["lcp"])
     assert np.array_equal(res.llv, t["llv"])
     assert np.array_equal(res.bwt, t["bwt"])
+
+
+def test_small_groups(gpu, monkeypatch):
+    """tie groups of three and four (sorted by direct comparisons): a pair with
+    a third suffix that shares 20 symbols only, three and four copies; with
+    the path switched off (GTAMD_NO_SMALL_GROUPS=1) the same tables"""
+    rng = np.random.default_rng(23)
+    a = rng.integers(0, 4, 5000, dtype=np.uint8)
+    third = np.concatenate([a[700:722], rng.integers(0, 4, 300, dtype=np.uint8)])   # 22 shared symbols
+    enc = np.concatenate([a, [255], a, [254], third, [255], a[:2000], [255], a[100:1900], [255],
+                          rng.integers(0, 4, 4000, dtype=np.uint8)]).astype(np.uint8)
+    enc = np.concatenate([enc, enc[::-1][:3000]]).astype(np.uint8)
+    ora = ou.esa(enc, 4)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res, ora)
+    monkeypatch.setenv("GTAMD_NO_SMALL_GROUPS", "1")
+    _assert_same_as_oracle(enc, 4, esa.suffixerator_tables(enc, 4), ora)
+
+
+def test_small_groups_too_deep_fall_back(gpu):
+    """three copies of 40 000 bases: the comparisons of the small-group path
+    give up beyond 2^15 symbols, those groups go through prefix doubling"""
+    rng = np.random.default_rng(29)
+    a = rng.integers(0, 4, 40000, dtype=np.uint8)
+    enc = np.concatenate([a, [255], a, [255], a, rng.integers(0, 4, 30000, dtype=np.uint8)]).astype(np.uint8)
+    res = esa.suffixerator_tables(enc, 4)
+    assert res.stats["refine_rounds"] >= 10
+    rc, where = ou.check_suffix_array(enc, res.suf)
+    assert rc == 0, (rc, where)
+    t = ou.tables_given_sa(enc, res.suf)
+    assert np.array_equal(res.lcp, t["lcp"])
+    assert np.array_equal(res.llv, t["llv"])
+    assert np.array_equal(res.bwt, t["bwt"])

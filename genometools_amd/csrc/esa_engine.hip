@@ -1282,59 +1282,69 @@ __global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ nee
 // with the heads of their tie groups, in any order (they are partitioned by
 // position next): a workgroup walks WF_TILES tiles of 4096 entries and reserves
 // room for each tile's entries with one atomic on the list's cursor
-constexpr int WF_PER = 16;
-constexpr int WF_TILES = 8;
-__global__ __launch_bounds__(256) void k_win_filter(
+constexpr int WF_THREADS = 1024;
+constexpr int WF_Q = 4;                                   // uint4 loads per thread
+constexpr u64 WF_SPAN = (u64) WF_THREADS * 4 * WF_Q;      // 16384 entries per workgroup
+
+__global__ __launch_bounds__(WF_THREADS) void k_win_filter(
     const u32 *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
     const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
     u32 *__restrict__ fpos, u32 *__restrict__ fhead, Stats *stats) {
-  __shared__ u32 s_scan[4];
+  // One walk.  Every lane loads four consecutive entries per step (the wave
+  // reads 1 KB in one piece), all steps' loads are issued before the first is
+  // used; ONE atomic per 16384 entries reserves the workgroup's room in the
+  // list (one per 4096 entries was an 8.7 ms queue on the cursor's address).
+  __shared__ u32 s_scan[WF_THREADS / 64];
   __shared__ u32 s_base;
-  for (int tl = 0; tl < WF_TILES; tl++) {
-    const u64 i0 = (((u64) blockIdx.x * WF_TILES + tl) * 256 + threadIdx.x) * WF_PER;
-    if ((u64) (blockIdx.x * (u64) WF_TILES + tl) * 256 * WF_PER >= NL) break;   // whole workgroup
-    u32 mask = 0;
-    u32 p[WF_PER];
-    if (i0 + WF_PER <= NL) {
+  const u64 first = (u64) blockIdx.x * WF_SPAN;
+  u32 p[WF_Q][4];
+  u32 mask[WF_Q];
 #pragma unroll
-      for (int q = 0; q < WF_PER / 4; q++) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0 + 4 * q);
-        p[4 * q] = v.x; p[4 * q + 1] = v.y; p[4 * q + 2] = v.z; p[4 * q + 3] = v.w;
-      }
-#pragma unroll
-      for (int k = 0; k < WF_PER; k++) {
-        const u32 w = p[k] >> wb;
-        mask |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
-      }
+  for (int q = 0; q < WF_Q; q++) {
+    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
+    if (i0 + 4 <= NL) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
+      p[q][0] = v.x; p[q][1] = v.y; p[q][2] = v.z; p[q][3] = v.w;
     } else {
 #pragma unroll
-      for (int k = 0; k < WF_PER; k++) {
-        p[k] = i0 + k < NL ? sa[i0 + k] : 0u;
-        const u32 w = p[k] >> wb;
-        if (i0 + k < NL && ((sel[w >> 5] >> (w & 31)) & 1u)) mask |= 1u << k;
-      }
+      for (int k = 0; k < 4; k++) p[q][k] = i0 + k < NL ? sa[i0 + k] : 0u;
     }
-    u32 tot;
-    u32 o = block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&stats->count, tot) : 0u;
-    __syncthreads();
-    o += s_base;
-    if (mask) {
-      // the heads of the tie groups: the entries of a thread share a bitmap word
-      // (16 | 64); head of an entry = head of the one before unless it starts a group
-      const u64 t = tiebits[i0 >> 6];
-      u32 h = group_head(tiebits, carry, i0);
+  }
+  u32 mine = 0;
 #pragma unroll
-      for (int k = 0; k < WF_PER; k++) {
-        if (k > 0 && !((t >> ((i0 + k) & 63)) & 1ull)) h = (u32) (i0 + k);
-        if ((mask >> k) & 1u) {
-          fpos[o] = p[k];
-          fhead[o] = h;
-          o++;
-        }
+  for (int q = 0; q < WF_Q; q++) {
+    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
+    u32 m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 w = p[q][k] >> wb;
+      if (i0 + k < NL) m |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
+    }
+    mask[q] = m;
+    mine += (u32) __popc(m);
+  }
+  u32 tot;
+  u32 o = block_scan_excl<SCAN_SUM, WF_THREADS>(mine, &tot, s_scan);
+  if (threadIdx.x == 0) s_base = tot ? atomicAdd(&stats->count, tot) : 0u;
+  __syncthreads();
+  o += s_base;
+#pragma unroll
+  for (int q = 0; q < WF_Q; q++) {
+    if (mask[q] == 0) continue;
+    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
+    // the heads of the tie groups: the four entries share a bitmap word; head of
+    // an entry = head of the one before unless it starts a group
+    const u64 t = tiebits[i0 >> 6];
+    u32 h = group_head(tiebits, carry, i0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (k > 0 && !((t >> ((i0 + k) & 63)) & 1ull)) h = (u32) (i0 + k);
+      if ((mask[q] >> k) & 1u) {
+        fpos[o] = p[q][k];
+        fhead[o] = h;
+        o++;
       }
     }
-    __syncthreads();   // s_base / s_scan are written again in the next turn
   }
 }
 
@@ -1709,10 +1719,11 @@ __global__ __launch_bounds__(256) void k_pair_apply(
     lcp[i + 1] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
     if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + 1] = lv;
   }
-  const u64 x = sa[i], y = sa[i + 1];
-  if (x == 0) stats->longest = index_offset + i;
-  if (y == 0) stats->longest = index_offset + i + 1;
+  // (a pair in its old order has its .suf / .bwt entries from the emission;
+  // suffix 0, whose place the statistics want, is always the first of its pair)
   if (r & PAIR_SWAP) {
+    const u64 x = sa[i], y = sa[i + 1];
+    if (y == 0) stats->longest = index_offset + i + 1;
     if (suf != nullptr) { suf[i] = x; suf[i + 1] = y; }
     if (bwt != nullptr) {
       const u8 b0 = bwt[i], b1 = bwt[i + 1];
@@ -3519,7 +3530,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         }
         // the pairs of the selected windows, partitioned by window
         HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 4, st));
-        k_win_filter<<<(u32) div_up(NL, (u64) 256 * WF_PER * WF_TILES), 256, 0, st>>>(
+        k_win_filter<<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
             spos, NL, wb, w_sel, tiebits2, carry, ppos, phead, c->d_stats);
         HIP_TRY(hipGetLastError());
         TRY(fetch_stats(c));
@@ -3706,6 +3717,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 nf = c->h_stats->count;
+      if (debug)
+        fprintf(stderr, "gtamd: part %u round %u: %llu entries in groups across tile borders\n",
+                c->part, rounds, (unsigned long long) nf);
       if (nf > 0) {
         // groups crossing a tile border / larger than a tile: ordered by
         // (group, k2) through two stable sorts of an index

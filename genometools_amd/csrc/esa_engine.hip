@@ -685,9 +685,16 @@ template <typename P> struct InitialRanks {
   P *isa;              // this part's tile of the rank table
   u32 *soff;
   P *srank;
+  const u32 *sel;      // windows of 2^wb positions whose ranks travel (nullptr: all)
+  int wb;
   __device__ __forceinline__ u32 dest(u64 j) const {
     u64 off;
-    const u32 d = tl.owner((u64) sa[c0 + j], &off);
+    const u64 p = (u64) sa[c0 + j];
+    if (sel != nullptr) {
+      const u64 w = p >> wb;
+      if (!((sel[w >> 5] >> (w & 31)) & 1u)) return DEST_NONE;
+    }
+    const u32 d = tl.owner(p, &off);
     return d == tl.self ? DEST_LOCAL : d;
   }
   __device__ __forceinline__ P rank_of(u64 i) const {
@@ -1758,8 +1765,12 @@ template <typename P>
 __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     const u32 *__restrict__ uidx, const P *__restrict__ upos,
     const u32 *__restrict__ ugrp, P *__restrict__ k2, u64 m,
-    P *__restrict__ cv, u32 *__restrict__ hv, u8 *__restrict__ flg,
-    u32 *__restrict__ tilecnt, const P *__restrict__ rank, u64 h, u64 n) {
+    P *__restrict__ cv, u32 *__restrict__ hv, const u32 *__restrict__ tstart,
+    u32 *__restrict__ flagbits, const P *__restrict__ rank, u64 h, u64 n) {
+  // tstart: the tiles start at group borders (k_tile_starts), so that a group
+  // no larger than RT_TILE - RT_STRIDE never reaches across a border; a tile
+  // that is larger than the LDS arrays is worked off in chunks, with the groups
+  // across chunk borders left to the global path (flagbits: one bit per slot)
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
   // of reading a k2 array (which a part build fills through the exchange)
   // 28 KB of LDS (32-bit positions), so that five workgroups share a CU (the
@@ -1777,8 +1788,9 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
   u32 *s_grp = reinterpret_cast<u32 *>(s_key);
   u32 *s_k2n = s_grp + RT_TILE;
   const int tid = threadIdx.x;
-  const u64 base = (u64) blockIdx.x * RT_TILE;
-  const u32 cnt = (u32) ((m - base) < (u64) RT_TILE ? (m - base) : (u64) RT_TILE);
+  const u64 tile_first = tstart[blockIdx.x], tile_end = tstart[blockIdx.x + 1];
+  for (u64 base = tile_first; base < tile_end; base += RT_TILE) {
+  const u32 cnt = (u32) ((tile_end - base) < (u64) RT_TILE ? (tile_end - base) : (u64) RT_TILE);
   // groups that continue in a neighbouring tile
   const u32 g_first = ugrp[base], g_last = ugrp[base + cnt - 1];
   const bool first_open = base > 0 && ugrp[base - 1] == g_first;
@@ -1853,8 +1865,14 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     if (open && rank != nullptr) k2[base + e] = (P) kraw;   // for the global path
     nflag += open;
   }
-  static_assert(RT_PER == 8, "one flag byte per thread");
-  flg[(u64) blockIdx.x * RT_THREADS + tid] = (u8) openbits;
+  if (openbits) {   // rare: a group larger than the tiles' slack, or than a tile
+#pragma unroll
+    for (int c = 0; c < RT_PER; c++)
+      if ((openbits >> c) & 1u) {
+        const u64 slot = base + e0 + c;
+        atomicOr(&flagbits[slot >> 5], 1u << (slot & 31));
+      }
+  }
   // (the barrier also orders the s_key writes before the network's reads)
   const int any_split = __syncthreads_or(splits);
   if (any_split) {
@@ -1954,25 +1972,45 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
       }
     }
   }
-  // number of deferred elements of the tile (k_flag_gather places them from a
-  // scan of these counts; the scan also gives their total)
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) nflag += __shfl_xor(nflag, d, 64);
-  if ((tid & 63) == 0) s_scan[tid >> 6] = nflag;   // free since the scan's last barrier
-  __syncthreads();
-  if (tid == 0) {
-    u32 t = 0;
-    for (int i = 0; i < RT_THREADS / 64; i++) t += s_scan[i];
-    tilecnt[blockIdx.x] = t;
+  (void) nflag;
+  __syncthreads();   // the LDS arrays are filled again by the next chunk
   }
+}
+
+// where the tiles of a round start: at the multiples of RT_STRIDE slots, moved
+// back to the first slot of the group that lies there (a group that starts
+// more than RT_TILE slots before stays cut: it is larger than a tile anyway)
+constexpr int RT_STRIDE = RT_TILE - 512;
+__global__ __launch_bounds__(256) void k_tile_starts(const u32 *__restrict__ ugrp, u64 m,
+                                                     u32 ntiles, u32 *__restrict__ tstart) {
+  const u32 t = blockIdx.x * 256 + threadIdx.x;
+  if (t > ntiles) return;
+  if (t == ntiles) { tstart[t] = (u32) m; return; }
+  u64 s = (u64) t * RT_STRIDE;
+  const u32 g = ugrp[s];
+  int steps = 0;
+  while (s > 0 && ugrp[s - 1] == g && steps < RT_TILE) { s--; steps++; }
+  if (steps == RT_TILE) s = (u64) t * RT_STRIDE;
+  tstart[t] = (u32) s;
+}
+
+// deferred slots per RT_TILE slots, from the bitmap
+__global__ __launch_bounds__(256) void k_flag_count(const u32 *__restrict__ flagbits, u64 m,
+                                                    u32 nblocks, u32 *__restrict__ blkcnt) {
+  const u32 b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nblocks) return;
+  u32 c = 0;
+  for (int w = 0; w < RT_TILE / 32; w++) c += (u32) __popc(flagbits[(u64) b * (RT_TILE / 32) + w]);
+  blkcnt[b] = c;
+  (void) m;
 }
 
 // global path for the deferred elements: order by (group, k2) with two stable
 // sorts -- on k2, then on the group -- of an index into the deferred list.  One
-// workgroup per tile of k_round_tile; tileoff = exclusive scan of its counts.
+// workgroup per RT_TILE slots; tileoff = exclusive scan of k_flag_count's counts.
 template <typename P>
 __global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
-    const u8 *__restrict__ flg, const u32 *__restrict__ tileoff,
+    const u32 *__restrict__ flagbits, const u32 *__restrict__ tileoff,
     const u32 *__restrict__ ugrp, const P *__restrict__ k2,
     const P *__restrict__ upos, u64 m, P *__restrict__ fk2, P *__restrict__ fk2_sort,
     u32 *__restrict__ fgrp, P *__restrict__ fpos, u32 *__restrict__ fj,
@@ -1980,7 +2018,8 @@ __global__ __launch_bounds__(RT_THREADS) void k_flag_gather(
   __shared__ u32 s_scan[4];
   const u64 base = (u64) blockIdx.x * RT_TILE + (u64) threadIdx.x * RT_PER;
   // (the tile kernel sets no bit at or behind m)
-  const u32 f = base < m ? (u32) flg[(u64) blockIdx.x * RT_THREADS + threadIdx.x] : 0u;
+  // (slot s is bit s & 31 of word s >> 5: byte s >> 3, bit s & 7)
+  const u32 f = base < m ? (u32) reinterpret_cast<const u8 *>(flagbits)[(u64) blockIdx.x * RT_THREADS + threadIdx.x] : 0u;
   const u32 cnt = (u32) __popc(f);
   u32 tot;
   u32 o = tileoff[blockIdx.x] + block_scan_excl_sum(cnt, &tot, s_scan);
@@ -3372,7 +3411,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         *rws2 = nullptr, *scanws2 = nullptr, *xoff = nullptr, *xorder = nullptr,
         *xbc_q = nullptr, *xbo_q = nullptr, *xbc_u = nullptr, *xbo_u = nullptr;
     u64 *keep = nullptr;
-    u8 *flg = nullptr, *xdest_q = nullptr, *xdest_u = nullptr;
+    u8 *xdest_q = nullptr, *xdest_u = nullptr;
+    u32 *flagbits = nullptr, *tstart = nullptr;
     auto layout = [&](Bump &a) {
       uidx0 = a.take<u32>(mp); uidx = a.take<u32>(mp); ugrp = a.take<u32>(mp);
       uidx2 = a.take<u32>(mp); ugrp2 = a.take<u32>(mp);
@@ -3382,7 +3422,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       keep = a.take<u64>(mp / 64 + 4);   // 1 bit per slot
       koff = a.take<u32>(mp);
       k2 = a.take<P>(mp);            // rank of the suffix h further on
-      flg = a.take<u8>(mp / 8 + 256);    // deferred to the global path (1 bit per slot)
+      flagbits = a.take<u32>(mp / 32 + RT_TILE / 32 + 64);   // deferred to the global path (1 bit per slot)
+      tstart = a.take<u32>(mp / RT_STRIDE + 64);              // where the tiles of a round start
       // global path of a round (groups across tile borders)
       fk2 = a.take<P>(mp); fk2s_a = a.take<P>(mp); fk2s_b = a.take<P>(mp);
       fpos = a.take<P>(mp); cvs = a.take<P>(mp);
@@ -3565,43 +3606,97 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       }
       return tot;
     };
+    // part builds: the first ranks go to the owners of the positions, ISA_CHUNK
+    // entries at a time -- only for the windows of positions the rounds can
+    // reach (the union over the parts; see k_win_mark), which is a fifth of the
+    // text for the human-like workload: the exchange shrinks accordingly
+    std::vector<u32> h_need, h_built, h_all;
+    u64 dw_nww = 0;
+    std::function<int()> send_ranks = []() -> int { return 0; };
     if (anyleft > 0 && dist) {
-      // first ranks to the owners of the positions, ICHUNK entries at a time
       isa = WIDE ? reinterpret_cast<P *>(fkey) : reinterpret_cast<P *>(fval);
-      u64 chunks = div_up(NL, ISA_CHUNK);
-      if (R > 1) {
-        std::vector<u64> all(R);
-        TRY(comm_allgather(c, 0, &chunks, all.data(), 8));
-        for (u32 r = 0; r < R; r++) chunks = all[r] > chunks ? all[r] : chunks;
+      rk_wb = 16;
+      rk_nwin = div_up(N, 1ull << rk_wb);
+      dw_nww = rk_nwin / 32 + 2;
+      const char *we = getenv("GTAMD_RANK_ALL_WINDOWS");           // A/B switch
+      rk_windows = !(we != nullptr && we[0] == '1');
+      fail = ensure_buf(c, c->winbuf, (3 * dw_nww + 16) * 4, "the rank windows") != 0;
+      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+      else if (fail) return -1;
+      w_need = c->winbuf.as<u32>(); w_built = w_need + dw_nww; w_sel = w_built + dw_nww;
+      h_need.assign(dw_nww, 0u); h_built.assign(dw_nww, 0u); h_all.assign((size_t) dw_nww * R, 0u);
+      HIP_TRY(hipMemsetAsync(w_need, 0, 3 * dw_nww * 4, st));
+      rk_h0 = (u64) K::SYMS << 9;
+      if (rk_h0 > (3ull << rk_wb)) rk_h0 = 3ull << rk_wb;
+      if (rk_windows && m0 > 0) {
+        k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, rk_wb, rk_nwin,
+                                                            w_need);
+        HIP_TRY(hipGetLastError());
       }
-      for (u64 ch = 0; ch < chunks; ch++) {
-        const u64 c0 = ch * ISA_CHUNK < NL ? ch * ISA_CHUNK : NL;
-        const u64 cm = NL - c0 < ISA_CHUNK ? NL - c0 : ISA_CHUNK;
-        InitialRanks<P> ir;
-        ir.sa = sa; ir.tiebits = tiebits2; ir.carry = carry; ir.c0 = c0;
-        ir.index_offset = index_offset; ir.tl = tl; ir.isa = isa; ir.soff = xoff; ir.srank = xrank;
-        TRY(dest_count(c, ir, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
-        HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
-                               hipMemcpyDeviceToHost, st));
-        TRY(dest_place(c, ir, cm, xdest_q, xbo_q));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<u64> sc(R), rc(R), mat((size_t) R * R);
-        for (u32 r = 0; r < R; r++) sc[r] = c->h_counts[r];
-        TRY(comm_allgather(c, 0, sc.data(), mat.data(), R * 8));
-        u64 nrecv = 0;
-        for (u32 s = 0; s < R; s++) { rc[s] = mat[(size_t) s * R + c->part]; nrecv += rc[s]; }
-        if (nrecv + 64 > xrecv_n) {
-          gtamd_set_error("rank exchange: %llu ranks for a tile of %llu positions",
-                          (unsigned long long) nrecv, (unsigned long long) Tn);
-          return -1;
+      send_ranks = [&]() -> int {
+        // the windows any part needs and nobody has sent yet
+        const u32 *d_sel = nullptr;
+        if (rk_windows) {
+          HIP_TRY(hipStreamSynchronize(st));
+          HIP_TRY(hipMemcpy(h_need.data(), w_need, dw_nww * 4, hipMemcpyDeviceToHost));
+          TRY(comm_allgather(c, 0, h_need.data(), h_all.data(), (u32) (dw_nww * 4)));
+          u64 fresh = 0, all = 0;
+          for (u64 w = 0; w < dw_nww; w++) {
+            u32 x = 0;
+            for (u32 r = 0; r < R; r++) x |= h_all[(size_t) r * dw_nww + w];
+            x &= ~h_built[w];
+            h_need[w] = x;
+            h_built[w] |= x;
+            fresh += (u64) __builtin_popcount(x);
+            all += (u64) __builtin_popcount(h_built[w]);
+          }
+          if (debug)
+            fprintf(stderr, "gtamd: part %u: ranks of %llu more windows of 2^%d positions travel "
+                    "(%llu of %llu so far)\n", c->part, (unsigned long long) fresh, rk_wb,
+                    (unsigned long long) all, (unsigned long long) rk_nwin);
+          if (fresh == 0) return 0;
+          HIP_TRY(hipMemcpyAsync(w_sel, h_need.data(), dw_nww * 4, hipMemcpyHostToDevice, st));
+          HIP_TRY(hipMemcpyAsync(w_built, h_built.data(), dw_nww * 4, hipMemcpyHostToDevice, st));
+          d_sel = w_sel;
         }
-        TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "rank offsets"));
-        TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "ranks"));
-        if (nrecv > 0) {
-          k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
-          HIP_TRY(hipGetLastError());
+        u64 chunks = div_up(NL, ISA_CHUNK);
+        if (R > 1) {
+          std::vector<u64> all(R);
+          TRY(comm_allgather(c, 0, &chunks, all.data(), 8));
+          for (u32 r = 0; r < R; r++) chunks = all[r] > chunks ? all[r] : chunks;
         }
-      }
+        for (u64 ch = 0; ch < chunks; ch++) {
+          const u64 c0 = ch * ISA_CHUNK < NL ? ch * ISA_CHUNK : NL;
+          const u64 cm = NL - c0 < ISA_CHUNK ? NL - c0 : ISA_CHUNK;
+          InitialRanks<P> ir;
+          ir.sa = sa; ir.tiebits = tiebits2; ir.carry = carry; ir.c0 = c0;
+          ir.index_offset = index_offset; ir.tl = tl; ir.isa = isa; ir.soff = xoff; ir.srank = xrank;
+          ir.sel = d_sel; ir.wb = rk_wb;
+          TRY(dest_count(c, ir, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
+          HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
+                                 hipMemcpyDeviceToHost, st));
+          TRY(dest_place(c, ir, cm, xdest_q, xbo_q));
+          HIP_TRY(hipStreamSynchronize(st));
+          std::vector<u64> sc(R), rc(R), mat((size_t) R * R);
+          for (u32 r = 0; r < R; r++) sc[r] = c->h_counts[r];
+          TRY(comm_allgather(c, 0, sc.data(), mat.data(), R * 8));
+          u64 nrecv = 0;
+          for (u32 s = 0; s < R; s++) { rc[s] = mat[(size_t) s * R + c->part]; nrecv += rc[s]; }
+          if (nrecv + 64 > xrecv_n) {
+            gtamd_set_error("rank exchange: %llu ranks for a tile of %llu positions",
+                            (unsigned long long) nrecv, (unsigned long long) Tn);
+            return -1;
+          }
+          TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "rank offsets"));
+          TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "ranks"));
+          if (nrecv > 0) {
+            k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
+            HIP_TRY(hipGetLastError());
+          }
+        }
+        return 0;
+      };
+      TRY(send_ranks());
     }
     TRY(launch_emission());   // (if the pair path has not started it)
     // ---- doubling rounds
@@ -3625,6 +3720,28 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       if (rounds >= 64) {
         gtamd_set_error("prefix doubling did not converge after 64 rounds");
         return -1;
+      }
+      if (dist && rk_windows && h > rk_h0) {
+        // does this round's offset reach windows whose ranks have not travelled?
+        // (all parts decide together; never happens while h <= rk_h0)
+        HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, 4, st));
+        if (m > 0) {
+          k_win_check<P><<<(u32) div_up(m, 256), 256, 0, st>>>(upos, m, h, rk_wb, rk_nwin, w_built,
+                                                             w_need, c->d_stats);
+          HIP_TRY(hipGetLastError());
+        }
+        TRY(fetch_stats(c));
+        u64 more = c->h_stats->count2 != 0;
+        if (R > 1) {
+          std::vector<u64> all(R);
+          TRY(comm_allgather(c, 0, &more, all.data(), 8));
+          for (u32 r = 0; r < R; r++) more |= all[r];
+        }
+        if (more) {
+          TRY(send_ranks());
+          // (the exchange used the bucketing buffers of this round's queries)
+          TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
+        }
       }
       if (dist) {
         // one allgather per round: pending updates, queries, and who is left
@@ -3697,7 +3814,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         HIP_TRY(hipMemsetAsync(c->d_counts, 0, 2 * DEST_MAXPARTS * 4, st));
         continue;
       }
-      if (rk_windows && h > rk_h0) {
+      if (!dist && rk_windows && h > rk_h0) {
         // an offset beyond the windows built so far?  then build what it reaches
         HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, 4, st));
         k_win_check<P><<<(u32) div_up(m, 256), 256, 0, st>>>(upos, m, h, rk_wb, rk_nwin, w_built,
@@ -3707,13 +3824,19 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         if (c->h_stats->count2 != 0) TRY(build_rank(false));
       }
       const u32 g = (u32) div_up(m, 256);
-      const u32 ntiles = (u32) div_up(m, RT_TILE);
-      u32 *tilecnt = koff, *tileoff = koff + ntiles + 16;   // (free until the apply step)
-      k_round_tile<P><<<ntiles, RT_THREADS, 0, st>>>(
-          uidx, upos, ugrp, k2, m, cvo, hv, flg, tilecnt, dist ? nullptr : rank, h, n);
+      const u32 ntiles = (u32) div_up(m, RT_STRIDE);   // tiles that start at group borders
+      const u32 nfb = (u32) div_up(m, RT_TILE);         // blocks of the deferred-slot bitmap
+      u32 *tilecnt = koff, *tileoff = koff + nfb + 16;  // (free until the apply step)
+      HIP_TRY(hipMemsetAsync(flagbits, 0, (u64) nfb * (RT_TILE / 8), st));
+      k_tile_starts<<<ntiles / 256 + 1, 256, 0, st>>>(ugrp, m, ntiles, tstart);
       HIP_TRY(hipGetLastError());
-      TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, ntiles, false, scanws2, st));
-      k_total<<<1, 1, 0, st>>>(tileoff, tilecnt, ntiles, c->d_stats);
+      k_round_tile<P><<<ntiles, RT_THREADS, 0, st>>>(
+          uidx, upos, ugrp, k2, m, cvo, hv, tstart, flagbits, dist ? nullptr : rank, h, n);
+      HIP_TRY(hipGetLastError());
+      k_flag_count<<<nfb / 256 + 1, 256, 0, st>>>(flagbits, m, nfb, tilecnt);
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, tilecnt, tileoff, nfb, false, scanws2, st));
+      k_total<<<1, 1, 0, st>>>(tileoff, tilecnt, nfb, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       const u64 nf = c->h_stats->count;
@@ -3723,7 +3846,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       if (nf > 0) {
         // groups crossing a tile border / larger than a tile: ordered by
         // (group, k2) through two stable sorts of an index
-        k_flag_gather<P><<<ntiles, RT_THREADS, 0, st>>>(flg, tileoff, ugrp, k2, upos, m, fk2,
+        k_flag_gather<P><<<nfb, RT_THREADS, 0, st>>>(flagbits, tileoff, ugrp, k2, upos, m, fk2,
                                                        fk2s_a, fgrp, fpos, fj, perm_a);
         HIP_TRY(hipGetLastError());
         TRY(radix_sort_pairs<P, u32>(fk2s_a, perm_a, fk2s_b, perm_b, nf, ps, pw, pn, rws2, st,

@@ -97,3 +97,31 @@ def test_many_parts(gpu):
     """more parts than the ballot loops unroll for; parts with empty slices"""
     _check(synth.generate(synth.MODEL_HUMANLIKE_DNA, 9, 120000), 4, 16)
     _check(np.tile(np.array([0, 1, 2, 3, 3], dtype=np.uint8), 400), 4, 6)
+
+
+@pytest.mark.parametrize("parts", [1, 3])
+def test_deep_groups_reach_new_rank_windows(gpu, monkeypatch, parts):
+    """five copies of 30 000 bases: groups of five stay tied for 11 rounds and
+    the offsets of the late rounds (h > 10 240) reach windows of the rank table
+    that were not built / sent at first -- the lazy extension, in a single
+    build (small windows forced) and in a part build"""
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 4, 30000, dtype=np.uint8)
+    enc = np.concatenate([a, [255], a, [254], a, [255], a, [255], a,
+                          rng.integers(0, 4, 200000, dtype=np.uint8)]).astype(np.uint8)
+    if parts == 1:
+        from genometools_amd import esa
+        monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", "8")
+        res = esa.suffixerator_tables(enc, 4)
+        tabs = {"suf": res.suf, "lcp": res.lcp, "llv": res.llv, "bwt": res.bwt}
+        rounds = res.stats["refine_rounds"]
+    else:
+        tabs, stats, _ = build_in_parts(enc, 4, parts)
+        rounds = stats["refine_rounds"]
+    assert rounds >= 10
+    rc, where = ou.check_suffix_array(enc, tabs["suf"])
+    assert rc == 0, (rc, where)
+    t = ou.tables_given_sa(enc, tabs["suf"])
+    assert np.array_equal(tabs["lcp"], t["lcp"])
+    assert np.array_equal(tabs["llv"], t["llv"])
+    assert np.array_equal(tabs["bwt"], t["bwt"])

@@ -63,7 +63,8 @@ class EsaTiming(ctypes.Structure):
                 ("scatter_items", ctypes.c_uint64),
                 ("comm_ms", ctypes.c_float),
                 ("comm_calls", ctypes.c_uint32),
-                ("comm_bytes", ctypes.c_uint64)]
+                ("comm_bytes", ctypes.c_uint64),
+                ("alloc_ms", ctypes.c_float)]
 
 
 class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd_encode.h

@@ -2451,6 +2451,7 @@ struct gtamd_esa_ctx {
   gtamd_esa_stats stats;
   gtamd_esa_timing timing;
   u64 alloc_bytes;         // device memory held by the context
+  float alloc_ms;          // host time of the allocations since the last run started
   // events
   hipEvent_t ev[8];
   hipEvent_t ev_scatter[2 * 16];
@@ -2465,10 +2466,13 @@ static int ensure_buf(gtamd_esa_ctx *c, DevBuf &b, u64 bytes, const char *what) 
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipStreamSynchronize(c->st2));
   HIP_TRY(hipStreamSynchronize(c->st3));
+  const auto t0 = std::chrono::steady_clock::now();
   c->alloc_bytes -= b.bytes;
   free_buf(b);
   bytes = (bytes + 255) & ~255ull;
-  if (hipMalloc(&b.p, bytes) != hipSuccess) {
+  const hipError_t me = hipMalloc(&b.p, bytes);
+  c->alloc_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (me != hipSuccess) {
     (void) hipGetLastError();
     b.p = nullptr;
     size_t mfree = 0, mtotal = 0;
@@ -2924,6 +2928,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   }
   memset(&c->timing, 0, sizeof c->timing);
   memset(&c->stats, 0, sizeof c->stats);
+  c->alloc_ms = 0;
   c->llv_pairs = 0;
   const bool debug = getenv("GTAMD_DEBUG") != nullptr;
 
@@ -4009,6 +4014,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   c->timing.scatter_ms = sc;
   c->timing.scatter_launches = (u32) nev;
   c->timing.scatter_items = NL;
+  c->timing.alloc_ms = c->alloc_ms;
   c->want = want;
   c->ran = true;
   return 0;

@@ -92,6 +92,10 @@ typedef struct {
   float comm_ms;
   uint32_t comm_calls;
   uint64_t comm_bytes;
+  /* host time this run spent allocating device memory (the workspace is
+     allocated by the first run that needs it: a cold run pays seconds for
+     ~140 GB at 3 Gbp, the following runs on the context nothing) */
+  float alloc_ms;
 } gtamd_esa_timing;
 
 typedef struct gtamd_esa_ctx gtamd_esa_ctx;

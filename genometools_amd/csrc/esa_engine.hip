@@ -1074,18 +1074,36 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(
 // a sequence with n >= 2^32 (GTAMD_FORCE_WIDE=1 takes it at any size).  Indices
 // into a part's slice stay 32-bit (a slice has fewer than 2^32 entries).
 
-// per 64-entry word: unresolved mask count and the highest "not tied" index
+// a workgroup of 256 threads owns 256 words (16384 entries) of the bitmap: it
+// delivers ONE count (the offsets inside are a block scan away for the kernels
+// that place things -- scans over one counter per word were 0.65 ms each, five
+// of them per build) and, per word, the highest "not tied" index
+__device__ __forceinline__ u32 block_total_256(u32 v, u32 *s4) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  if (lane == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const u32 t = s4[0] + s4[1] + s4[2] + s4[3];
+  __syncthreads();
+  return t;
+}
+
 __global__ __launch_bounds__(256) void k_tie_words(
-    const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
+    const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ blkcnt,
     u32 *__restrict__ headw) {
+  __shared__ u32 s4[4];
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const u64 t = tiebits[w];
-  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
-  const u64 u = t | (t >> 1) | (nx << 63);
-  cnt[w] = (u32) __popcll(u);
-  const u64 z = ~t;
-  headw[w] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : 0u;
+  u32 c = 0;
+  if (w < nwords) {
+    const u64 t = tiebits[w];
+    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    c = (u32) __popcll(t | (t >> 1) | (nx << 63));
+    const u64 z = ~t;
+    headw[w] = z ? (u32) (w * 64 + (63 - __clzll((long long) z))) : 0u;
+  }
+  const u32 tot = block_total_256(c, s4);
+  if (threadIdx.x == 0) blkcnt[blockIdx.x] = tot;
 }
 
 // head (first index) of the tie group that entry i belongs to
@@ -1100,20 +1118,25 @@ __device__ __forceinline__ u32 group_head(const u64 *tiebits, const u32 *carry,
 
 // one thread per 64-entry word of the bitmap (few words have an unresolved
 // entry at all: a lane per entry left most lanes idle -- 4.6 ms for 50 M
-// entries of 3 G); the threads of a wave write neighbouring stretches of the list
+// entries of 3 G); the threads of a wave write neighbouring stretches of the
+// list.  blkoff: exclusive scan of k_tie_words' workgroup counts.
 template <typename P>
 __global__ __launch_bounds__(256) void k_unres_emit(
-    const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
+    const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ blkoff,
     const u32 *__restrict__ carry, const P *__restrict__ sa,
     u32 *__restrict__ uidx0, u32 *__restrict__ uidx, P *__restrict__ upos,
     u32 *__restrict__ ugrp) {
+  __shared__ u32 s_scan[4];
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const u64 t = tiebits[w];
-  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
-  u64 u = t | (t >> 1) | (nx << 63);
+  u64 t = 0, u = 0;
+  if (w < nwords) {
+    t = tiebits[w];
+    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    u = t | (t >> 1) | (nx << 63);
+  }
+  u32 tot;
+  u32 j = blkoff[blockIdx.x] + block_scan_excl_sum((u32) __popcll(u), &tot, s_scan);
   if (u == 0) return;
-  u32 j = off[w];
   const u32 carryw = carry[w];
   while (u) {
     const int b = __ffsll((unsigned long long) u) - 1;
@@ -1382,24 +1405,30 @@ __device__ __forceinline__ u64 small_heads(u64 t, u64 nx, int g) {
   return m;
 }
 
-// per word: number of pair heads and of small-group heads, and the bitmap
-// without the pairs
+// per workgroup of 256 words: number of pair heads, of small-group heads and of
+// the small groups' records; per word: the bitmap without the pairs
 __global__ __launch_bounds__(256) void k_pair_words(
     const u64 *__restrict__ tiebits, u64 nwords, u32 *__restrict__ cnt,
     u32 *__restrict__ scnt, u32 *__restrict__ rcnt, u64 *__restrict__ tiebits2) {
+  __shared__ u32 s4[4];
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const u64 t = tiebits[w];
-  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
-  const u64 ph = pair_heads(t, nx);
-  // a pair head in bit 63 of the word before clears this word's bit 0
-  u64 prevhead = 0;
-  if (w > 0) prevhead = pair_heads(tiebits[w - 1], t) >> 63;
-  cnt[w] = (u32) __popcll(ph);
-  const u32 n3 = (u32) __popcll(small_heads(t, nx, 3)), n4 = (u32) __popcll(small_heads(t, nx, 4));
-  scnt[w] = n3 + n4;              // small groups ...
-  rcnt[w] = 3u * n3 + 6u * n4;    // ... and their pairs of members
-  tiebits2[w] = t & ~((ph << 1) | prevhead);
+  u32 np = 0, n3 = 0, n4 = 0;
+  if (w < nwords) {
+    const u64 t = tiebits[w];
+    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    const u64 ph = pair_heads(t, nx);
+    // a pair head in bit 63 of the word before clears this word's bit 0
+    u64 prevhead = 0;
+    if (w > 0) prevhead = pair_heads(tiebits[w - 1], t) >> 63;
+    np = (u32) __popcll(ph);
+    n3 = (u32) __popcll(small_heads(t, nx, 3));
+    n4 = (u32) __popcll(small_heads(t, nx, 4));
+    tiebits2[w] = t & ~((ph << 1) | prevhead);
+  }
+  const u32 tp = block_total_256(np, s4);
+  const u32 ts = block_total_256(n3 + n4, s4);
+  const u32 tr = block_total_256(3u * n3 + 6u * n4, s4);
+  if (threadIdx.x == 0) { cnt[blockIdx.x] = tp; scnt[blockIdx.x] = ts; rcnt[blockIdx.x] = tr; }
 }
 
 // ---------------------------------------------------------------------------
@@ -1427,15 +1456,22 @@ __global__ __launch_bounds__(256) void k_small_emit(
     const u32 *__restrict__ roff, const P *__restrict__ sa, u64 np,
     u32 *__restrict__ sidx, u8 *__restrict__ ssize, u32 *__restrict__ srec,
     P *__restrict__ pkey, u64 *__restrict__ pval) {
+  // soff / roff: exclusive scans of k_pair_words' workgroup counts
+  __shared__ u32 s_scan[4];
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const u64 t = tiebits[w];
-  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
-  const u64 h3 = small_heads(t, nx, 3), h4 = small_heads(t, nx, 4);
+  u64 t = 0, h3 = 0, h4 = 0;
+  if (w < nwords) {
+    t = tiebits[w];
+    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    h3 = small_heads(t, nx, 3);
+    h4 = small_heads(t, nx, 4);
+  }
   u64 h = h3 | h4;
+  u32 tot;
+  u32 j = soff[blockIdx.x] + block_scan_excl_sum((u32) __popcll(h), &tot, s_scan);
+  u64 r = np + roff[blockIdx.x] +
+          block_scan_excl_sum(3u * (u32) __popcll(h3) + 6u * (u32) __popcll(h4), &tot, s_scan);
   if (h == 0) return;
-  u32 j = soff[w];
-  u64 r = np + roff[w];
   while (h) {
     const int b = __ffsll((unsigned long long) h) - 1;
     h &= h - 1;
@@ -1574,31 +1610,50 @@ __global__ __launch_bounds__(256) void k_small_apply(
 // (smaller position, value | ordinal of the pair << 32) with value = the other
 // position (32-bit positions) or the index of the pair's first entry (64-bit
 // positions: the partner is looked up), and that index again by ordinal; one
-// thread per bitmap word
+// thread per bitmap word.  The workgroup's pairs are staged in LDS and leave in
+// whole lines (a thread's three or four pairs written one by one cost 12.7 GB
+// of HBM writes for 2.7 GB of pairs).  off: exclusive scan of the workgroup counts.
+constexpr int PE_STAGE = 2048;
 template <typename P>
 __global__ __launch_bounds__(256) void k_pair_emit(
     const u64 *__restrict__ tiebits, u64 nwords, const u32 *__restrict__ off,
     const P *__restrict__ sa, P *__restrict__ pkey, u64 *__restrict__ pval,
     u32 *__restrict__ pidx) {
+  __shared__ u32 s_scan[4];
+  __shared__ P s_pk[PE_STAGE];
+  __shared__ u64 s_pv[PE_STAGE];
+  __shared__ u32 s_pi[PE_STAGE];
   const u64 w = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (w >= nwords) return;
-  const u64 t = tiebits[w];
-  const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
-  u64 ph = pair_heads(t, nx);
-  if (ph == 0) return;
-  u32 j = off[w];
+  u64 ph = 0;
+  if (w < nwords) {
+    const u64 t = tiebits[w];
+    const u64 nx = w + 1 < nwords ? tiebits[w + 1] : 0ull;
+    ph = pair_heads(t, nx);
+  }
+  u32 tot;
+  u32 local = block_scan_excl_sum((u32) __popcll(ph), &tot, s_scan);
+  const u32 base = off[blockIdx.x];
+  const bool staged = tot <= (u32) PE_STAGE;
   while (ph) {
     const int b = __ffsll((unsigned long long) ph) - 1;
     ph &= ph - 1;
     const u64 i = w * 64 + b;
-    pkey[j] = sa[i];    // the stable sort left equal keys in position order
+    const u64 j = (u64) base + local;
+    const P a = sa[i];    // the stable sort left equal keys in position order
     // 32-bit positions: the partner travels with the pair (no look-up later)
-    pval[j] = (sizeof(P) == 4 ? (u64) sa[i + 1] : i) | ((u64) j << 32);
-    pidx[j] = (u32) i;
-    j++;
+    const u64 v = (sizeof(P) == 4 ? (u64) sa[i + 1] : i) | (j << 32);
+    if (staged) { s_pk[local] = a; s_pv[local] = v; s_pi[local] = (u32) i; }
+    else { pkey[j] = a; pval[j] = v; pidx[j] = (u32) i; }
+    local++;
+  }
+  if (!staged) return;   // (whole workgroup)
+  __syncthreads();
+  for (u32 k = threadIdx.x; k < tot; k += 256) {
+    pkey[base + k] = s_pk[k];
+    pval[base + k] = s_pv[k];
+    pidx[base + k] = s_pi[k];
   }
 }
-
 
 // order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
 // per thread.  Only reads the suffix array (the rank table is built from it
@@ -3212,14 +3267,15 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u32 *roff = rcnt + nwords + 16;
     u32 *scanws = roff + nwords + 16;
     u32 *pws = scanws + scan_workspace_words(nwords) + 64;   // radix workspace (NL pairs)
+    const u64 nwb = div_up(nwords, 256);   // workgroups of 256 bitmap words
     auto tie_words = [&](const u64 *bits) -> int {
       if (NL > 0) {
-        k_tie_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(bits, nwords, cntw, headw);
+        k_tie_words<<<(u32) nwb, 256, 0, st>>>(bits, nwords, cntw, headw);
         HIP_TRY(hipGetLastError());
-        TRY(scan_u32(SCAN_SUM, cntw, offw, nwords, false, scanws, st));
+        TRY(scan_u32(SCAN_SUM, cntw, offw, nwb, false, scanws, st));
         TRY(scan_u32(SCAN_MAX, headw, carry, nwords, false, scanws, st));
       }
-      k_total<<<1, 1, 0, st>>>(offw, cntw, nwords, c->d_stats);
+      k_total<<<1, 1, 0, st>>>(offw, cntw, NL > 0 ? nwb : 0, c->d_stats);
       HIP_TRY(hipGetLastError());
       TRY(fetch_stats(c));
       return 0;
@@ -3288,15 +3344,14 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       if (no_pairs) {
         HIP_TRY(hipMemcpyAsync(tiebits2, tiebits, nwords * 8, hipMemcpyDeviceToDevice, st));
       } else {
-        k_pair_words<<<(u32) div_up(nwords, 256), 256, 0, st>>>(tiebits, nwords, pcnt, scnt,
-                                                               rcnt, tiebits2);
+        k_pair_words<<<(u32) nwb, 256, 0, st>>>(tiebits, nwords, pcnt, scnt, rcnt, tiebits2);
         HIP_TRY(hipGetLastError());
-        TRY(scan_u32(SCAN_SUM, pcnt, poff, nwords, false, scanws, st));
-        TRY(scan_u32(SCAN_SUM, scnt, soff, nwords, false, scanws, st));
-        TRY(scan_u32(SCAN_SUM, rcnt, roff, nwords, false, scanws, st));
-        k_total2<<<1, 1, 0, st>>>(poff, pcnt, nwords, c->d_stats);
-        k_total3<<<1, 1, 0, st>>>(soff, scnt, nwords, c->d_stats);
-        k_total<<<1, 1, 0, st>>>(roff, rcnt, nwords, c->d_stats);
+        TRY(scan_u32(SCAN_SUM, pcnt, poff, nwb, false, scanws, st));
+        TRY(scan_u32(SCAN_SUM, scnt, soff, nwb, false, scanws, st));
+        TRY(scan_u32(SCAN_SUM, rcnt, roff, nwb, false, scanws, st));
+        k_total2<<<1, 1, 0, st>>>(poff, pcnt, nwb, c->d_stats);
+        k_total3<<<1, 1, 0, st>>>(soff, scnt, nwb, c->d_stats);
+        k_total<<<1, 1, 0, st>>>(roff, rcnt, nwb, c->d_stats);
         HIP_TRY(hipGetLastError());
         TRY(fetch_stats(c));
         npairs = c->h_stats->count2;

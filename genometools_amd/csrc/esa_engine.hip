@@ -8,10 +8,17 @@
 //   sort      stable LSD radix sort of (key, position)        [esa_prims.hip]
 //   finalize  widen positions to .suf, LCP from clz(key xor key'), BWT from
 //             the key payload, mark suffixes tied on the whole key
-//   refine    only for tied suffixes: prefix doubling on a rank table
-//             (rank of suffix p+h decides among suffixes equal on h symbols)
+//   pairs     tie groups of two (most tied suffixes of a genome: low-copy
+//             repeats): one comparison on the packed text each, amortised
+//             along the text; groups of three and four through the same list
+//   refine    what is left: prefix doubling on a rank table (rank of suffix
+//             p+h decides among suffixes equal on h symbols), built only for
+//             the windows of positions the rounds can reach
 //   fixtied   LCP (direct word compare on the packed text) and BWT of the
 //             tied suffixes, .llv pairs
+// A part build (one of R lexicographic ranges, one per GPU) makes the keys of
+// its text tile, exchanges the pairs with the range owners and keeps the rank
+// table cut by text position (see "part builds" below).
 //
 // What the reference does instead (for the record, not followed): bucket by a
 // k-mer prefix (src/match/sfx-suffixer.c:1703,2012), then sort each bucket with

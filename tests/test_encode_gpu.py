@@ -191,3 +191,54 @@ def test_device_encoder_large_input_and_engine_handover(gpu, host, tmp_path):
             eng.run(esa.WANT_SUF)
             suf = eng.table(esa.TAB_SUF)
     assert ou.check_suffix_array(enc, suf)[0] == 0
+
+
+def test_capacity_is_checked(gpu, tmp_path):
+    """every entry point that fills caller arrays takes their capacity and
+    writes nothing when the section does not fit (round 1's fuzz campaign
+    stopped on an overwritten heap block once: no entry point may be able to)"""
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 3, 100000)
+    path = str(tmp_path / "cap.fna")
+    synth.write_fasta(path, enc)
+    lib = gpu
+    with encode.DeviceEncoder() as de:
+        de.encode([path])
+        k = lib.gtamd_encoder_num_descriptions(de._enc)
+        assert k == 24
+        guard = 0xA5A5A5A5A5A5A5A5
+        f = np.full(k, 7, dtype=np.uint32)
+        a = np.full(k, guard, dtype=np.uint64)
+        b = np.full(k, guard, dtype=np.uint64)
+        assert lib.gtamd_encoder_get_descriptions(de._enc, f.ctypes.data, a.ctypes.data,
+                                                  b.ctypes.data, k - 1) == -1
+        assert b"do not fit" in lib.gtamd_esa_last_error()
+        assert (a == guard).all() and (b == guard).all() and (f == 7).all()
+        assert lib.gtamd_encoder_get_descriptions(de._enc, f.ctypes.data, a.ctypes.data,
+                                                  b.ctypes.data, k) == 0
+        s = de.summary()
+        n = de.length
+        words = np.full(2 + (n - 1) // 32, guard, dtype=np.uint64)
+        assert lib.gtamd_encoder_pack_twobit(de._enc, 1, 0, words.ctypes.data, words.size - 1) == -1
+        assert (words == guard).all()
+        assert lib.gtamd_encoder_pack_twobit(de._enc, 1, 0, words.ctypes.data, words.size) == 0
+        sb = np.full(1 + (n + 63) // 64, guard, dtype=np.uint64)
+        assert lib.gtamd_encoder_pack_specialbits(de._enc, sb.ctypes.data, sb.size - 1) == -1
+        assert (sb == guard).all()
+        assert lib.gtamd_encoder_pack_specialbits(de._enc, sb.ctypes.data, sb.size) == 0
+        pk = np.full((3 * n + 7) // 8, 0xA5, dtype=np.uint8)
+        assert lib.gtamd_encoder_pack_bytecompress(de._enc, pk.ctypes.data, pk.size - 1) == -1
+        assert (pk == 0xA5).all()
+        runs = s["realwildcardranges"]
+        ws = np.full(runs, guard, dtype=np.uint64)
+        wl = np.full(runs, guard, dtype=np.uint64)
+        assert lib.gtamd_encoder_get_wildcard_runs(de._enc, ws.ctypes.data, wl.ctypes.data,
+                                                   runs - 1) == -1
+        assert (ws == guard).all() and (wl == guard).all()
+        assert lib.gtamd_encoder_get_wildcard_runs(de._enc, ws.ctypes.data, wl.ctypes.data,
+                                                   runs) == 0
+        assert int(wl.sum()) == s["wildcards"]
+        sep = np.full(23, guard, dtype=np.uint64)
+        assert lib.gtamd_encoder_get_separators(de._enc, sep.ctypes.data, 22) == -1
+        assert (sep == guard).all()
+        assert lib.gtamd_encoder_get_separators(de._enc, sep.ctypes.data, 23) == 0
+        assert np.array_equal(sep, np.flatnonzero(enc == 255).astype(np.uint64))

@@ -1830,7 +1830,7 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
     P *__restrict__ cv, u32 *__restrict__ hv, const u32 *__restrict__ tstart,
     u32 *__restrict__ flagbits, const P *__restrict__ rank, u64 h, u64 n) {
   // tstart: the tiles start at group borders (k_tile_starts), so that a group
-  // no larger than RT_TILE - RT_STRIDE never reaches across a border; a tile
+  // no larger than the tiles' slack never reaches across a border; a tile
   // that is larger than the LDS arrays is worked off in chunks, with the groups
   // across chunk borders left to the global path (flagbits: one bit per slot)
   // rank != nullptr: look the ranks up here (k2[j] = rank[upos[j] + h]) instead
@@ -2042,17 +2042,18 @@ __global__ __launch_bounds__(RT_THREADS) void k_round_tile(
 // where the tiles of a round start: at the multiples of RT_STRIDE slots, moved
 // back to the first slot of the group that lies there (a group that starts
 // more than RT_TILE slots before stays cut: it is larger than a tile anyway)
-constexpr int RT_STRIDE = RT_TILE - 512;
+constexpr int RT_STRIDE_MIN = 512;
 __global__ __launch_bounds__(256) void k_tile_starts(const u32 *__restrict__ ugrp, u64 m,
-                                                     u32 ntiles, u32 *__restrict__ tstart) {
+                                                     u32 ntiles, u32 stride,
+                                                     u32 *__restrict__ tstart) {
   const u32 t = blockIdx.x * 256 + threadIdx.x;
   if (t > ntiles) return;
   if (t == ntiles) { tstart[t] = (u32) m; return; }
-  u64 s = (u64) t * RT_STRIDE;
+  u64 s = (u64) t * stride;
   const u32 g = ugrp[s];
   int steps = 0;
   while (s > 0 && ugrp[s - 1] == g && steps < RT_TILE) { s--; steps++; }
-  if (steps == RT_TILE) s = (u64) t * RT_STRIDE;
+  if (steps == RT_TILE) s = (u64) t * stride;
   tstart[t] = (u32) s;
 }
 
@@ -3490,7 +3491,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       koff = a.take<u32>(mp);
       k2 = a.take<P>(mp);            // rank of the suffix h further on
       flagbits = a.take<u32>(mp / 32 + RT_TILE / 32 + 64);   // deferred to the global path (1 bit per slot)
-      tstart = a.take<u32>(mp / RT_STRIDE + 64);              // where the tiles of a round start
+      tstart = a.take<u32>(mp / RT_STRIDE_MIN + 64);          // where the tiles of a round start
       // global path of a round (groups across tile borders)
       fk2 = a.take<P>(mp); fk2s_a = a.take<P>(mp); fk2s_b = a.take<P>(mp);
       fpos = a.take<P>(mp); cvs = a.take<P>(mp);
@@ -3770,6 +3771,14 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     int gs[8], gw[8];
     const int gn = passes_for(nbl, gs, gw);
     u64 m = m0, h = (u64) K::SYMS;
+    // nominal distance of the round tiles' starts: the rest of a tile is the
+    // slack for the group that lies across (a group larger than the slack goes
+    // through the global path, forty launches per round)
+    u32 rt_stride = 1536;
+    if (const char *e = getenv("GTAMD_ROUND_STRIDE")) {
+      const int v = atoi(e);
+      if (v >= RT_STRIDE_MIN && v <= RT_TILE) rt_stride = (u32) v;
+    }
     // part builds: the queries of the coming round and the rank updates of the
     // last one are bucketed by owner before the parts agree on the counts
     RankQueries<P> rq;
@@ -3891,11 +3900,11 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         if (c->h_stats->count2 != 0) TRY(build_rank(false));
       }
       const u32 g = (u32) div_up(m, 256);
-      const u32 ntiles = (u32) div_up(m, RT_STRIDE);   // tiles that start at group borders
+      const u32 ntiles = (u32) div_up(m, rt_stride);   // tiles that start at group borders
       const u32 nfb = (u32) div_up(m, RT_TILE);         // blocks of the deferred-slot bitmap
       u32 *tilecnt = koff, *tileoff = koff + nfb + 16;  // (free until the apply step)
       HIP_TRY(hipMemsetAsync(flagbits, 0, (u64) nfb * (RT_TILE / 8), st));
-      k_tile_starts<<<ntiles / 256 + 1, 256, 0, st>>>(ugrp, m, ntiles, tstart);
+      k_tile_starts<<<ntiles / 256 + 1, 256, 0, st>>>(ugrp, m, ntiles, rt_stride, tstart);
       HIP_TRY(hipGetLastError());
       k_round_tile<P><<<ntiles, RT_THREADS, 0, st>>>(
           uidx, upos, ugrp, k2, m, cvo, hv, tstart, flagbits, dist ? nullptr : rank, h, n);

@@ -1,11 +1,20 @@
 /* gt-suffixerator-amd: command line entry, behaves like `gt suffixerator`
-   (exit code 1 and "gt suffixerator: error: ..." on stderr, src/gt.c:48-52) */
+   (exit code 1 and "gt suffixerator: error: ..." on stderr, src/gt.c:48-52);
+   `gt-suffixerator-amd mergeesa ...` is `gt dev mergeesa ...` */
 #include <stdio.h>
+#include <string.h>
 #include "gtamd_host.h"
 
 int main(int argc, char **argv)
 {
   char err[2048] = "";
+  if (argc > 1 && !strcmp(argv[1], "mergeesa")) {
+    if (gtamd_mergeesa(argc - 1, (const char **) argv + 1, err, sizeof err) != 0) {
+      fprintf(stderr, "gt dev mergeesa: error: %s\n", err);
+      return 1;
+    }
+    return 0;
+  }
   if (gtamd_suffixerator(argc, (const char **) argv, err, sizeof err) != 0) {
     fprintf(stderr, "gt suffixerator: error: %s\n", err);
     return 1;

@@ -498,3 +498,85 @@ done:
   free(enc);
   return rc;
 }
+
+/* ---------------------------------------------------------------------------
+   gt dev mergeesa (src/tools/gt_mergeesa.c, src/match/test-mergeesa.c:110-190,
+   src/match/esa-merge.c:136-200): INDEX.suf / .lcp / .llv of the concatenation
+   of the sequence sets of several indexes, in the order given, one separator
+   between consecutive sets (src/match/encseq2offset.c) -- by the reference's
+   own test the very tables `gt suffixerator` writes for all the files at once
+   (testsuite/gt_mergeesa_include.rb:17-19).  The reference merges the input
+   tables through a trie because sorting is what costs it minutes; on a device
+   that sorts 15 Gbp/s the merge IS a build: the encoded sequences of the input
+   indexes are read (INDEX.esq, any access type), joined and built.  The input
+   .suf/.lcp tables only have to exist (as the reference demands of its input).
+   --------------------------------------------------------------------------- */
+int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen)
+{
+  const char *indexname = NULL;
+  const char **inputs = NULL;
+  size_t numinputs = 0;
+  uint8_t *all = NULL;
+  uint64_t total = 0;
+  int protein_all = -1, rc = -1;
+  gtamd_esa_ctx *ctx = NULL;
+
+  for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-indexname")) {
+      if (++i >= argc) return fail(err, errlen, "missing argument to option \"%s\"", "-indexname");
+      indexname = argv[i];
+    } else if (!strcmp(argv[i], "-ii")) {
+      inputs = argv + i + 1;
+      while (i + 1 < argc && argv[i + 1][0] != '-') { i++; numinputs++; }
+    } else
+      return fail(err, errlen, "unknown option: %s (try -indexname NAME -ii INDEX...)", argv[i]);
+  }
+  if (indexname == NULL) return fail(err, errlen, "option \"%s\" is mandatory", "-indexname");
+  if (numinputs == 0) return fail(err, errlen, "option \"%s\" is mandatory", "-ii");
+  printf("# storeindex=%s\n", indexname);
+  for (size_t k = 0; k < numinputs; k++) {
+    uint8_t *enc = NULL, *grown;
+    uint64_t n = 0;
+    int protein = 0;
+    gtamd_seqstats ss;
+    char path[4096];
+    FILE *fp;
+    printf("# input=%s\n", inputs[k]);
+    /* the reference maps SARR_SUFTAB | SARR_LCPTAB of every input */
+    snprintf(path, sizeof path, "%s.suf", inputs[k]);
+    if ((fp = fopen(path, "rb")) == NULL) { fail(err, errlen, "cannot open file '%s'", path); goto done; }
+    fclose(fp);
+    snprintf(path, sizeof path, "%s.lcp", inputs[k]);
+    if ((fp = fopen(path, "rb")) == NULL) { fail(err, errlen, "cannot open file '%s'", path); goto done; }
+    fclose(fp);
+    if (gtamd_read_esq(inputs[k], &enc, &n, &protein, &ss, err, errlen) != 0) goto done;
+    if (protein_all >= 0 && protein != protein_all) {
+      free(enc);
+      fail(err, errlen, "index '%s' has another alphabet than the indexes before it", inputs[k]);
+      goto done;
+    }
+    protein_all = protein;
+    grown = realloc(all, total + n + 2);
+    if (grown == NULL) { free(enc); fail(err, errlen, "out of memory (%s)", "mergeesa"); goto done; }
+    all = grown;
+    if (k > 0) all[total++] = (uint8_t) GTAMD_SEPARATOR;
+    memcpy(all + total, enc, n);
+    total += n;
+    free(enc);
+  }
+  ctx = gtamd_esa_create(0, total, protein_all ? 20 : 4);
+  if (ctx == NULL || gtamd_esa_set_sequence_bytes(ctx, all, total, 0) != 0 ||
+      gtamd_esa_run(ctx, GTAMD_WANT_SUF | GTAMD_WANT_LCP) != 0) {
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+    goto done;
+  }
+  if (write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", 8, err, errlen) != 0 ||
+      write_table(ctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0 ||
+      write_table(ctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0)
+    goto done;
+  rc = 0;
+done:
+  gtamd_esa_destroy(ctx);
+  free(all);
+  return rc;
+}

@@ -239,6 +239,16 @@ int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
    caller prints "gt suffixerator: error: <err>" and exits 1, src/gt.c:48-52). */
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen);
 
+/* `gt dev mergeesa -indexname OUT -ii INDEX1 INDEX2 ...` (tool function
+   src/tools/gt_mergeesa.c:61, engine src/match/esa-merge.c:136-200, output
+   src/match/test-mergeesa.c:110-190): OUT.suf / OUT.lcp / OUT.llv of the
+   concatenation of the indexes' sequence sets -- byte for byte what
+   `gt suffixerator` writes for all their files at once, which is what the
+   reference's own test compares the merge with
+   (testsuite/gt_mergeesa_include.rb:17-19).  Here the merge is a build on the
+   device from the input indexes' INDEX.esq. */
+int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

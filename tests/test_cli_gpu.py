@@ -356,3 +356,33 @@ def test_cli_lossless_with_tables(cli, name, tmp_path):
         with open(idx + "." + ext, "rb") as f:
             assert hashlib.md5(f.read()).hexdigest() == e["tables"][ext]["md5"], ext
     assert _reference_accepts(idx).returncode == 0
+
+
+@pytest.mark.parametrize("files", [["Atinsert.fna", "Duplicate.fna"],
+                                   ["Random.fna", "RandomN.fna", "TTTN.fna", "Atinsert.fna"],
+                                   ["sw100K1.fsa", "sw100K2.fsa"]])
+def test_mergeesa_equals_suffixerator_over_all_files(cli, files, tmp_path):
+    """the reference's own merge test (testsuite/gt_mergeesa_include.rb:1-22): one
+    index per file, `gt dev mergeesa`, and `cmp` of .suf/.lcp/.llv with the index
+    over all files at once"""
+    protein = files[0].endswith(".fsa")
+    kind = "-protein" if protein else "-dna"
+    paths = [ou.fixture_path(f) for f in files]
+    subprocess.run([cli, kind, "-suf", "-lcp", "-indexname", str(tmp_path / "all"), "-db"] + paths,
+                   check=True)
+    idx = []
+    for k, p in enumerate(paths):
+        idx.append(str(tmp_path / ("midx%d" % k)))
+        subprocess.run([cli, kind, "-suf", "-lcp", "-indexname", idx[-1], "-db", p], check=True)
+    out = subprocess.run([cli, "mergeesa", "-indexname", str(tmp_path / "midx-all"), "-ii"] + idx,
+                         check=True, capture_output=True, text=True).stdout
+    assert out.startswith("# storeindex=")
+    for ext in ("suf", "lcp", "llv"):
+        with open(str(tmp_path / "all") + "." + ext, "rb") as a, \
+                open(str(tmp_path / "midx-all") + "." + ext, "rb") as b:
+            assert a.read() == b.read(), ext
+    # an input without tables is refused, as the reference refuses to map it
+    os.remove(idx[0] + ".lcp")
+    r = subprocess.run([cli, "mergeesa", "-indexname", str(tmp_path / "x"), "-ii"] + idx,
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "gt dev mergeesa: error: cannot open file" in r.stderr

@@ -614,3 +614,22 @@ def test_tool_lossless_matches_reference(host, name, tmp_path):
         assert len(raw) == v["bytes"], ext
         assert hashlib.md5(raw).hexdigest() == v["md5"], ext
     assert os.path.exists(idx + ".ois")
+
+
+def test_mergeesa_option_errors(host, tmp_path):
+    """`gt dev mergeesa` (include/gtamd_host.h gtamd_mergeesa): the mandatory
+    options and unreadable inputs are reported before any device is touched"""
+    host.gtamd_mergeesa.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                    ctypes.c_char_p, ctypes.c_size_t]
+
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"mergeesa", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        return host.gtamd_mergeesa(len(args) + 1, argv, err, 2048), err.value.decode()
+
+    assert run("-ii", "a", "b") == (-1, 'option "-indexname" is mandatory')
+    assert run("-indexname", "x") == (-1, 'option "-ii" is mandatory')
+    rc, msg = run("-indexname", str(tmp_path / "x"), "-ii", str(tmp_path / "nothere"))
+    assert rc == -1 and "cannot open file" in msg and "nothere.suf" in msg
+    rc, msg = run("-frobnicate")
+    assert rc == -1 and "unknown option" in msg

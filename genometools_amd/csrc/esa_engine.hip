@@ -1663,15 +1663,14 @@ __global__ __launch_bounds__(256) void k_pair_emit(
 }
 
 // order and LCP of every pair, LCP_CHUNK consecutive pairs (by text position)
-// per thread.  Only reads the suffix array (the rank table is built from it
-// at the same time on another stream): k_pair_swap puts the pairs in order,
-// the tables get their entries from k_pair_apply -- both walk the pairs in
-// TABLE order (in text order the five accesses per pair of the apply step
-// were five random lines: 18 ms for 170 M pairs)
+// per thread; a pair in the wrong order changes places in the suffix array
+// here, the tables get their entries from k_pair_apply, which walks the pairs
+// in TABLE order (in text order its five accesses per pair were five random
+// lines: 18 ms for 170 M pairs)
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
     Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 nrec, u64 np,
-    const P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
+    const u32 *__restrict__ pidx, P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
   // records with ordinal < np are pairs (their LCP is a table entry: counted in
   // the statistics); the others are pairs of members of small groups
   __shared__ unsigned long long s_sum[4], s_large[4];
@@ -1726,6 +1725,15 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
       const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
       res[j] = lv | (a_first ? 0u : PAIR_SWAP);   // by ordinal: the later steps walk the table
       if (j < np) {
+        // a pair in the wrong order changes places here (both positions are at
+        // hand; this kernel waits for memory anyway -- as a kernel of its own
+        // the swap was 5.4 ms of read-modify-write); the small groups are
+        // sorted by k_small_combine
+        if (!a_first) {
+          const u64 i = sizeof(P) == 4 ? (u64) pidx[j] : (iv & 0xFFFFFFFFull);
+          sa[i] = (P) b;
+          sa[i + 1] = (P) a;
+        }
         sum += lv;     // tied suffixes have >= KEY_SYMS >= prefixlength letters
         nlarge += lv >= GTAMD_LCPOVERFLOW;
         mx = lv > mx ? lv : mx;
@@ -1750,24 +1758,6 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
     if (S) atomicAdd(&stats->lcpsum, S);
     if (Lg) atomicAdd(&stats->numlarge, Lg);
     if (M) atomicMax(&stats->maxlcp, M);
-  }
-}
-
-// pairs in the wrong order change places in the suffix array; where a rank
-// table has been built from the old order (single builds), its two entries too
-template <typename P>
-__global__ __launch_bounds__(256) void k_pair_swap(
-    const u32 *__restrict__ pidx, const u32 *__restrict__ res, u64 np,
-    P *__restrict__ sa, P *__restrict__ rank, u64 rank_offset) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= np || !(res[j] & PAIR_SWAP)) return;
-  const u64 i = pidx[j];
-  const P a = sa[i], b = sa[i + 1];
-  sa[i] = b;
-  sa[i + 1] = a;
-  if (rank != nullptr) {
-    rank[b] = (P) (rank_offset + i);
-    rank[a] = (P) (rank_offset + i + 1);
   }
 }
 
@@ -2470,8 +2460,7 @@ struct gtamd_esa_ctx {
   u64 max_n, n, N;         // N = n + 1 entries
   int readmode;            // GtReadmode of the sequence handed in as bytes
   hipStream_t st, st2;     // st2: table emission beside the refinement
-  hipStream_t st3;         // rank table build beside the pair comparisons
-  hipEvent_t ev_sorted, ev_emitted, ev_rank_in, ev_rank_done;
+  hipEvent_t ev_sorted, ev_emitted;
   // resident sequence
   DevBuf tb_own, sp_own;
   Text text;
@@ -2528,7 +2517,6 @@ static int ensure_buf(gtamd_esa_ctx *c, DevBuf &b, u64 bytes, const char *what) 
   if (bytes <= b.bytes) return 0;
   HIP_TRY(hipStreamSynchronize(c->st));
   HIP_TRY(hipStreamSynchronize(c->st2));
-  HIP_TRY(hipStreamSynchronize(c->st3));
   const auto t0 = std::chrono::steady_clock::now();
   c->alloc_bytes -= b.bytes;
   free_buf(b);
@@ -2558,7 +2546,6 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   (void) hipSetDevice(c->device);
   if (c->st != nullptr) (void) hipStreamSynchronize(c->st);
   if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
-  if (c->st3 != nullptr) (void) hipStreamSynchronize(c->st3);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
                     &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf};
@@ -2572,9 +2559,6 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
   if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
   if (c->ev_emitted != nullptr) (void) hipEventDestroy(c->ev_emitted);
-  if (c->ev_rank_in != nullptr) (void) hipEventDestroy(c->ev_rank_in);
-  if (c->ev_rank_done != nullptr) (void) hipEventDestroy(c->ev_rank_done);
-  if (c->st3 != nullptr) (void) hipStreamDestroy(c->st3);
   if (c->st2 != nullptr) (void) hipStreamDestroy(c->st2);
   if (c->st != nullptr) (void) hipStreamDestroy(c->st);
   delete c;
@@ -2629,9 +2613,6 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   CTX_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
-  CTX_TRY(hipStreamCreateWithFlags(&c->st3, hipStreamNonBlocking));
-  CTX_TRY(hipEventCreateWithFlags(&c->ev_rank_in, hipEventDisableTiming));
-  CTX_TRY(hipEventCreateWithFlags(&c->ev_rank_done, hipEventDisableTiming));
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
   CTX_TRY(hipHostMalloc(&c->h_counts, 4 * DEST_MAXPARTS * 4, hipHostMallocDefault));
@@ -3223,14 +3204,12 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // It is started where the first stream turns latency-bound (the comparisons
   // of the pair path, the rounds), so that the two actually overlap; whatever
   // it writes for tied entries is provisional and overwritten after the join.
-  bool emitted = false, rank_building = false;
+  bool emitted = false;
   auto launch_emission = [&]() -> int {
     if (emitted) return 0;
     emitted = true;
     HIP_TRY(hipEventRecord(c->ev_sorted, st));
     HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
-    // (two bandwidth-bound jobs at once gain nothing: behind the rank build)
-    if (rank_building) HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_rank_done, 0));
     if (NL > 0) {
       k_finalize<BITS, P><<<stride_grid(div_up(NL, FIN_TILE)), FIN_THREADS, 0, c->st2>>>(
           skey, sa, NL, prefixlength, d_suf, d_lcp, d_bwt, nullptr,
@@ -3429,13 +3408,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
       TRY(launch_emission());   // bandwidth-bound, beside the comparisons
       k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, nrec, npairs, sa, pres, c->d_stats);
+          c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats);
       HIP_TRY(hipGetLastError());
-      // pairs in the wrong order change places; the small groups are sorted
-      if (npairs > 0) {
-        k_pair_swap<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(pidx, pres, npairs, sa, nullptr, 0);
-        HIP_TRY(hipGetLastError());
-      }
       if (nsmall > 0) {
         k_small_combine<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(
             sidx, ssize, srec, pres, nsmall, sa, tiebits2, sres, slcp, c->d_stats);

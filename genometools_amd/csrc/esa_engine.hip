@@ -2452,6 +2452,8 @@ static inline u32 stride_grid(u64 tiles) {
   return (u32) (tiles < cap ? (tiles ? tiles : 1) : cap);
 }
 
+#include "esa_msd.h"
+
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
@@ -2480,6 +2482,7 @@ struct gtamd_esa_ctx {
   DevBuf isa_tmp;          // 8 B per entry: partitioned pairs of the rank build /
                            // bucketing scratch and 64-bit positions of a part build
   DevBuf rws;              // radix / scan workspace
+  DevBuf msd;              // tables of the most-significant-digit-first sort (esa_msd.h)
   DevBuf dig0, dig1;       // digit side arrays of the first sort (experiment)
   DevBuf suf, lcp, bwt;    // outputs at on-disk width
   DevBuf tiebits, tiebits2;
@@ -2557,7 +2560,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
-                    &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf};
+                    &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf, &c->msd};
   for (DevBuf *b : bufs) free_buf(*b);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
@@ -2950,6 +2953,202 @@ static int ensure_workspace(gtamd_esa_ctx *c, u64 cap, u32 want, bool dist) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// the first sort of a DNA whole-table build, most significant digit first
+// (esa_msd.h): keygen, sort, tie bitmap and table emission in one go
+// ---------------------------------------------------------------------------
+static int msd_cbits(u64 N) {
+  if (const char *e = getenv("GTAMD_MSD_CBITS")) {   // tests: every depth at small N
+    const int v = atoi(e);
+    if (v >= 0 && v <= 8) return v;
+  }
+  const int c = bits_for(N > 1 ? N - 1 : 1) - 24;    // ranges of ~256 entries after level C
+  return c < 0 ? 0 : (c > 8 ? 8 : c);
+}
+static u32 msd_big_max() {
+  if (const char *e = getenv("GTAMD_MSD_BIG_MAX")) {   // tests: the giant path at small N
+    const long v = atol(e);
+    if (v >= MS_TILE && v <= (long) MSD_BIG_MAX) return (u32) v;
+  }
+  return MSD_BIG_MAX;
+}
+struct MsdWs {
+  u32 *hist, *scanws, *tcnt, *tfirst, *dtcnt, *dtfirst, *startA, *startB, *F, *scan2, *counters,
+      *biglist, *giantlist;
+  MsTile *desc;
+  MdTile *dtiles;
+  u64 *firstkey, *lastkey;
+  u32 rows, tilesB_ub, tilesC_ub, tilesD_ub;
+  u64 nf;
+};
+static u64 msd_carve(u64 N, int cb, u8 *base, MsdWs *w) {
+  const u32 ntA = (u32) div_up(N, MS_TILE);
+  w->tilesB_ub = ntA + 256;
+  w->tilesC_ub = ntA + MSD_PARENTS;
+  w->tilesD_ub = (u32) div_up(N, MSD_STRIDE) + MSD_PARENTS;
+  w->rows = w->tilesC_ub + 2;
+  w->nf = (u64) MSD_PARENTS << cb;
+  Bump b;
+  b.base = base;
+  b.off = 0;
+  w->hist = b.take<u32>((u64) w->rows * 256);
+  w->scanws = b.take<u32>(radix_rows_workspace_words(w->rows));
+  w->desc = b.take<MsTile>(w->tilesC_ub);
+  w->tcnt = b.take<u32>(MSD_PARENTS + 8);
+  w->tfirst = b.take<u32>(MSD_PARENTS + 8);
+  w->dtcnt = b.take<u32>(MSD_PARENTS + 8);
+  w->dtfirst = b.take<u32>(MSD_PARENTS + 8);
+  w->startA = b.take<u32>(256 + 8);
+  w->startB = b.take<u32>(MSD_PARENTS + 8);
+  w->F = b.take<u32>(w->nf + 8);
+  w->scan2 = b.take<u32>(scan_workspace_words(w->nf + 1) + 64);
+  w->counters = b.take<u32>(16);
+  w->dtiles = b.take<MdTile>(w->tilesD_ub);
+  w->firstkey = b.take<u64>(w->tilesD_ub);
+  w->lastkey = b.take<u64>(w->tilesD_ub);
+  w->biglist = b.take<u32>(w->tilesD_ub);
+  w->giantlist = b.take<u32>((u64) (N / MS_TILE) + 8);
+  return b.off + 256;
+}
+
+// One level below A: parents pstart[0 .. np], digit = the top `cb` bits of the
+// key word.  prepare: tiles, histogram, scan, child starts (cstart, (np << cb)
+// + 1 entries); scatter: the move.
+static int msd_level_prepare(gtamd_esa_ctx *c, const MsdWs &w, const u32 *pstart, u32 np, int cb,
+                             u32 tiles_ub, const u32 *kin, u32 *cstart) {
+  hipStream_t st = c->st;
+  k_msd_tilecount<<<(np + 1 + 255) / 256, 256, 0, st>>>(pstart, 0, np, (u32) MS_TILE, w.tcnt);
+  HIP_TRY(hipGetLastError());
+  TRY(scan_u32(SCAN_SUM, w.tcnt, w.tfirst, (u64) np + 1, false, w.scan2, st));
+  k_msd_tiledesc<<<(tiles_ub + 255) / 256, 256, 0, st>>>(pstart, w.tfirst, np, tiles_ub, w.desc);
+  HIP_TRY(hipGetLastError());
+  k_msd_hist_lvl<<<tiles_ub + 1, MS_THREADS, 0, st>>>(kin, w.desc, tiles_ub, 32 - cb, w.hist);
+  HIP_TRY(hipGetLastError());
+  TRY(radix_scan_tile_rows(w.hist, tiles_ub + 1, w.scanws, st));
+  const u64 nchild = (u64) np << cb;
+  k_msd_tot<<<(u32) div_up(nchild + 1, 256), 256, 0, st>>>(w.hist, w.tfirst, np, cb, cstart);
+  HIP_TRY(hipGetLastError());
+  TRY(scan_u32(SCAN_SUM, cstart, cstart, nchild + 1, false, w.scan2, st));
+  return 0;
+}
+
+// on return the tables are emitted (provisional for tied entries, as after
+// k_finalize): *sa_out holds the positions in suffix order, (*fkey, *fval) are
+// free buffers of 8 / 4 bytes per entry, the tie bitmap and stats->numties are set
+static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_out,
+                         u64 **fkey, u32 **fval) {
+  const u64 N = c->N;
+  hipStream_t st = c->st;
+  const int cb = msd_cbits(N);
+  MsdWs w;
+  const u64 bytes = msd_carve(N, cb, nullptr, &w);
+  TRY(ensure_buf(c, c->msd, bytes, "the tables of the first sort"));
+  (void) msd_carve(N, cb, c->msd.as<u8>(), &w);
+  const u32 ntA = (u32) div_up(N, MS_TILE);
+  const u32 last_valid = (u32) (N - (u64) (ntA - 1) * MS_TILE);
+  const u64 pad = N + 8;
+  // buffer pairs: (k0, v0) and (k1, v1) as 32-bit keys and positions; the bytes
+  // of level A in the upper half of k1
+  u32 *ka = c->k0.as<u32>(), *pa = c->v0.as<u32>();
+  u32 *kb = c->k1.as<u32>(), *pb = c->v1.as<u32>();
+  u8 *xa = c->k1.as<u8>() + pad * 4;
+  // ---- level A
+  k_msd_hist_a<<<ntA, MS_THREADS, 0, st>>>(c->text, N, w.hist);
+  HIP_TRY(hipGetLastError());
+  TRY(radix_scan_tile_rows(w.hist, ntA, w.scanws, st));
+  k_msd_starts_a<<<1, 256, 0, st>>>(w.hist, (u32) N, w.startA);
+  HIP_TRY(hipGetLastError());
+  k_msd_scatter_a<<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(c->text, N, last_valid, w.hist,
+                                                               ntA, ka, xa, pa);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev[1], st));
+  // ---- level B: (ka, xa, pa) -> (kb, pb)
+  TRY(msd_level_prepare(c, w, w.startA, 256, 8, w.tilesB_ub, ka, w.startB));
+  k_msd_scatter_lvl<1><<<((w.tilesB_ub + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+      ka, xa, pa, w.desc, w.tilesB_ub, w.hist, w.tfirst, w.startB, 8, 24, kb, pb);
+  HIP_TRY(hipGetLastError());
+  // ---- level C: (kb, pb) -> (ka, pa); its scatter waits for the look at the tiles
+  u32 *kf = kb, *pf = pb, *ko = ka, *po = pa;   // (kf, pf): where the finest level ends up
+  const u32 *F = w.startB;
+  if (cb > 0) {
+    TRY(msd_level_prepare(c, w, w.startB, MSD_PARENTS, cb, w.tilesC_ub, kb, w.F));
+    F = w.F;
+    kf = ka; pf = pa; ko = kb; po = pb;
+  }
+  // ---- level D tiles, and a look at them
+  HIP_TRY(hipMemsetAsync(w.counters, 0, 64, st));
+  k_msd_tilecount<<<(MSD_PARENTS + 1 + 255) / 256, 256, 0, st>>>(F, cb, MSD_PARENTS, MSD_STRIDE,
+                                                               w.dtcnt);
+  HIP_TRY(hipGetLastError());
+  TRY(scan_u32(SCAN_SUM, w.dtcnt, w.dtfirst, (u64) MSD_PARENTS + 1, false, w.scan2, st));
+  k_msd_dtiles<<<(w.tilesD_ub + 255) / 256, 256, 0, st>>>(F, cb, w.dtfirst, w.tilesD_ub, w.dtiles,
+                                                        w.biglist, w.giantlist, w.counters,
+                                                        msd_big_max());
+  HIP_TRY(hipGetLastError());
+  u32 *hc = c->h_counts;
+  HIP_TRY(hipMemcpyAsync(hc, w.counters, 16, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(hc + 4, w.dtfirst + MSD_PARENTS, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const u32 nbig = hc[0], maxrun = hc[1], nbigentries = hc[2], ngiant = hc[3], ntD = hc[4];
+  if (getenv("GTAMD_DEBUG") != nullptr)
+    fprintf(stderr, "gtamd: msd sort: %d bits at level C, %u runs, %u big (largest %u, %u entries "
+            "in all), %u giant\n", cb, ntD, nbig, maxrun, nbigentries, ngiant);
+  std::vector<MdTile> giants(ngiant);
+  std::vector<u32> giant_t(ngiant);
+  if (ngiant > 0) {
+    // (blocking copies: the destinations are containers of this frame)
+    HIP_TRY(hipMemcpy(giant_t.data(), w.giantlist, (size_t) ngiant * 4, hipMemcpyDeviceToHost));
+    for (u32 i = 0; i < ngiant; i++)
+      HIP_TRY(hipMemcpy(&giants[i], w.dtiles + giant_t[i], sizeof(MdTile), hipMemcpyDeviceToHost));
+  }
+  if (cb > 0) {
+    k_msd_scatter_lvl<2><<<((w.tilesC_ub + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+        kb, nullptr, pb, w.desc, w.tilesC_ub, w.hist, w.tfirst, w.F, cb, 32 - cb, ka, pa);
+    HIP_TRY(hipGetLastError());
+  }
+  // ---- level D
+  MsdOut o;
+  o.suf = (want & GTAMD_WANT_SUF) ? c->suf.as<u64>() : nullptr;
+  o.lcp = (want & GTAMD_WANT_LCP) ? c->lcp.as<u8>() : nullptr;
+  o.bwt = (want & GTAMD_WANT_BWT) ? c->bwt.as<u8>() : nullptr;
+  o.sa = pf;
+  o.tiebits = c->tiebits.as<u64>();
+  o.firstkey = w.firstkey;
+  o.lastkey = w.lastkey;
+  o.stats = c->d_stats;
+  o.prefixlength = prefixlength;
+  HIP_TRY(hipMemsetAsync(o.tiebits, 0, (div_up(N, 64) + 2) * 8, st));
+  if (ntD > 0) {
+    k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb, o);
+    HIP_TRY(hipGetLastError());
+  }
+  if (nbig > 0) {
+    k_msd_big<<<nbig < 2048u ? nbig : 2048u, MS_THREADS, 0, st>>>(kf, pf, ko, po, w.dtiles,
+                                                                w.biglist, w.counters, cb, o);
+    HIP_TRY(hipGetLastError());
+  }
+  for (u32 i = 0; i < ngiant; i++) {
+    // the 29 bits of K2 above the payload, least significant digit first
+    const MdTile g = giants[i];
+    const u64 cnt = g.end - g.begin;
+    const int shifts[4] = {3, 11, 19, 27}, widths[4] = {8, 8, 8, 5};
+    int nev = 0;
+    TRY(radix_sort_pairs<u32, u32>(kf + g.begin, pf + g.begin, ko + g.begin, po + g.begin, cnt,
+                                   shifts, widths, 4, c->rws.as<u32>(), st, nullptr, &nev));
+    k_msd_emit_run<<<(u32) div_up(cnt, MS_TILE), MS_THREADS, 0, st>>>(kf, pf, giant_t[i], g.begin,
+                                                                     (u32) cnt, g.s16, o);
+    HIP_TRY(hipGetLastError());
+  }
+  if (ntD > 0) {
+    k_msd_seams<<<(ntD + 255) / 256, 256, 0, st>>>(w.dtiles, ntD, o);
+    HIP_TRY(hipGetLastError());
+  }
+  *sa_out = pf;
+  *fkey = reinterpret_cast<u64 *>(ko);
+  *fval = po;
+  return 0;
+}
+
 // BITS: symbol width; WIDE: positions and ranks are 64-bit (part builds of
 // sequences with n >= 2^32)
 template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, bool dist) {
@@ -2995,12 +3194,25 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // DNA whole-table builds: the keygen also does the sort's first pass (the
   // dcode digit); GTAMD_FUSED_PASS0=0 takes the plain keygen + full sort
   bool pass0_done = false;
+  // DNA whole-table builds with 32-bit positions: keygen, sort and emission
+  // most significant digit first (esa_msd.h).  GTAMD_MSD=0 takes the LSD sort,
+  // GTAMD_MSD=1 the MSD sort at any size (tests; by default from 2^24 entries)
+  bool msd = false;
+  u32 *msd_sa = nullptr, *msd_fval = nullptr;
+  u64 *msd_fkey = nullptr;
+  if (!dist && BITS == 2 && !WIDE && !(want & GTAMD_WANT_BCK) && N >= 64) {
+    const char *e = getenv("GTAMD_MSD");
+    msd = e != nullptr ? e[0] == '1' : N >= (1ull << 24);
+  }
   if (!dist) {
     TRY(ensure_workspace(c, N, want, false));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
     HIP_TRY(hipEventRecord(c->ev[0], st));
     const char *fz = getenv("GTAMD_FUSED_PASS0");
-    if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
+    if (msd) {
+      TRY(msd_sort_emit(c, want, prefixlength, &msd_sa, &msd_fkey, &msd_fval));
+      HIP_TRY(hipEventRecord(c->ev_emitted, st));   // (what the joins below wait for)
+    } else if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
       k_dc_hist_dna<<<ntiles, KP_THREADS, 0, st>>>(c->text, N, c->rws.as<u32>());
       HIP_TRY(hipGetLastError());
@@ -3148,7 +3360,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
             c->part, R, (unsigned long long) Tn, (unsigned long long) NL,
             (unsigned long long) index_offset, WIDE ? " (64-bit positions)" : "");
   if (dist) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
-  HIP_TRY(hipEventRecord(c->ev[1], st));
+  if (!msd) HIP_TRY(hipEventRecord(c->ev[1], st));   // (the MSD sort: after its level A)
 
   // ---- first sort: all key bits above the payload
   int shifts[16], widths[16], np = 0;
@@ -3170,13 +3382,20 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       *kb = pass0_done ? c->k0.as<u64>() : c->k1.as<u64>();
   u32 *va = pass0_done ? c->v1.as<u32>() : c->v0.as<u32>(),
       *vb = pass0_done ? c->v0.as<u32>() : c->v1.as<u32>();
-  TRY(radix_sort_pairs<u64, u32>(ka, va, kb, vb, NL, shifts, widths, np,
-                            c->rws.as<u32>(), st, c->ev_scatter, &nev, c->dig0.as<u8>(),
-                            c->dig1.as<u8>()));
+  if (!msd)
+    TRY(radix_sort_pairs<u64, u32>(ka, va, kb, vb, NL, shifts, widths, np,
+                              c->rws.as<u32>(), st, c->ev_scatter, &nev, c->dig0.as<u8>(),
+                              c->dig1.as<u8>()));
   u64 *skey = (np & 1) ? kb : ka;   // sorted keys
   u32 *sa32 = (np & 1) ? vb : va;   // positions in suffix order (low half)
   u64 *fkey = (np & 1) ? ka : kb;   // free key-sized buffer
   u32 *fval = (np & 1) ? va : vb;   // free value-sized buffer
+  if (msd) {
+    skey = nullptr;                 // (no sorted keys: the tables are out already)
+    sa32 = msd_sa;
+    fkey = msd_fkey;
+    fval = msd_fval;
+  }
   HIP_TRY(hipEventRecord(c->ev[2], st));
 
   if (want & GTAMD_WANT_BCK) TRY(build_bcktab<BITS>(c, skey, NL, prefixlength, st));
@@ -3213,7 +3432,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // It is started where the first stream turns latency-bound (the comparisons
   // of the pair path, the rounds), so that the two actually overlap; whatever
   // it writes for tied entries is provisional and overwritten after the join.
-  bool emitted = false;
+  bool emitted = msd;
   auto launch_emission = [&]() -> int {
     if (emitted) return 0;
     emitted = true;
@@ -3229,7 +3448,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     return 0;
   };
   u64 *tiebits = c->tiebits.as<u64>();
-  if (NL > 0) {
+  if (NL > 0 && !msd) {
     k_tiebits<BITS><<<stride_grid(div_up(NL, 4096)), 256, 0, st>>>(skey, NL, tiebits,
                                                                    c->d_stats);
     HIP_TRY(hipGetLastError());

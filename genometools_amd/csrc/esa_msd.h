@@ -1,0 +1,981 @@
+// esa_msd.h -- the first sort of a big DNA build, most significant digit first,
+// with entries that shrink as digits are used up, and the table emission done
+// by the kernel that finishes the sort.  Included by esa_engine.hip (kernels
+// only; the driver is msd_sort_emit there).
+//
+// Why: the LSD sort moves the whole 12-byte (key, position) pair through HBM
+// once per digit -- keygen 36 GB + 5 x (24 GB histogram read + 72 GB scatter)
+// at 3 Gbp, then 66 GB more for tie bits and table emission: 580 GB, 145 ms of
+// a 204 ms build.  Most significant digit first, a digit that has been used is
+// implied by where the entry lies, so it need not be carried:
+//
+//   level A  (fused with the keygen, text order)   digit = symbols 0..3
+//            writes  K1 = symbols 4..19 (u32), X = dcode | payload (u8), P (u32)  27 GB
+//   level B  inside each of the 256 ranges         digit = symbols 4..7
+//            writes  K2 = symbols 8..19 | X (u32), P                             12 + 27 + 24 GB
+//   level C  inside each of the 65536 ranges       digit = the next `cbits` bits
+//            writes  K2, P                                                       12 + 24 + 24 GB
+//   level D  one workgroup per run of whole ranges (<= 4096 entries): stable
+//            LSD sort of the rest of K2 in LDS, then .suf/.lcp/.bwt, the tie
+//            bitmap and the statistics straight from LDS                         24 + 42 GB
+//
+// 216 GB.  Levels A-C are stable partitions (per-tile histogram, column scan,
+// ballot-ranked scatter: the LSD sort's machinery), so entries with equal keys
+// stay in text order, which the order of suffixes that run into a special
+// relies on (esa_common.h).  The levels below A work on ragged tiles: a tile
+// never straddles two parent ranges, a parent range of s entries has
+// ceil(s / 4096) tiles, the last one partial.
+//
+// Runs of ranges that exceed the LDS tile (repeats: one 12-mer with 10^5
+// occurrences) are sorted by one workgroup each in global memory
+// (k_msd_big), ping-pong between the two buffer pairs of the levels; runs above
+// MSD_BIG_MAX entries (the suffixes that start with a wildcard all have one
+// key; poly-A; two-letter texts) by the device-wide LSD sort on the 29 bits that
+// are left, run by run, followed by k_msd_emit_run.
+#pragma once
+
+constexpr int MS_TILE = 4096;
+constexpr int MS_THREADS = 512;
+constexpr int MS_WAVES = MS_THREADS / 64;
+constexpr int MS_ITEMS = MS_TILE / MS_THREADS;     // 8
+constexpr int MS_WCHUNK = MS_ITEMS * 64;           // 512 consecutive entries per wave
+constexpr int MS_PAD = 520;                        // row pitch of the keygen transposition
+constexpr u32 MSD_PARENTS = 65536;                 // ranges after levels A and B
+constexpr u32 MSD_STRIDE = 2560;                   // level D: entries per tile before snapping
+constexpr u32 MSD_BIG_MAX = 1u << 19;              // largest run one workgroup sorts alone
+
+struct MsTile {       // ragged tile of a level pass
+  u32 start;          // index of its first entry
+  u32 segvalid;       // parent range << 13 | entries (0 .. 4096)
+};
+struct MdTile {       // level D: a run of whole finest-level ranges
+  u32 begin, end;     // entries [begin, end)
+  u32 s16;            // the 16 key bits levels A and B have used
+  u32 pad;
+};
+struct MsdOut {
+  u64 *suf;
+  u8 *lcp;
+  u8 *bwt;
+  u32 *sa;            // positions in suffix order, 32-bit (what the refinement reads)
+  u64 *tiebits;       // zeroed by the driver
+  u64 *firstkey, *lastkey;   // per level-D tile: its first and last key, for the seams
+  Stats *stats;
+  u32 prefixlength;
+};
+struct MsdAcc {
+  unsigned long long sum, ties;
+  u32 mx;
+};
+
+__device__ __forceinline__ u32 ms_xcd_tile(u32 b, u32 ntiles) {
+  const u32 per = (ntiles + 7u) >> 3;
+  return (b & 7u) * per + (b >> 3);
+}
+
+// the 64-bit key (layout of Key<2>) from what levels A-C keep of it
+__device__ __forceinline__ u64 msd_full(u32 s16, u32 k2) {
+  return ((u64) s16 << 48) | ((u64) (k2 >> 8) << 24) | ((u64) ((k2 >> 3) & 31u) << 19) |
+         (u64) (k2 & 7u);
+}
+
+// keys of the suffixes p0 .. p0+7 (p0 a multiple of 8), bit for bit those of
+// make_key<2>; the arithmetic of k_keygen_pass0_dna
+__device__ __forceinline__ void dna_keys8(const Text &t, u64 p0, u64 (&key)[KP_PER]) {
+  using K = Key<2>;
+  using P = Pay<2>;
+  constexpr int SYMS = K::SYMS;
+  const u64 w = p0 >> 5;
+  const int o = (int) (p0 & 31) * 2;
+  const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
+  const u64 a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;
+  const u64 a_lo = lo << o;
+  const u64 sw = p0 >> 6;
+  const int so = (int) (p0 & 63);
+  const u64 s0 = sp_word(t, sw), s1 = sp_word(t, sw + 1);
+  const u64 S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;
+  u32 pay;
+  if (p0 == 0) {
+    pay = P::UNDEF;
+  } else {
+    const u32 c = o ? (u32) (hi >> (64 - o)) & 3u : (u32) tb_word(t, w - 1) & 3u;
+    const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
+    pay = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+#pragma unroll
+  for (int g = 0; g < KP_PER; g++) {
+    const u64 win = g ? (a_hi << (2 * g)) | (a_lo >> (64 - 2 * g)) : a_hi;
+    const u64 s = (S >> g) & ((1ull << SYMS) - 1ull);
+    const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+    if (d == 0) {
+      key[g] = (~0ull << K::DSHIFT) | pay;
+    } else {
+      u64 pre = win >> K::LOW_BITS;
+      u32 dc = 0;
+      if (d < SYMS) {
+        pre |= (1ull << (2 * (SYMS - d))) - 1ull;
+        dc = (u32) (SYMS - d);
+      }
+      key[g] = (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
+    }
+    const u32 c = (u32) (win >> 62);
+    pay = (c < 2u && (s & 1ull)) ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+}
+
+// lanes of the wave that hold the same NB-bit digit, as a count of those below
+// this lane and the size of the group (the ranking of esa_prims.hip's scatter
+// kernel: one bit-field extract, one compare and one three-input bit operation
+// per half and bit)
+template <int NB>
+__device__ __forceinline__ void ms_match(u32 d, u32 &intra, u32 &group) {
+  u32 mlo = ~0u, mhi = ~0u;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    u32 sx = (u32) ((int) (d << (31 - b)) >> 31);
+    asm volatile("" : "+v"(sx));
+    const u64 bal = __ballot(sx != 0);
+    mlo = __builtin_amdgcn_bitop3_b32(mlo, (u32) bal, sx, 0x90);
+    mhi = __builtin_amdgcn_bitop3_b32(mhi, (u32) (bal >> 32), sx, 0x90);
+  }
+  intra = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+  group = (u32) __popc(mlo) + (u32) __popc(mhi);
+}
+
+typedef __attribute__((address_space(3))) volatile u16 ms_vu16;
+
+// ---------------------------------------------------------------------------
+// level A: keygen + partition on the first four symbols
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist_a(Text t, u64 N,
+                                                           u32 *__restrict__ hist) {
+  __shared__ u32 h[MS_WAVES][256];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < MS_WAVES * 256; i += MS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 p0 = (u64) blockIdx.x * MS_TILE + (u64) tid * KP_PER;
+  if (p0 < N) {
+    const int npos = N - p0 < KP_PER ? (int) (N - p0) : KP_PER;
+    u64 key[KP_PER];
+    dna_keys8(t, p0, key);
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++)
+      if (g < npos) atomicAdd(&h[w][(u32) (key[g] >> 56)], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < MS_WAVES; i++) c += h[i][tid];
+    hist[(u64) blockIdx.x * 256 + tid] = c;
+  }
+}
+
+// starts of the 256 level-A ranges: row 0 of the scanned histogram
+__global__ void k_msd_starts_a(const u32 *__restrict__ scanned, u32 N, u32 *__restrict__ start) {
+  const u32 d = threadIdx.x;
+  if (d < 256) start[d] = scanned[d];
+  if (d == 0) start[256] = N;
+}
+
+__global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
+    Text t, u64 N, u32 last_valid, const u32 *__restrict__ scanned, u32 ntiles,
+    u32 *__restrict__ k1out, u8 *__restrict__ xout, u32 *__restrict__ pout) {
+  // 40 KB: first the keys in (suffix of the thread, thread) order, padded
+  // against bank conflicts; then the staging area in digit order
+  __shared__ u64 s_t[5120];
+  __shared__ u16 s_cnt_mem[MS_WAVES * 256];
+  __shared__ u32 s_obase[256];
+  __shared__ u32 s_scan[MS_WAVES];
+  static_assert(KP_PER * MS_PAD <= 5120 && MS_TILE * 10 <= 5120 * 8, "staging fits");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile = ms_xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const u64 tile_base = (u64) tile * MS_TILE;
+  const u32 valid = tile + 1u == ntiles ? last_valid : (u32) MS_TILE;
+  for (int i = tid; i < MS_WAVES * 256 / 2; i += MS_THREADS)
+    reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+  u32 gbase = 0;
+  if (tid < 256) gbase = scanned[(u64) tile * 256 + tid];
+  {
+    u64 key[KP_PER];
+    const u64 p0 = tile_base + (u64) tid * KP_PER;
+    if (p0 < N) {
+      dna_keys8(t, p0, key);
+    } else {
+#pragma unroll
+      for (int g = 0; g < KP_PER; g++) key[g] = ~0ull;
+    }
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) s_t[g * MS_PAD + tid] = key[g];
+  }
+  __syncthreads();
+  u64 key[MS_ITEMS];
+  u32 rk[MS_ITEMS];
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;   // suffix tile_base + e
+    key[j] = s_t[(e & 7u) * MS_PAD + (e >> 3)];
+  }
+  __syncthreads();   // the transposition area is free
+  ms_vu16 *cnt_w = (ms_vu16 *) s_cnt_mem + w * 256;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+    const u32 d = e < valid ? (u32) (key[j] >> 56) : 255u;
+    u32 intra, group;
+    ms_match<8>(d, intra, group);
+    const u32 old = cnt_w[d];
+    if (intra == 0) cnt_w[d] = (u16) (old + group);
+    rk[j] = ((old + intra) << 8) | d;
+  }
+  __syncthreads();
+  {
+    ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+    u32 c[MS_WAVES];
+    u32 tot = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int i = 0; i < MS_WAVES; i++) {
+        c[i] = s_cnt[i * 256 + tid];
+        tot += c[i];
+      }
+    }
+    u32 all;
+    u32 dbase = block_scan_excl<SCAN_SUM, MS_THREADS>(tot, &all, s_scan);
+    if (tid < 256) {
+      s_obase[tid] = gbase - dbase;
+#pragma unroll
+      for (int i = 0; i < MS_WAVES; i++) {
+        s_cnt[i * 256 + tid] = (u16) dbase;
+        dbase += c[i];
+      }
+    }
+  }
+  __syncthreads();
+  u32 *s_k1 = reinterpret_cast<u32 *>(s_t);
+  u32 *s_p = s_k1 + MS_TILE;
+  u8 *s_x = reinterpret_cast<u8 *>(s_p + MS_TILE);
+  u8 *s_d = s_x + MS_TILE;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+    const u32 d = rk[j] & 255u;
+    const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
+    s_k1[pos] = (u32) (key[j] >> 24);
+    s_p[pos] = (u32) tile_base + e;
+    s_x[pos] = (u8) ((((u32) (key[j] >> 19) & 31u) << 3) | ((u32) key[j] & 7u));
+    s_d[pos] = (u8) d;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) j * MS_THREADS + tid;
+    if (e < valid) {
+      const u32 g = s_obase[s_d[e]] + e;
+      k1out[g] = s_k1[e];
+      pout[g] = s_p[e];
+      xout[g] = s_x[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// levels B and C: stable partition inside every parent range
+// ---------------------------------------------------------------------------
+// tiles per parent range; entry np is 0 (its exclusive scan is the tile count).
+// Parent s covers pstart[s << sh] .. pstart[(s + 1) << sh].
+__global__ __launch_bounds__(256) void k_msd_tilecount(const u32 *__restrict__ pstart, int sh,
+                                                       u32 np, u32 per, u32 *__restrict__ cnt) {
+  const u32 s = blockIdx.x * 256u + threadIdx.x;
+  if (s > np) return;
+  if (s == np) { cnt[s] = 0; return; }
+  const u32 size = pstart[(u64) (s + 1) << sh] - pstart[(u64) s << sh];
+  cnt[s] = (size + per - 1u) / per;
+}
+
+// largest s with tfirst[s] <= t (tfirst has np + 1 entries, tfirst[np] > t)
+__device__ __forceinline__ u32 ms_parent_of(const u32 *__restrict__ tfirst, u32 np, u32 t) {
+  u32 lo = 0, hi = np;        // answer in [lo, hi)
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (tfirst[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_msd_tiledesc(const u32 *__restrict__ pstart,
+                                                      const u32 *__restrict__ tfirst, u32 np,
+                                                      u32 tiles_ub, MsTile *__restrict__ desc) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= tiles_ub) return;
+  MsTile d;
+  d.start = 0;
+  d.segvalid = 0;
+  if (t < tfirst[np]) {
+    const u32 s = ms_parent_of(tfirst, np, t);
+    const u32 k = t - tfirst[s];
+    const u32 b = pstart[s] + k * (u32) MS_TILE, e = pstart[s + 1];
+    const u32 valid = e - b < (u32) MS_TILE ? e - b : (u32) MS_TILE;
+    d.start = b;
+    d.segvalid = (s << 13) | valid;
+  }
+  desc[t] = d;
+}
+
+// row t: counts of the digit  key >> dsh  over tile t; rows >= tiles_ub are zero
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist_lvl(
+    const u32 *__restrict__ keys, const MsTile *__restrict__ desc, u32 tiles_ub, int dsh,
+    u32 *__restrict__ hist) {
+  __shared__ u32 h[MS_WAVES][256];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < MS_WAVES * 256; i += MS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u32 t = blockIdx.x;
+  if (t < tiles_ub) {
+    const MsTile d = desc[t];
+    const u32 valid = d.segvalid & 0x1FFFu;
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+      const u32 e = (u32) j * MS_THREADS + tid;
+      if (e < valid) atomicAdd(&h[w][keys[(u64) d.start + e] >> dsh], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < MS_WAVES; i++) c += h[i][tid];
+    hist[(u64) t * 256 + tid] = c;
+  }
+}
+
+// entries of child (s, d): difference of the scanned rows at the parent's tile
+// borders; tot[np << cb] = 0
+__global__ __launch_bounds__(256) void k_msd_tot(const u32 *__restrict__ scanned,
+                                                 const u32 *__restrict__ tfirst, u32 np, int cb,
+                                                 u32 *__restrict__ tot) {
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  const u64 nchild = (u64) np << cb;
+  if (i > nchild) return;
+  if (i == nchild) { tot[i] = 0; return; }
+  const u32 s = (u32) (i >> cb), d = (u32) i & ((1u << cb) - 1u);
+  tot[i] = scanned[(u64) tfirst[s + 1] * 256 + d] - scanned[(u64) tfirst[s] * 256 + d];
+}
+
+// LEVEL 1 (B): (K1, X, P) -> (K2 = K1 << 8 | X, P), digit K1 >> 24
+// LEVEL 2 (C): (K2, P) -> (K2, P), digit K2 >> dsh
+template <int LEVEL>
+__global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_lvl(
+    const u32 *__restrict__ kin, const u8 *__restrict__ xin, const u32 *__restrict__ pin,
+    const MsTile *__restrict__ desc, u32 tiles_ub, const u32 *__restrict__ scanned,
+    const u32 *__restrict__ tfirst, const u32 *__restrict__ cstart, int cb, int dsh,
+    u32 *__restrict__ kout, u32 *__restrict__ pout) {
+  __shared__ u32 s_key[MS_TILE];
+  __shared__ u32 s_val[MS_TILE];
+  __shared__ u8 s_x[LEVEL == 1 ? MS_TILE : 4];
+  __shared__ u16 s_cnt_mem[MS_WAVES * 256];
+  __shared__ u32 s_obase[256];
+  __shared__ u32 s_scan[MS_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile = ms_xcd_tile(blockIdx.x, tiles_ub);
+  if (tile >= tiles_ub) return;
+  const MsTile td = desc[tile];
+  const u32 valid = td.segvalid & 0x1FFFu, seg = td.segvalid >> 13;
+  if (valid == 0) return;
+  for (int i = tid; i < MS_WAVES * 256 / 2; i += MS_THREADS)
+    reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+  // where this tile's entries of digit d go: start of child (seg, d) + what the
+  // tiles of the parent in front of this one hold of d
+  u32 gbase = 0;
+  if (tid < (1 << cb))
+    gbase = cstart[((u64) seg << cb) + tid] + scanned[(u64) tile * 256 + tid] -
+            scanned[(u64) tfirst[seg] * 256 + tid];
+  u32 key[MS_ITEMS], val[MS_ITEMS], xv[MS_ITEMS], rk[MS_ITEMS];
+  const u32 *kp = kin + td.start;
+  const u32 *pp = pin + td.start;
+  const u8 *xp = xin + td.start;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+    if (e < valid) {
+      key[j] = kp[e];
+      val[j] = pp[e];
+      xv[j] = LEVEL == 1 ? (u32) xp[e] : 0u;
+    } else {
+      key[j] = ~0u;
+      val[j] = 0;
+      xv[j] = 0;
+    }
+  }
+  __syncthreads();   // counters are zero
+  ms_vu16 *cnt_w = (ms_vu16 *) s_cnt_mem + w * 256;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+    const u32 d = e < valid ? key[j] >> dsh : 255u;
+    u32 intra, group;
+    ms_match<8>(d, intra, group);
+    const u32 old = cnt_w[d];
+    if (intra == 0) cnt_w[d] = (u16) (old + group);
+    rk[j] = ((old + intra) << 8) | d;
+  }
+  __syncthreads();
+  {
+    ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+    u32 c[MS_WAVES];
+    u32 tot = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int i = 0; i < MS_WAVES; i++) {
+        c[i] = s_cnt[i * 256 + tid];
+        tot += c[i];
+      }
+    }
+    u32 all;
+    u32 dbase = block_scan_excl<SCAN_SUM, MS_THREADS>(tot, &all, s_scan);
+    if (tid < 256) {
+      s_obase[tid] = gbase - dbase;
+#pragma unroll
+      for (int i = 0; i < MS_WAVES; i++) {
+        s_cnt[i * 256 + tid] = (u16) dbase;
+        dbase += c[i];
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 d = rk[j] & 255u;
+    const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
+    s_key[pos] = key[j];
+    s_val[pos] = val[j];
+    if (LEVEL == 1) s_x[pos] = (u8) xv[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) j * MS_THREADS + tid;
+    if (e < valid) {
+      const u32 k = s_key[e];
+      const u32 g = s_obase[k >> dsh] + e;
+      kout[g] = LEVEL == 1 ? (k << 8) | (u32) s_x[e] : k;
+      pout[g] = s_val[e];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// level D: tiles of whole finest-level ranges
+// ---------------------------------------------------------------------------
+// F: starts of the finest-level ranges (nf + 1 entries), range j of parent s16 is
+// (s16 << cb) + j.  Tile k of a parent starts at the first range start that is
+// >= parent start + k * MSD_STRIDE.  A tile above the LDS tile goes to the big
+// list (one workgroup sorts it in global memory), one above MSD_BIG_MAX to the
+// giant list (the driver sorts it with the device-wide sort).  counters: [0] big
+// tiles, [1] largest tile, [2] entries in big and giant tiles, [3] giant tiles
+__global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, int cb,
+                                                    const u32 *__restrict__ tfirst, u32 tiles_ub,
+                                                    MdTile *__restrict__ tiles,
+                                                    u32 *__restrict__ biglist,
+                                                    u32 *__restrict__ giantlist,
+                                                    u32 *__restrict__ counters, u32 big_max) {
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= tiles_ub) return;
+  MdTile d;
+  d.begin = d.end = d.s16 = d.pad = 0;
+  if (t < tfirst[MSD_PARENTS]) {
+    const u32 s = ms_parent_of(tfirst, MSD_PARENTS, t);
+    const u32 k = t - tfirst[s], count = tfirst[s + 1] - tfirst[s];
+    const u64 lo = (u64) s << cb, hi = (u64) (s + 1) << cb;
+    const u32 pbase = F[lo];
+    u32 cut[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const u32 kk = k + (u32) q;
+      if (kk == 0) cut[q] = pbase;
+      else if (kk >= count) cut[q] = F[hi];
+      else {
+        // first range start >= target among F[lo .. hi]
+        const u64 target = (u64) pbase + (u64) kk * MSD_STRIDE;
+        u64 a = lo, b = hi;           // F[a] < target <= F[b] (F[hi] = parent end >= target)
+        while (b - a > 1) {
+          const u64 mid = (a + b) >> 1;
+          if ((u64) F[mid] >= target) b = mid; else a = mid;
+        }
+        cut[q] = F[b];
+      }
+    }
+    d.begin = cut[0];
+    d.end = cut[1];
+    d.s16 = s;
+    const u32 cnt = d.end - d.begin;
+    if (cnt > big_max) {
+      giantlist[atomicAdd(&counters[3], 1u)] = t;
+      atomicAdd(&counters[2], cnt);
+      atomicMax(&counters[1], cnt);
+    } else if (cnt > (u32) MS_TILE) {
+      biglist[atomicAdd(&counters[0], 1u)] = t;
+      atomicAdd(&counters[2], cnt);
+      atomicMax(&counters[1], cnt);
+    }
+  }
+  tiles[t] = d;
+}
+
+// Table entries of the sorted run [gbeg, gbeg + cnt) that lies in LDS
+// (s_key[i] + base = K2 of entry i, s_val[i] its position): .suf, .lcp
+// (provisional for tied entries, as k_finalize), .bwt, the 32-bit positions and
+// the tie bits.  The entry in front of the run: prevkey if has_prev, else the
+// run's first entry gets lcp 0 and k_msd_seams settles it.
+__device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32 cnt, u64 gbeg,
+                                         u32 base, u32 s16, bool has_prev, u64 prevkey,
+                                         const MsdOut &o, u32 *s_bits, MsdAcc &acc) {
+  using K = Key<2>;
+  const int tid = threadIdx.x;
+  const u32 off64 = (u32) (gbeg & 63);
+  const u32 nbw = (cnt + off64 + 63u) >> 6;
+  for (u32 i = tid; i < 2u * nbw; i += MS_THREADS) s_bits[i] = 0;
+  __syncthreads();
+  const u32 mis = (u32) (gbeg & 3);
+  const u32 nquads = (cnt + mis + 3u) >> 2;
+  const u64 gq = gbeg - mis;
+  for (u32 q = tid; q < nquads; q += MS_THREADS) {
+    const int i0 = (int) (4u * q) - (int) mis;
+    u64 k[4];
+    u32 pv[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = i0 + c;
+      const bool ok = i >= 0 && i < (int) cnt;
+      k[c] = ok ? msd_full(s16, s_key[i] + base) : 0ull;
+      pv[c] = ok ? s_val[i] : 0u;
+    }
+    const u64 prevk = i0 > 0 ? msd_full(s16, s_key[i0 - 1] + base) : prevkey;
+    u32 lcpv[4] = {0, 0, 0, 0}, tiemask = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = i0 + c;
+      if (i < 0 || i >= (int) cnt) continue;
+      const bool have_a = i > 0 || has_prev;
+      const u64 a = (c == 0 || i == 0) ? prevk : k[c - 1], b = k[c];
+      const u32 da = K::letters(a), db = K::letters(b);
+      const u64 x = (a ^ b) >> K::LOW_BITS;
+      const u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;
+      u32 l = m < da ? m : da;
+      l = l < db ? l : db;
+      bool tie = m == (u32) K::SYMS && K::dcode(a) == 0 && K::dcode(b) == 0;
+      if (!have_a) { l = 0; tie = false; }
+      lcpv[c] = l;
+      if (tie) {
+        tiemask |= 1u << c;
+        acc.ties++;
+      } else {
+        if (have_a) {
+          acc.mx = l > acc.mx ? l : acc.mx;
+          if (db >= o.prefixlength) acc.sum += l;
+        }
+        if (pv[c] == 0) o.stats->longest = gq + 4ull * q + (u64) c;
+      }
+    }
+    const u64 g0 = gq + 4ull * q;
+    if (i0 >= 0 && i0 + 4 <= (int) cnt) {
+      if (o.suf != nullptr) {
+        *reinterpret_cast<ulonglong2 *>(o.suf + g0) = make_ulonglong2(pv[0], pv[1]);
+        *reinterpret_cast<ulonglong2 *>(o.suf + g0 + 2) = make_ulonglong2(pv[2], pv[3]);
+      }
+      *reinterpret_cast<uint4 *>(o.sa + g0) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+      if (o.lcp != nullptr)
+        *reinterpret_cast<u32 *>(o.lcp + g0) =
+            lcpv[0] | (lcpv[1] << 8) | (lcpv[2] << 16) | (lcpv[3] << 24);
+      if (o.bwt != nullptr) {
+        u32 bw = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+          bw |= (u32) Pay<2>::to_bwt((u32) (k[c] & K::PAY_MASK)) << (8 * c);
+        *reinterpret_cast<u32 *>(o.bwt + g0) = bw;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int i = i0 + c;
+        if (i < 0 || i >= (int) cnt) continue;
+        if (o.suf != nullptr) o.suf[g0 + c] = pv[c];
+        o.sa[g0 + c] = pv[c];
+        if (o.lcp != nullptr) o.lcp[g0 + c] = (u8) lcpv[c];
+        if (o.bwt != nullptr) o.bwt[g0 + c] = Pay<2>::to_bwt((u32) (k[c] & K::PAY_MASK));
+      }
+    }
+    if (tiemask) {
+      const u32 bo = 4u * q + (off64 - mis);   // bit of quad entry 0 in the LDS bitmap
+      atomicOr(&s_bits[bo >> 5], tiemask << (bo & 31u));
+    }
+  }
+  __syncthreads();
+  const u64 w0 = gbeg >> 6;
+  for (u32 wi = tid; wi < nbw; wi += MS_THREADS) {
+    const u64 v = (u64) s_bits[2u * wi] | ((u64) s_bits[2u * wi + 1u] << 32);
+    if (v == 0) continue;
+    const bool interior = (wi > 0 || off64 == 0) && (w0 + wi + 1) * 64 <= gbeg + cnt;
+    if (interior) o.tiebits[w0 + wi] = v;
+    else atomicOr(reinterpret_cast<unsigned long long *>(o.tiebits + w0 + wi),
+                  (unsigned long long) v);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void msd_acc_flush(MsdAcc acc, Stats *stats) {
+  __shared__ unsigned long long s_sum[MS_WAVES], s_ties[MS_WAVES];
+  __shared__ u32 s_max[MS_WAVES];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    acc.sum += __shfl_xor(acc.sum, d, 64);
+    acc.ties += __shfl_xor(acc.ties, d, 64);
+    const u32 ot = __shfl_xor(acc.mx, d, 64);
+    acc.mx = ot > acc.mx ? ot : acc.mx;
+  }
+  if (lane == 0) { s_sum[w] = acc.sum; s_ties[w] = acc.ties; s_max[w] = acc.mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long S = 0, T = 0;
+    u32 M = 0;
+    for (int i = 0; i < (int) (blockDim.x >> 6); i++) {
+      S += s_sum[i]; T += s_ties[i]; M = s_max[i] > M ? s_max[i] : M;
+    }
+    if (S) atomicAdd(&stats->lcpsum, S);
+    if (T) atomicAdd(&stats->numties, T);
+    if (M) atomicMax(&stats->maxlcp, M);
+  }
+}
+
+// what of K2 is left to sort in the run [begin, end): K2 minus the first
+// entry's level-C digit, bits [3, nbits)
+__device__ __forceinline__ void msd_run_bits(const u32 *__restrict__ kin, u32 begin, u32 end,
+                                             int cb, u32 &base, int &nbits) {
+  if (cb == 0) { base = 0; nbits = 32; return; }
+  const int csh = 32 - cb;
+  const u32 f0 = kin[begin] >> csh, f1 = kin[end - 1] >> csh;
+  base = f0 << csh;
+  nbits = csh + (f1 > f0 ? 32 - __clz((int) (f1 - f0)) : 0);
+}
+
+constexpr int MD_BITS = 9;
+constexpr int MD_RADIX = 1 << MD_BITS;
+static_assert(MD_RADIX == MS_THREADS, "one thread per digit in the scan");
+
+__global__ __launch_bounds__(MS_THREADS) void k_msd_local(
+    const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
+    u32 ntiles, int cb, MsdOut o) {
+  __shared__ u32 s_key[MS_TILE];
+  __shared__ u32 s_val[MS_TILE];
+  __shared__ u16 s_cnt_mem[MS_WAVES * MD_RADIX];
+  __shared__ u32 s_scan[MS_WAVES];
+  __shared__ u32 s_bits[(MS_TILE + 128) / 32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+  ms_vu16 *cnt_w = s_cnt + w * MD_RADIX;
+  MsdAcc acc;
+  acc.sum = acc.ties = 0;
+  acc.mx = 0;
+  for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const MdTile td = tiles[t];
+    const u32 cnt = td.end - td.begin;
+    if (cnt == 0 || cnt > (u32) MS_TILE) continue;   // (oversize: k_msd_big)
+    u32 base;
+    int nbits;
+    msd_run_bits(kin, td.begin, td.end, cb, base, nbits);
+    const int npass = nbits > 3 ? (nbits - 3 + MD_BITS - 1) / MD_BITS : 0;
+    // items per thread and the wave's chunk, so that a part-filled tile keeps
+    // all eight waves busy
+    const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
+    u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
+    const u32 *kp = kin + td.begin;
+    const u32 *pp = pin + td.begin;
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+      const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+      if ((u32) j < items && e < cnt) {
+        key[j] = kp[e] - base;
+        val[j] = pp[e];
+      } else {
+        key[j] = ~0u;
+        val[j] = 0;
+      }
+    }
+    if (npass == 0) {
+#pragma unroll
+      for (int j = 0; j < MS_ITEMS; j++) {
+        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+        if ((u32) j < items && e < (u32) MS_TILE) { s_key[e] = key[j]; s_val[e] = val[j]; }
+      }
+      __syncthreads();
+    }
+    for (int p = 0; p < npass; p++) {
+      const int shift = 3 + MD_BITS * p;
+      for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS)
+        reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < MS_ITEMS; j++) {
+        if ((u32) j < items) {
+          const u32 d = (key[j] >> shift) & (u32) (MD_RADIX - 1);
+          u32 intra, group;
+          ms_match<MD_BITS>(d, intra, group);
+          const u32 old = cnt_w[d];
+          if (intra == 0) cnt_w[d] = (u16) (old + group);
+          rk[j] = ((old + intra) << MD_BITS) | d;
+        }
+      }
+      __syncthreads();
+      {
+        u32 c[MS_WAVES];
+        u32 tot = 0;
+#pragma unroll
+        for (int i = 0; i < MS_WAVES; i++) {
+          c[i] = s_cnt[i * MD_RADIX + tid];
+          tot += c[i];
+        }
+        u32 all;
+        u32 dbase = block_scan_excl<SCAN_SUM, MS_THREADS>(tot, &all, s_scan);
+#pragma unroll
+        for (int i = 0; i < MS_WAVES; i++) {
+          s_cnt[i * MD_RADIX + tid] = (u16) dbase;
+          dbase += c[i];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < MS_ITEMS; j++) {
+        if ((u32) j < items) {
+          const u32 d = rk[j] & (u32) (MD_RADIX - 1);
+          const u32 pos = (u32) cnt_w[d] + (rk[j] >> MD_BITS);
+          s_key[pos] = key[j];
+          s_val[pos] = val[j];
+        }
+      }
+      __syncthreads();
+      if (p + 1 < npass) {
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          if ((u32) j < items) {
+            const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+            key[j] = s_key[e];
+            val[j] = s_val[e];
+          }
+        }
+      }
+    }
+    if (tid == 0) {
+      o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
+      o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
+    }
+    msd_emit(s_key, s_val, cnt, td.begin, base, td.s16, false, 0ull, o, s_bits, acc);
+  }
+  msd_acc_flush(acc, o.stats);
+}
+
+// oversize runs: one workgroup sorts a run in global memory, 8-bit digits,
+// ping-pong between (ka, pa) -- where the run lies and where the 32-bit
+// positions have to end up -- and the same index range of (kb, pb)
+__global__ __launch_bounds__(MS_THREADS) void k_msd_big(
+    u32 *__restrict__ ka, u32 *__restrict__ pa, u32 *__restrict__ kb, u32 *__restrict__ pb,
+    const MdTile *__restrict__ tiles, const u32 *__restrict__ biglist,
+    const u32 *__restrict__ counters, int cb, MsdOut o) {
+  __shared__ u32 s_key[MS_TILE];
+  __shared__ u32 s_val[MS_TILE];
+  __shared__ u16 s_cnt_mem[MS_WAVES * 256];
+  __shared__ u32 s_obase[256], s_cur[256];
+  __shared__ u32 s_scan[MS_WAVES];
+  __shared__ u32 s_bits[(MS_TILE + 128) / 32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+  ms_vu16 *cnt_w = s_cnt + w * 256;
+  const u32 nbig = counters[0];
+  MsdAcc acc;
+  acc.sum = acc.ties = 0;
+  acc.mx = 0;
+  for (u32 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const u32 t = biglist[bi];
+    const MdTile td = tiles[t];
+    const u32 cnt = td.end - td.begin;
+    u32 base;
+    int nbits;
+    msd_run_bits(ka, td.begin, td.end, cb, base, nbits);
+    const int npass = nbits > 3 ? (nbits - 3 + 7) / 8 : 0;
+    u32 *sk = ka + td.begin, *sp = pa + td.begin, *dk = kb + td.begin, *dp = pb + td.begin;
+    __syncthreads();   // (base was read from ka by every thread before anyone writes)
+    for (int p = 0; p < npass; p++) {
+      const int shift = 3 + 8 * p;
+      if (tid < 256) s_cur[tid] = 0;
+      __syncthreads();
+      for (u32 e = tid; e < cnt; e += MS_THREADS)
+        atomicAdd(&s_cur[((sk[e] - base) >> shift) & 255u], 1u);
+      __syncthreads();
+      {
+        const u32 v = tid < 256 ? s_cur[tid] : 0u;
+        u32 all;
+        const u32 x = block_scan_excl<SCAN_SUM, MS_THREADS>(v, &all, s_scan);
+        if (tid < 256) s_cur[tid] = x;
+      }
+      __syncthreads();
+      for (u32 c0 = 0; c0 < cnt; c0 += (u32) MS_TILE) {
+        const u32 valid = cnt - c0 < (u32) MS_TILE ? cnt - c0 : (u32) MS_TILE;
+        for (int i = tid; i < MS_WAVES * 256 / 2; i += MS_THREADS)
+          reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+        u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+          if (e < valid) {
+            key[j] = sk[c0 + e] - base;
+            val[j] = sp[c0 + e];
+          } else {
+            key[j] = ~0u;
+            val[j] = 0;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+          const u32 d = e < valid ? (key[j] >> shift) & 255u : 255u;
+          u32 intra, group;
+          ms_match<8>(d, intra, group);
+          const u32 old = cnt_w[d];
+          if (intra == 0) cnt_w[d] = (u16) (old + group);
+          rk[j] = ((old + intra) << 8) | d;
+        }
+        __syncthreads();
+        {
+          u32 c[MS_WAVES];
+          u32 tot = 0;
+          if (tid < 256) {
+#pragma unroll
+            for (int i = 0; i < MS_WAVES; i++) {
+              c[i] = s_cnt[i * 256 + tid];
+              tot += c[i];
+            }
+          }
+          u32 all;
+          u32 dbase = block_scan_excl<SCAN_SUM, MS_THREADS>(tot, &all, s_scan);
+          if (tid < 256) {
+            const u32 cur = s_cur[tid];
+            s_obase[tid] = cur - dbase;
+            // (the entries behind `valid` sit in digit 255: they are not written
+            // and do not move the cursor)
+            s_cur[tid] = cur + tot - (tid == 255 ? (u32) MS_TILE - valid : 0u);
+#pragma unroll
+            for (int i = 0; i < MS_WAVES; i++) {
+              s_cnt[i * 256 + tid] = (u16) dbase;
+              dbase += c[i];
+            }
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          const u32 d = rk[j] & 255u;
+          const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
+          s_key[pos] = key[j];
+          s_val[pos] = val[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          const u32 e = (u32) j * MS_THREADS + tid;
+          if (e < valid) {
+            const u32 k = s_key[e];
+            const u32 g = s_obase[(k >> shift) & 255u] + e;
+            dk[g] = k + base;
+            dp[g] = s_val[e];
+          }
+        }
+        __syncthreads();
+      }
+      u32 *x = sk; sk = dk; dk = x;
+      x = sp; sp = dp; dp = x;
+    }
+    // the sorted run is in (sk, sp); table entries chunk by chunk
+    u64 prevkey = 0;
+    for (u32 c0 = 0; c0 < cnt; c0 += (u32) MS_TILE) {
+      const u32 valid = cnt - c0 < (u32) MS_TILE ? cnt - c0 : (u32) MS_TILE;
+#pragma unroll
+      for (int j = 0; j < MS_ITEMS; j++) {
+        const u32 e = (u32) j * MS_THREADS + tid;
+        if (e < valid) {
+          s_key[e] = sk[c0 + e] - base;
+          s_val[e] = sp[c0 + e];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        if (c0 == 0) o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
+        if (c0 + valid == cnt) o.lastkey[t] = msd_full(td.s16, s_key[valid - 1] + base);
+      }
+      const u64 lastk = msd_full(td.s16, s_key[valid - 1] + base);
+      msd_emit(s_key, s_val, valid, (u64) td.begin + c0, base, td.s16, c0 > 0, prevkey, o,
+               s_bits, acc);
+      prevkey = lastk;
+    }
+  }
+  msd_acc_flush(acc, o.stats);
+}
+
+// table entries of a giant run the device-wide sort has put in order
+__global__ __launch_bounds__(MS_THREADS) void k_msd_emit_run(
+    const u32 *__restrict__ kin, const u32 *__restrict__ pin, u32 t, u32 begin, u32 cnt, u32 s16,
+    MsdOut o) {
+  __shared__ u32 s_key[MS_TILE];
+  __shared__ u32 s_val[MS_TILE];
+  __shared__ u32 s_bits[(MS_TILE + 128) / 32];
+  const int tid = threadIdx.x;
+  MsdAcc acc;
+  acc.sum = acc.ties = 0;
+  acc.mx = 0;
+  const u32 c0 = blockIdx.x * (u32) MS_TILE;
+  const u32 valid = cnt - c0 < (u32) MS_TILE ? cnt - c0 : (u32) MS_TILE;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u32 e = (u32) j * MS_THREADS + tid;
+    if (e < valid) {
+      s_key[e] = kin[(u64) begin + c0 + e];
+      s_val[e] = pin[(u64) begin + c0 + e];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (c0 == 0) o.firstkey[t] = msd_full(s16, s_key[0]);
+    if (c0 + valid == cnt) o.lastkey[t] = msd_full(s16, s_key[valid - 1]);
+  }
+  const u64 prevkey = c0 > 0 ? msd_full(s16, kin[(u64) begin + c0 - 1]) : 0ull;
+  msd_emit(s_key, s_val, valid, (u64) begin + c0, 0u, s16, c0 > 0, prevkey, o, s_bits, acc);
+  msd_acc_flush(acc, o.stats);
+}
+
+// lcp of every run's first entry with the last entry of the run in front of it
+__global__ __launch_bounds__(256) void k_msd_seams(const MdTile *__restrict__ tiles, u32 ntiles,
+                                                   MsdOut o) {
+  using K = Key<2>;
+  const u32 t = blockIdx.x * 256u + threadIdx.x;
+  MsdAcc acc;
+  acc.sum = acc.ties = 0;
+  acc.mx = 0;
+  if (t < ntiles) {
+    const MdTile td = tiles[t];
+    if (td.end > td.begin && td.begin > 0) {
+      u32 u = t - 1;
+      while (u > 0 && tiles[u].end == tiles[u].begin) u--;   // (an entry in front exists: begin > 0)
+      const u64 a = o.lastkey[u], b = o.firstkey[t];
+      const u32 da = K::letters(a), db = K::letters(b);
+      const u64 x = (a ^ b) >> K::LOW_BITS;
+      const u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;
+      u32 l = m < da ? m : da;
+      l = l < db ? l : db;
+      if (o.lcp != nullptr) o.lcp[td.begin] = (u8) l;
+      acc.mx = l;
+      if (db >= o.prefixlength) acc.sum = l;
+    }
+  }
+  msd_acc_flush(acc, o.stats);
+}

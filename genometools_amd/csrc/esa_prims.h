@@ -34,6 +34,10 @@ int radix_sort_pairs(K *keys_a, V *vals_a, K *keys_b, V *vals_b, u64 n,
 // tile); on return every entry is the global output index where that tile's
 // pairs of that digit start, exactly what the sort's own passes use.
 int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st);
+// the same scan over `nrows` rows of a tile-major histogram that lies anywhere
+// (rows of 256 counters; scanws: radix_rows_workspace_words(nrows) words)
+u64 radix_rows_workspace_words(u64 nrows);
+int radix_scan_tile_rows(u32 *hist, u32 nrows, u32 *scanws, hipStream_t st);
 
 // One pass of the same sort whose VALUES are not read but made on the fly:
 // value of input pair i = offset + (head of the tie group of entry i), from the

@@ -1065,7 +1065,13 @@ int radix_partition_u32(const u32 *keys_a, const u32 *vals_a, u32 *keys_b, u32 *
 
 int radix_scan_tile_hist(u32 *ws, u64 n, hipStream_t st) {
   const u32 ntiles = (u32) div_up(n, RS_TILE);
-  u32 *hist = ws, *scanws = ws + (u64) ntiles * RADIX;
+  return radix_scan_tile_rows(ws, ntiles, ws + (u64) ntiles * RADIX, st);
+}
+
+u64 radix_rows_workspace_words(u64 nrows) { return cs_workspace_words(nrows) + 64; }
+
+int radix_scan_tile_rows(u32 *hist, u32 ntiles, u32 *scanws, hipStream_t st) {
+  if (ntiles == 0) return 0;
   const u32 nchunks = (ntiles + CS_ROWS - 1) / CS_ROWS;
   k_cs_chunksum<<<nchunks, RADIX, 0, st>>>(hist, ntiles, scanws);
   HIP_TRY(hipGetLastError());

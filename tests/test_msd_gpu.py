@@ -1,0 +1,167 @@
+"""The first sort of a DNA whole-table build, most significant digit first
+(genometools_amd/csrc/esa_msd.h): keygen fused with level A, two ragged-tile
+levels, the LDS sort that also emits the tables, the one-workgroup path for
+oversize runs and the device-wide path for giant ones.  By default the engine
+takes it from 2^24 entries; GTAMD_MSD=1 takes it at any size, so that all of it
+is checked bit for bit against the oracle and the reference's fixtures, and at
+sizes the oracle cannot reach against the LSD sort (GTAMD_MSD=0)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import oracle_util as ou
+from genometools_amd import esa, synth
+from test_esa_gpu import _assert_same_as_oracle, _cases, _pair_cases
+
+pytestmark = pytest.mark.gpu
+GOLDEN = ou.golden()
+DNA_FIXTURES = sorted(k for k in GOLDEN if GOLDEN[k]["alphabet"] != "protein")
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture
+def msd(monkeypatch):
+    monkeypatch.setenv("GTAMD_MSD", "1")
+    return monkeypatch
+
+
+@pytest.mark.parametrize("name", DNA_FIXTURES)
+def test_reference_fixtures(gpu, msd, name):
+    e = GOLDEN[name]
+    enc = ou.encode_fasta(ou.fixture_path(name), False)
+    res = esa.suffixerator_tables(enc, 4)
+    assert _md5(res.suf) == e["tables"]["suf"]["md5"]
+    assert _md5(res.lcp) == e["tables"]["lcp"]["md5"]
+    assert _md5(res.llv) == e["tables"]["llv"]["md5"]
+    assert _md5(res.bwt) == e["tables"]["bwt"]["md5"]
+    ss = ou.seqstats(enc, 4)
+    assert esa.prj_text(ss, res.stats) == e["prj"]
+
+
+@pytest.mark.parametrize("cbits", ["0", "3", "8"])
+@pytest.mark.parametrize("n", [63, 64, 65, 255, 4095, 4096, 4097, 8191, 20000, 70001])
+def test_uniform_dna_small(gpu, msd, cbits, n):
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 42, n)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("cbits", ["0", "5", "8"])
+@pytest.mark.parametrize("model,n,seed", [
+    (synth.MODEL_UNIFORM_DNA, 1 << 20, 1),
+    (synth.MODEL_HUMANLIKE_DNA, 70000, 2),
+    (synth.MODEL_HUMANLIKE_DNA, 600000, 3),
+    (synth.MODEL_REPEAT_HEAVY, 300000, 6),
+])
+def test_synthetic_models(gpu, msd, cbits, model, n, seed):
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    enc = synth.generate(model, seed, n)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("name,enc", list(_cases()) + list(_pair_cases()),
+                         ids=[c[0] for c in list(_cases()) + list(_pair_cases())])
+@pytest.mark.parametrize("cbits", ["0", "8"])
+def test_edge_cases(gpu, msd, cbits, name, enc):
+    """one letter, periods, specials everywhere: runs above the LDS tile (one
+    workgroup each)"""
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+def _skewed():
+    rng = np.random.default_rng(23)
+    r = rng.integers(0, 4, 30000, dtype=np.uint8)
+    yield "poly_A_inside_random", np.concatenate([r, np.zeros(20000, np.uint8), r[:5000]])
+    yield "poly_T_at_the_end", np.concatenate([r, np.full(9000, 3, np.uint8)])
+    yield "wildcard_run", np.concatenate([r, np.full(15000, 254, np.uint8), r[:100]])
+    yield "two_letters", rng.integers(0, 2, 60000, dtype=np.uint8)
+    yield "one_12mer_over_and_over", np.concatenate(
+        [np.concatenate([r[:12], rng.integers(0, 4, 9, dtype=np.uint8)]) for _ in range(3000)])
+    yield "separators_everywhere", np.where(rng.random(50000) < 0.1, 255,
+                                            rng.integers(0, 4, 50000)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name,enc", list(_skewed()), ids=[c[0] for c in _skewed()])
+@pytest.mark.parametrize("big_max", ["4096", "524288"])
+@pytest.mark.parametrize("cbits", ["0", "8"])
+def test_skewed_ranges(gpu, msd, cbits, big_max, name, enc):
+    """ranges far above the LDS tile; with GTAMD_MSD_BIG_MAX=4096 every oversize
+    run takes the device-wide path of the giant runs"""
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    msd.setenv("GTAMD_MSD_BIG_MAX", big_max)
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+@pytest.mark.parametrize("kind", ["all_wildcards", "alternating", "every_20th", "runs_of_19",
+                                  "separators_every_21"])
+def test_special_heavy(gpu, msd, kind):
+    n = 3 * 4096 + 77
+    rng = np.random.default_rng(5)
+    enc = rng.integers(0, 4, size=n).astype(np.uint8)
+    if kind == "all_wildcards":
+        enc[:] = 254
+    elif kind == "alternating":
+        enc[::2] = 254
+    elif kind == "every_20th":
+        enc[19::20] = 254
+    elif kind == "runs_of_19":
+        enc[:] = 254
+        enc[::20] = rng.integers(0, 4, size=enc[::20].size)
+    else:
+        enc[21::22] = 255
+        enc[-1] = 0
+    res = esa.suffixerator_tables(enc, 4)
+    _assert_same_as_oracle(enc, 4, res)
+
+
+def test_want_subsets_and_reuse(gpu, msd):
+    enc1 = synth.generate(synth.MODEL_HUMANLIKE_DNA, 9, 200000)
+    enc2 = synth.generate(synth.MODEL_UNIFORM_DNA, 10, 50000)
+    with esa.EsaEngine(200000, 4) as eng:
+        for enc in (enc1, enc2, enc1):
+            ora = ou.esa(enc, 4)
+            eng.set_sequence(enc)
+            for want in (esa.WANT_SUF, esa.WANT_LCP, esa.WANT_BWT,
+                         esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT):
+                eng.run(want)
+                r = eng.result()
+                if want & esa.WANT_SUF:
+                    assert np.array_equal(r.suf, ora["suf"])
+                if want & esa.WANT_LCP:
+                    assert np.array_equal(r.lcp, ora["lcp"])
+                    assert np.array_equal(r.llv, ora["llv"])
+                if want & esa.WANT_BWT:
+                    assert np.array_equal(r.bwt, ora["bwt"])
+
+
+@pytest.mark.parametrize("model,n,seed", [
+    (synth.MODEL_HUMANLIKE_DNA, 40_000_000, 11),     # 2 bits at level C
+    (synth.MODEL_REPEAT_HEAVY, 20_000_003, 12),      # 1 bit, satellite arrays: big runs
+    (synth.MODEL_UNIFORM_DNA, 150_000_000, 13),      # 4 bits
+])
+def test_same_tables_as_the_lsd_sort(gpu, monkeypatch, model, n, seed):
+    """beyond the oracle's reach: the two sorts must agree on every table and
+    statistic (the LSD sort is pinned at these sizes by test_fullsize_gpu and by
+    the property tests of test_esa_gpu)"""
+    enc = synth.generate(model, seed, n)
+    out = {}
+    with esa.EsaEngine(n, 4) as eng:
+        eng.set_sequence(enc)
+        for mode in ("0", "1"):
+            monkeypatch.setenv("GTAMD_MSD", mode)
+            eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT)
+            r = eng.result()
+            out[mode] = (_md5(r.suf), _md5(r.lcp), _md5(r.bwt), _md5(r.llv), dict(r.stats))
+    assert out["0"][:4] == out["1"][:4]
+    for k in ("longest", "largelcpvalues", "maxbranchdepth", "lcptabsum", "prefixlength",
+              "numberofallsortedsuffixes"):
+        assert out["0"][4][k] == out["1"][4][k], k

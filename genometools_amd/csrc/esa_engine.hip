@@ -3119,7 +3119,11 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   o.prefixlength = prefixlength;
   HIP_TRY(hipMemsetAsync(o.tiebits, 0, (div_up(N, 64) + 2) * 8, st));
   if (ntD > 0) {
-    k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb, o);
+    // (GTAMD_MSD_RADIX=1: the LSD passes in every tile -- what a tile with a
+    // crowded bin falls back to; tests)
+    const char *fr = getenv("GTAMD_MSD_RADIX");
+    k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
+                                                        fr != nullptr && fr[0] == '1', o);
     HIP_TRY(hipGetLastError());
   }
   if (nbig > 0) {

@@ -51,7 +51,7 @@ struct MsTile {       // ragged tile of a level pass
 struct MdTile {       // level D: a run of whole finest-level ranges
   u32 begin, end;     // entries [begin, end)
   u32 s16;            // the 16 key bits levels A and B have used
-  u32 pad;
+  u32 pad;            // level-C digit of the first range | number of ranges << 16
 };
 struct MsdOut {
   u64 *suf;
@@ -143,6 +143,31 @@ __device__ __forceinline__ void ms_match(u32 d, u32 &intra, u32 &group) {
 }
 
 typedef __attribute__((address_space(3))) volatile u16 ms_vu16;
+
+// barrier for kernels whose threads share LDS only: waits for this wave's LDS
+// operations, not for its global loads and stores (__syncthreads() makes the
+// stores of the table emission and the loads fetched ahead for the next run
+// complete first: ~2 us per barrier in a kernel that has a dozen per run)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+// block_scan_excl of esa_devutil.h (sum, 512 threads) on that barrier
+__device__ __forceinline__ u32 ms_scan_excl(u32 v, u32 *lds8) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const u32 inc = wave_scan_incl<SCAN_SUM>(v);
+  if (lane == 63) lds8[w] = inc;
+  lds_barrier();
+  u32 carry = 0;
+#pragma unroll
+  for (int i = 0; i < MS_WAVES; i++) {
+    const u32 x = lds8[i];
+    if (i < w) carry += x;
+  }
+  lds_barrier();
+  u32 prev = __shfl_up(inc, 1, 64);
+  if (lane == 0) prev = 0;
+  return carry + prev;
+}
 
 // ---------------------------------------------------------------------------
 // level A: keygen + partition on the first four symbols
@@ -490,11 +515,12 @@ __global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, i
     const u64 lo = (u64) s << cb, hi = (u64) (s + 1) << cb;
     const u32 pbase = F[lo];
     u32 cut[2];
+    u64 cutj[2];     // the range the cut is the start of
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const u32 kk = k + (u32) q;
-      if (kk == 0) cut[q] = pbase;
-      else if (kk >= count) cut[q] = F[hi];
+      if (kk == 0) { cut[q] = pbase; cutj[q] = lo; }
+      else if (kk >= count) { cut[q] = F[hi]; cutj[q] = hi; }
       else {
         // first range start >= target among F[lo .. hi]
         const u64 target = (u64) pbase + (u64) kk * MSD_STRIDE;
@@ -504,11 +530,15 @@ __global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, i
           if ((u64) F[mid] >= target) b = mid; else a = mid;
         }
         cut[q] = F[b];
+        cutj[q] = b;
       }
     }
     d.begin = cut[0];
     d.end = cut[1];
     d.s16 = s;
+    // level-C digit of the first range and the number of ranges: what is left
+    // to sort is K2 - (digit << (32 - cb)), below (ranges << (32 - cb))
+    d.pad = (u32) (cutj[0] - lo) | ((u32) (cutj[1] - cutj[0]) << 16);
     const u32 cnt = d.end - d.begin;
     if (cnt > big_max) {
       giantlist[atomicAdd(&counters[3], 1u)] = t;
@@ -536,7 +566,7 @@ __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32
   const u32 off64 = (u32) (gbeg & 63);
   const u32 nbw = (cnt + off64 + 63u) >> 6;
   for (u32 i = tid; i < 2u * nbw; i += MS_THREADS) s_bits[i] = 0;
-  __syncthreads();
+  lds_barrier();
   const u32 mis = (u32) (gbeg & 3);
   const u32 nquads = (cnt + mis + 3u) >> 2;
   const u64 gq = gbeg - mis;
@@ -611,7 +641,7 @@ __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32
       atomicOr(&s_bits[bo >> 5], tiemask << (bo & 31u));
     }
   }
-  __syncthreads();
+  lds_barrier();
   const u64 w0 = gbeg >> 6;
   for (u32 wi = tid; wi < nbw; wi += MS_THREADS) {
     const u64 v = (u64) s_bits[2u * wi] | ((u64) s_bits[2u * wi + 1u] << 32);
@@ -621,7 +651,7 @@ __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32
     else atomicOr(reinterpret_cast<unsigned long long *>(o.tiebits + w0 + wi),
                   (unsigned long long) v);
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 __device__ __forceinline__ void msd_acc_flush(MsdAcc acc, Stats *stats) {
@@ -664,114 +694,236 @@ constexpr int MD_BITS = 9;
 constexpr int MD_RADIX = 1 << MD_BITS;
 static_assert(MD_RADIX == MS_THREADS, "one thread per digit in the scan");
 
-__global__ __launch_bounds__(MS_THREADS) void k_msd_local(
+// The sort inside a run.  Fast path: ONE counting pass on the top 13 of the
+// bits that are left (LDS atomics; a bin holds the entries that share ~18.5
+// symbols: one, seldom more), then every entry finds its place inside its bin by
+// comparing (rest of the bits, input order) with its bin mates -- exact and
+// stable whatever order the atomics came back in.  A tile with a bin above
+// MD_BIN_LIMIT (many copies of one 20-mer) takes the stable LSD passes instead
+// (three or four 9-bit digits, ballot-ranked like the scatter kernels).
+constexpr int MD_BINBITS = 13;
+constexpr int MD_BINS = 1 << MD_BINBITS;
+constexpr u32 MD_BIN_LIMIT = 32;
+
+__device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
+  return (s_binw[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu;
+}
+
+__global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
-    u32 ntiles, int cb, MsdOut o) {
+    u32 ntiles, int cb, int force_radix, MsdOut o) {
   __shared__ u32 s_key[MS_TILE];
   __shared__ u32 s_val[MS_TILE];
-  __shared__ u16 s_cnt_mem[MS_WAVES * MD_RADIX];
+  // bin counters (two 16-bit counters per word, one more for the end of the
+  // last bin) and the flag; the LSD passes keep their wave counters here too
+  __shared__ __attribute__((aligned(16))) u32 s_binw[MD_BINS / 2 + 8];
   __shared__ u32 s_scan[MS_WAVES];
   __shared__ u32 s_bits[(MS_TILE + 128) / 32];
+  static_assert(MS_WAVES * MD_RADIX * 2 <= MD_BINS * 2, "wave counters fit the bin counters");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+  ms_vu16 *s_cnt = (ms_vu16 *) s_binw;
   ms_vu16 *cnt_w = s_cnt + w * MD_RADIX;
+  u32 *s_c = s_key;     // (rest of the bits, input order) at the counting-sort place
   MsdAcc acc;
   acc.sum = acc.ties = 0;
   acc.mx = 0;
-  for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const MdTile td = tiles[t];
-    const u32 cnt = td.end - td.begin;
-    if (cnt == 0 || cnt > (u32) MS_TILE) continue;   // (oversize: k_msd_big)
-    u32 base;
-    int nbits;
-    msd_run_bits(kin, td.begin, td.end, cb, base, nbits);
-    const int npass = nbits > 3 ? (nbits - 3 + MD_BITS - 1) / MD_BITS : 0;
-    // items per thread and the wave's chunk, so that a part-filled tile keeps
-    // all eight waves busy
+  // The kernel is bound by latency, not by instructions or bytes (a run is
+  // 2500 entries: five per thread): the next run's entries are fetched while
+  // this run's tables are written, and no barrier waits for global memory.
+  u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
+  MdTile td;
+  td.begin = td.end = td.s16 = td.pad = 0;
+  u32 t = blockIdx.x;
+  if (t < ntiles) td = tiles[t];
+  auto fetch = [&](const MdTile &x) {
+    const u32 cnt = x.end - x.begin;
+    if (cnt == 0 || cnt > (u32) MS_TILE) return;
     const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
-    u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
-    const u32 *kp = kin + td.begin;
-    const u32 *pp = pin + td.begin;
+    const u32 *kp = kin + x.begin;
+    const u32 *pp = pin + x.begin;
 #pragma unroll
     for (int j = 0; j < MS_ITEMS; j++) {
       const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
       if ((u32) j < items && e < cnt) {
-        key[j] = kp[e] - base;
+        key[j] = kp[e];
         val[j] = pp[e];
+      }
+    }
+  };
+  fetch(td);
+  while (t < ntiles) {
+    const u32 tn = t + gridDim.x;
+    MdTile tdn;
+    tdn.begin = tdn.end = tdn.s16 = tdn.pad = 0;
+    if (tn < ntiles) tdn = tiles[tn];
+    const u32 cnt = td.end - td.begin;
+    if (cnt == 0 || cnt > (u32) MS_TILE) {   // (oversize: k_msd_big, k_msd_emit_run)
+      fetch(tdn);
+      t = tn;
+      td = tdn;
+      continue;
+    }
+    // what is left to sort: K2 minus the first range's level-C digit
+    const int csh = 32 - cb;
+    const u32 span = td.pad >> 16;
+    const u32 base = cb ? (td.pad & 0xFFFFu) << csh : 0u;
+    const int nbits = cb ? csh + (span > 1u ? 32 - __clz((int) (span - 1u)) : 0) : 32;
+    // items per thread and the wave's chunk, so that a part-filled tile keeps
+    // all eight waves busy
+    const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
+    // ---- counting pass
+    const int sb = nbits - 3;
+    const int binshift = sb > MD_BINBITS ? nbits - MD_BINBITS : 3;
+    const u32 lowmask = sb > MD_BINBITS ? (1u << (binshift - 3)) - 1u : 0u;
+    for (int i = tid; i < MD_BINS / 2 + 8; i += MS_THREADS) s_binw[i] = 0;
+    lds_barrier();
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+      const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+      if ((u32) j < items && e < cnt) {
+        key[j] -= base;
+        const u32 bin = key[j] >> binshift;
+        const u32 old = atomicAdd(&s_binw[bin >> 1], (bin & 1u) ? 65536u : 1u);
+        rk[j] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
       } else {
         key[j] = ~0u;
         val[j] = 0;
       }
     }
-    if (npass == 0) {
+    lds_barrier();
+    {
+      // thread tid owns bins 16 tid .. 16 tid + 15: counts -> exclusive starts
+      uint4 q0 = reinterpret_cast<uint4 *>(s_binw)[2 * tid];
+      uint4 q1 = reinterpret_cast<uint4 *>(s_binw)[2 * tid + 1];
+      u32 wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      u32 run = 0, mx = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const u32 c0 = wd[k] & 0xFFFFu, c1 = wd[k] >> 16;
+        mx = c0 > mx ? c0 : mx;
+        mx = c1 > mx ? c1 : mx;
+        wd[k] = run | ((run + c0) << 16);
+        run += c0 + c1;
+      }
+      const u32 pre = ms_scan_excl(run, s_scan);
+#pragma unroll
+      for (int k = 0; k < 8; k++) wd[k] += pre * 0x10001u;
+      reinterpret_cast<uint4 *>(s_binw)[2 * tid] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+      reinterpret_cast<uint4 *>(s_binw)[2 * tid + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
+      if (tid == 0) s_binw[MD_BINS / 2] = cnt;           // end of the last bin
+      if (mx > MD_BIN_LIMIT || force_radix) s_binw[MD_BINS / 2 + 1] = 1u;
+    }
+    lds_barrier();
+    const bool crowded = s_binw[MD_BINS / 2 + 1] != 0;     // the same for every thread
+    if (!crowded) {
 #pragma unroll
       for (int j = 0; j < MS_ITEMS; j++) {
         const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-        if ((u32) j < items && e < (u32) MS_TILE) { s_key[e] = key[j]; s_val[e] = val[j]; }
+        if ((u32) j < items && e < cnt) {
+          const u32 b0 = md_base(s_binw, key[j] >> binshift);
+          s_c[b0 + rk[j]] = (((key[j] >> 3) & lowmask) << 12) | e;
+        }
       }
-      __syncthreads();
-    }
-    for (int p = 0; p < npass; p++) {
-      const int shift = 3 + MD_BITS * p;
-      for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS)
-        reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < MS_ITEMS; j++) {
-        if ((u32) j < items) {
-          const u32 d = (key[j] >> shift) & (u32) (MD_RADIX - 1);
-          u32 intra, group;
-          ms_match<MD_BITS>(d, intra, group);
-          const u32 old = cnt_w[d];
-          if (intra == 0) cnt_w[d] = (u16) (old + group);
-          rk[j] = ((old + intra) << MD_BITS) | d;
+        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+        if ((u32) j < items && e < cnt) {
+          const u32 bin = key[j] >> binshift;
+          const u32 b0 = md_base(s_binw, bin), b1 = md_base(s_binw, bin + 1u);
+          const u32 c = (((key[j] >> 3) & lowmask) << 12) | e;
+          // the first four bin mates in one go (a bin seldom has more), the
+          // rest one by one
+          const u32 last = b1 - 1u;
+          const u32 c0 = s_c[b0], c1 = s_c[b0 + 1u < last ? b0 + 1u : last],
+                    c2 = s_c[b0 + 2u < last ? b0 + 2u : last],
+                    c3 = s_c[b0 + 3u < last ? b0 + 3u : last];
+          u32 r = b0 + (c0 < c ? 1u : 0u);
+          r += (b0 + 1u < b1 && c1 < c) ? 1u : 0u;
+          r += (b0 + 2u < b1 && c2 < c) ? 1u : 0u;
+          r += (b0 + 3u < b1 && c3 < c) ? 1u : 0u;
+          for (u32 q = b0 + 4u; q < b1; q++) r += s_c[q] < c ? 1u : 0u;
+          rk[j] = r;
         }
       }
-      __syncthreads();
-      {
-        u32 c[MS_WAVES];
-        u32 tot = 0;
-#pragma unroll
-        for (int i = 0; i < MS_WAVES; i++) {
-          c[i] = s_cnt[i * MD_RADIX + tid];
-          tot += c[i];
-        }
-        u32 all;
-        u32 dbase = block_scan_excl<SCAN_SUM, MS_THREADS>(tot, &all, s_scan);
-#pragma unroll
-        for (int i = 0; i < MS_WAVES; i++) {
-          s_cnt[i * MD_RADIX + tid] = (u16) dbase;
-          dbase += c[i];
-        }
-      }
-      __syncthreads();
+      lds_barrier();   // s_c is read, its space is s_key again
 #pragma unroll
       for (int j = 0; j < MS_ITEMS; j++) {
-        if ((u32) j < items) {
-          const u32 d = rk[j] & (u32) (MD_RADIX - 1);
-          const u32 pos = (u32) cnt_w[d] + (rk[j] >> MD_BITS);
-          s_key[pos] = key[j];
-          s_val[pos] = val[j];
+        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+        if ((u32) j < items && e < cnt) {
+          s_key[rk[j]] = key[j];
+          s_val[rk[j]] = val[j];
         }
       }
-      __syncthreads();
-      if (p + 1 < npass) {
+      lds_barrier();
+    } else {
+      const int npass = (sb + MD_BITS - 1) / MD_BITS;
+      for (int p = 0; p < npass; p++) {
+        const int shift = 3 + MD_BITS * p;
+        lds_barrier();
+        for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS) s_binw[i] = 0;
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < MS_ITEMS; j++) {
           if ((u32) j < items) {
-            const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-            key[j] = s_key[e];
-            val[j] = s_val[e];
+            const u32 d = (key[j] >> shift) & (u32) (MD_RADIX - 1);
+            u32 intra, group;
+            ms_match<MD_BITS>(d, intra, group);
+            const u32 old = cnt_w[d];
+            if (intra == 0) cnt_w[d] = (u16) (old + group);
+            rk[j] = ((old + intra) << MD_BITS) | d;
+          }
+        }
+        lds_barrier();
+        {
+          u32 c[MS_WAVES];
+          u32 tot = 0;
+#pragma unroll
+          for (int i = 0; i < MS_WAVES; i++) {
+            c[i] = s_cnt[i * MD_RADIX + tid];
+            tot += c[i];
+          }
+          u32 dbase = ms_scan_excl(tot, s_scan);
+#pragma unroll
+          for (int i = 0; i < MS_WAVES; i++) {
+            s_cnt[i * MD_RADIX + tid] = (u16) dbase;
+            dbase += c[i];
+          }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < MS_ITEMS; j++) {
+          if ((u32) j < items) {
+            const u32 d = rk[j] & (u32) (MD_RADIX - 1);
+            const u32 pos = (u32) cnt_w[d] + (rk[j] >> MD_BITS);
+            s_key[pos] = key[j];
+            s_val[pos] = val[j];
+          }
+        }
+        lds_barrier();
+        if (p + 1 < npass) {
+#pragma unroll
+          for (int j = 0; j < MS_ITEMS; j++) {
+            if ((u32) j < items) {
+              const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+              key[j] = s_key[e];
+              val[j] = s_val[e];
+            }
           }
         }
       }
     }
+    // the next run's entries are on their way while this one's tables go out
+    fetch(tdn);
     if (tid == 0) {
       o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
       o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
     }
     msd_emit(s_key, s_val, cnt, td.begin, base, td.s16, false, 0ull, o, s_bits, acc);
+    t = tn;
+    td = tdn;
   }
+  __syncthreads();
   msd_acc_flush(acc, o.stats);
 }
 

@@ -51,6 +51,7 @@ def test_uniform_dna_small(gpu, msd, cbits, n):
     _assert_same_as_oracle(enc, 4, res)
 
 
+@pytest.mark.parametrize("radix", ["0", "1"])
 @pytest.mark.parametrize("cbits", ["0", "5", "8"])
 @pytest.mark.parametrize("model,n,seed", [
     (synth.MODEL_UNIFORM_DNA, 1 << 20, 1),
@@ -58,8 +59,11 @@ def test_uniform_dna_small(gpu, msd, cbits, n):
     (synth.MODEL_HUMANLIKE_DNA, 600000, 3),
     (synth.MODEL_REPEAT_HEAVY, 300000, 6),
 ])
-def test_synthetic_models(gpu, msd, cbits, model, n, seed):
+def test_synthetic_models(gpu, msd, radix, cbits, model, n, seed):
+    """radix=1: the LSD passes inside every run (what a run with a crowded bin
+    of the counting pass falls back to)"""
     msd.setenv("GTAMD_MSD_CBITS", cbits)
+    msd.setenv("GTAMD_MSD_RADIX", radix)
     enc = synth.generate(model, seed, n)
     res = esa.suffixerator_tables(enc, 4)
     _assert_same_as_oracle(enc, 4, res)

@@ -9,14 +9,18 @@ template <int OP> __device__ __forceinline__ u32 sc_op(u32 a, u32 b) {
   return OP == SCAN_SUM ? a + b : (a > b ? a : b);
 }
 
-// inclusive scan across the 64 lanes of a wave
+// inclusive scan across the 64 lanes of a wave: four shifts inside the rows of
+// 16 lanes and two row broadcasts, all as DPP operands of the VALU (a
+// __shfl_up goes through the LDS crossbar: six dependent round trips of ~100
+// cycles each, which was most of the latency of a block scan).  0 is the
+// identity of both operations; a lane without a source reads it.
 template <int OP> __device__ __forceinline__ u32 wave_scan_incl(u32 v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    u32 o = __shfl_up(v, d, 64);
-    if (lane >= d) v = sc_op<OP>(v, o);
-  }
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false));  // row_shr:1
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false));  // row_shr:2
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false));  // row_shr:4
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false));  // row_shr:8
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+  v = sc_op<OP>(v, (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false));  // row_bcast:31
   return v;
 }
 
@@ -37,8 +41,8 @@ __device__ __forceinline__ u32 block_scan_excl(u32 v, u32 *total, u32 *lds4) {
   }
   __syncthreads();
   *total = tot;
-  u32 prev = __shfl_up(inc, 1, 64);
-  if (lane == 0) prev = 0;
+  // the inclusive value of the lane below (wave_shr:1; lane 0 reads 0)
+  const u32 prev = (u32) __builtin_amdgcn_update_dpp(0, (int) inc, 0x138, 0xf, 0xf, false);
   return sc_op<OP>(carry, prev);
 }
 

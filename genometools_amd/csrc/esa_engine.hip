@@ -2974,7 +2974,7 @@ static u32 msd_big_max() {
 }
 struct MsdWs {
   u32 *hist, *scanws, *tcnt, *tfirst, *dtcnt, *dtfirst, *startA, *startB, *F, *scan2, *counters,
-      *biglist, *giantlist;
+      *biglist, *giantlist, *crowdlist;
   MsTile *desc;
   MdTile *dtiles;
   u64 *firstkey, *lastkey;
@@ -3007,6 +3007,7 @@ static u64 msd_carve(u64 N, int cb, u8 *base, MsdWs *w) {
   w->firstkey = b.take<u64>(w->tilesD_ub);
   w->lastkey = b.take<u64>(w->tilesD_ub);
   w->biglist = b.take<u32>(w->tilesD_ub);
+  w->crowdlist = b.take<u32>(w->tilesD_ub);
   w->giantlist = b.take<u32>((u64) (N / MS_TILE) + 8);
   return b.off + 256;
 }
@@ -3082,8 +3083,8 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   HIP_TRY(hipGetLastError());
   TRY(scan_u32(SCAN_SUM, w.dtcnt, w.dtfirst, (u64) MSD_PARENTS + 1, false, w.scan2, st));
   k_msd_dtiles<<<(w.tilesD_ub + 255) / 256, 256, 0, st>>>(F, cb, w.dtfirst, w.tilesD_ub, w.dtiles,
-                                                        w.biglist, w.giantlist, w.counters,
-                                                        msd_big_max());
+                                                        w.biglist, w.giantlist, w.crowdlist,
+                                                        w.counters, msd_big_max());
   HIP_TRY(hipGetLastError());
   u32 *hc = c->h_counts;
   HIP_TRY(hipMemcpyAsync(hc, w.counters, 16, hipMemcpyDeviceToHost, st));
@@ -3119,11 +3120,16 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   o.prefixlength = prefixlength;
   HIP_TRY(hipMemsetAsync(o.tiebits, 0, (div_up(N, 64) + 2) * 8, st));
   if (ntD > 0) {
-    // (GTAMD_MSD_RADIX=1: the LSD passes in every tile -- what a tile with a
-    // crowded bin falls back to; tests)
+    // (GTAMD_MSD_RADIX=1: every run takes the LSD passes a run with a crowded
+    // bin of the counting pass is left to; tests)
     const char *fr = getenv("GTAMD_MSD_RADIX");
     k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
-                                                        fr != nullptr && fr[0] == '1', o);
+                                                        fr != nullptr && fr[0] == '1', w.crowdlist,
+                                                        w.counters, o);
+    HIP_TRY(hipGetLastError());
+    k_msd_local_radix<<<ntD < 2048u ? ntD : 2048u, MS_THREADS, 0, st>>>(kf, pf, w.dtiles,
+                                                                        w.crowdlist, w.counters,
+                                                                        cb, o);
     HIP_TRY(hipGetLastError());
   }
   if (nbig > 0) {

@@ -41,7 +41,9 @@ constexpr int MS_ITEMS = MS_TILE / MS_THREADS;     // 8
 constexpr int MS_WCHUNK = MS_ITEMS * 64;           // 512 consecutive entries per wave
 constexpr int MS_PAD = 520;                        // row pitch of the keygen transposition
 constexpr u32 MSD_PARENTS = 65536;                 // ranges after levels A and B
-constexpr u32 MSD_STRIDE = 2560;                   // level D: entries per tile before snapping
+constexpr u32 MSD_STRIDE = 3328;                   // level D: entries per tile before snapping
+constexpr int MD_ITEMS = 8;                        // level D: entries per thread, at most
+constexpr u32 MD_CAP = MD_ITEMS * MS_THREADS;      // largest run of the LDS kernels
 constexpr u32 MSD_BIG_MAX = 1u << 19;              // largest run one workgroup sorts alone
 
 struct MsTile {       // ragged tile of a level pass
@@ -164,9 +166,7 @@ __device__ __forceinline__ u32 ms_scan_excl(u32 v, u32 *lds8) {
     if (i < w) carry += x;
   }
   lds_barrier();
-  u32 prev = __shfl_up(inc, 1, 64);
-  if (lane == 0) prev = 0;
-  return carry + prev;
+  return carry + (inc - v);
 }
 
 // ---------------------------------------------------------------------------
@@ -498,12 +498,14 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_lvl(
 // >= parent start + k * MSD_STRIDE.  A tile above the LDS tile goes to the big
 // list (one workgroup sorts it in global memory), one above MSD_BIG_MAX to the
 // giant list (the driver sorts it with the device-wide sort).  counters: [0] big
-// tiles, [1] largest tile, [2] entries in big and giant tiles, [3] giant tiles
+// tiles, [1] largest tile, [2] entries in big and giant tiles, [3] giant tiles,
+// [4] tiles k_msd_local leaves to k_msd_local_radix
 __global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, int cb,
                                                     const u32 *__restrict__ tfirst, u32 tiles_ub,
                                                     MdTile *__restrict__ tiles,
                                                     u32 *__restrict__ biglist,
                                                     u32 *__restrict__ giantlist,
+                                                    u32 *__restrict__ crowdlist,
                                                     u32 *__restrict__ counters, u32 big_max) {
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   if (t >= tiles_ub) return;
@@ -556,12 +558,92 @@ __global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, i
 // Table entries of the sorted run [gbeg, gbeg + cnt) that lies in LDS
 // (s_key[i] + base = K2 of entry i, s_val[i] its position): .suf, .lcp
 // (provisional for tied entries, as k_finalize), .bwt, the 32-bit positions and
-// the tie bits.  The entry in front of the run: prevkey if has_prev, else the
-// run's first entry gets lcp 0 and k_msd_seams settles it.
+// the tie bits.  The entries of a run share their first 8 symbols, so all of
+// it is 32-bit arithmetic on K2 (symbols 8..19 | dcode | payload).  The entry
+// in front of the run: K2 = prevk2 if has_prev, else the run's first entry
+// gets lcp 0 and k_msd_seams settles it.
+__device__ __forceinline__ u32 k2_letters(u32 k2) {
+  const u32 dc = (k2 >> 3) & 31u;
+  return dc == 0 ? 20u : (dc == 31u ? 0u : 20u - dc);
+}
+// one quad of table entries (entries i0 .. i0+3 of the run, global index g0 ..);
+// INTERIOR: all four and the entry in front are inside the run
+template <bool INTERIOR>
+__device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val, int i0, u32 cnt,
+                                             u64 g0, u32 base, bool has_prev, u32 prevk2,
+                                             const MsdOut &o, MsdAcc &acc) {
+  u32 k[4], pv[4];
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int i = i0 + c;
+    const bool ok = INTERIOR || (i >= 0 && i < (int) cnt);
+    k[c] = ok ? s_key[i] + base : 0u;
+    pv[c] = ok ? s_val[i] : 0u;
+  }
+  const u32 prevk = (INTERIOR || i0 > 0) ? s_key[i0 - 1] + base : prevk2;
+  u32 lcpv[4] = {0, 0, 0, 0}, tiemask = 0;
+  u32 da = k2_letters(prevk);
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int i = i0 + c;
+    const bool ok = INTERIOR || (i >= 0 && i < (int) cnt);
+    const bool have_a = INTERIOR || i > 0 || has_prev;
+    const u32 a = (c == 0 || (!INTERIOR && i == 0)) ? prevk : k[c - 1], b = k[c];
+    if (!INTERIOR && c > 0 && i == 0) da = k2_letters(prevk);
+    const u32 db = k2_letters(b);
+    const u32 x = (a ^ b) >> 8;                       // symbols 8 .. 19
+    const u32 m = x ? 8u + ((u32) __clz((int) x) - 8u) / 2u : 20u;
+    u32 l = m < da ? m : da;
+    l = l < db ? l : db;
+    bool tie = x == 0 && ((a | b) & 0xF8u) == 0;      // all 20 symbols, both dcodes 0
+    if (!have_a) { l = 0; tie = false; }
+    da = db;
+    if (!ok) continue;
+    lcpv[c] = l;
+    if (tie) {
+      tiemask |= 1u << c;
+      acc.ties++;
+    } else {
+      if (have_a) {
+        acc.mx = l > acc.mx ? l : acc.mx;
+        if (db >= o.prefixlength) acc.sum += l;
+      }
+      if (pv[c] == 0) o.stats->longest = g0 + (u64) c;
+    }
+  }
+  if (INTERIOR || (i0 >= 0 && i0 + 4 <= (int) cnt)) {
+    if (o.suf != nullptr) {
+      *reinterpret_cast<ulonglong2 *>(o.suf + g0) = make_ulonglong2(pv[0], pv[1]);
+      *reinterpret_cast<ulonglong2 *>(o.suf + g0 + 2) = make_ulonglong2(pv[2], pv[3]);
+    }
+    *reinterpret_cast<uint4 *>(o.sa + g0) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
+    if (o.lcp != nullptr)
+      *reinterpret_cast<u32 *>(o.lcp + g0) =
+          lcpv[0] | (lcpv[1] << 8) | (lcpv[2] << 16) | (lcpv[3] << 24);
+    if (o.bwt != nullptr) {
+      u32 bw = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) bw |= (u32) Pay<2>::to_bwt(k[c] & 7u) << (8 * c);
+      *reinterpret_cast<u32 *>(o.bwt + g0) = bw;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = i0 + c;
+      if (i < 0 || i >= (int) cnt) continue;
+      if (o.suf != nullptr) o.suf[g0 + c] = pv[c];
+      o.sa[g0 + c] = pv[c];
+      if (o.lcp != nullptr) o.lcp[g0 + c] = (u8) lcpv[c];
+      if (o.bwt != nullptr) o.bwt[g0 + c] = Pay<2>::to_bwt(k[c] & 7u);
+    }
+  }
+  return tiemask;
+}
+
 __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32 cnt, u64 gbeg,
-                                         u32 base, u32 s16, bool has_prev, u64 prevkey,
+                                         u32 base, bool has_prev, u32 prevk2,
                                          const MsdOut &o, u32 *s_bits, MsdAcc &acc) {
-  using K = Key<2>;
+  static_assert(Key<2>::SYMS == 20 && Key<2>::DMAX == 31, "the layout msd_full spells out");
   const int tid = threadIdx.x;
   const u32 off64 = (u32) (gbeg & 63);
   const u32 nbw = (cnt + off64 + 63u) >> 6;
@@ -572,70 +654,12 @@ __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32
   const u64 gq = gbeg - mis;
   for (u32 q = tid; q < nquads; q += MS_THREADS) {
     const int i0 = (int) (4u * q) - (int) mis;
-    u64 k[4];
-    u32 pv[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = i0 + c;
-      const bool ok = i >= 0 && i < (int) cnt;
-      k[c] = ok ? msd_full(s16, s_key[i] + base) : 0ull;
-      pv[c] = ok ? s_val[i] : 0u;
-    }
-    const u64 prevk = i0 > 0 ? msd_full(s16, s_key[i0 - 1] + base) : prevkey;
-    u32 lcpv[4] = {0, 0, 0, 0}, tiemask = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = i0 + c;
-      if (i < 0 || i >= (int) cnt) continue;
-      const bool have_a = i > 0 || has_prev;
-      const u64 a = (c == 0 || i == 0) ? prevk : k[c - 1], b = k[c];
-      const u32 da = K::letters(a), db = K::letters(b);
-      const u64 x = (a ^ b) >> K::LOW_BITS;
-      const u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;
-      u32 l = m < da ? m : da;
-      l = l < db ? l : db;
-      bool tie = m == (u32) K::SYMS && K::dcode(a) == 0 && K::dcode(b) == 0;
-      if (!have_a) { l = 0; tie = false; }
-      lcpv[c] = l;
-      if (tie) {
-        tiemask |= 1u << c;
-        acc.ties++;
-      } else {
-        if (have_a) {
-          acc.mx = l > acc.mx ? l : acc.mx;
-          if (db >= o.prefixlength) acc.sum += l;
-        }
-        if (pv[c] == 0) o.stats->longest = gq + 4ull * q + (u64) c;
-      }
-    }
     const u64 g0 = gq + 4ull * q;
-    if (i0 >= 0 && i0 + 4 <= (int) cnt) {
-      if (o.suf != nullptr) {
-        *reinterpret_cast<ulonglong2 *>(o.suf + g0) = make_ulonglong2(pv[0], pv[1]);
-        *reinterpret_cast<ulonglong2 *>(o.suf + g0 + 2) = make_ulonglong2(pv[2], pv[3]);
-      }
-      *reinterpret_cast<uint4 *>(o.sa + g0) = make_uint4(pv[0], pv[1], pv[2], pv[3]);
-      if (o.lcp != nullptr)
-        *reinterpret_cast<u32 *>(o.lcp + g0) =
-            lcpv[0] | (lcpv[1] << 8) | (lcpv[2] << 16) | (lcpv[3] << 24);
-      if (o.bwt != nullptr) {
-        u32 bw = 0;
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-          bw |= (u32) Pay<2>::to_bwt((u32) (k[c] & K::PAY_MASK)) << (8 * c);
-        *reinterpret_cast<u32 *>(o.bwt + g0) = bw;
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const int i = i0 + c;
-        if (i < 0 || i >= (int) cnt) continue;
-        if (o.suf != nullptr) o.suf[g0 + c] = pv[c];
-        o.sa[g0 + c] = pv[c];
-        if (o.lcp != nullptr) o.lcp[g0 + c] = (u8) lcpv[c];
-        if (o.bwt != nullptr) o.bwt[g0 + c] = Pay<2>::to_bwt((u32) (k[c] & K::PAY_MASK));
-      }
-    }
+    u32 tiemask;
+    if (i0 >= 1 && i0 + 4 <= (int) cnt)
+      tiemask = msd_emit_quad<true>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, o, acc);
+    else
+      tiemask = msd_emit_quad<false>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, o, acc);
     if (tiemask) {
       const u32 bo = 4u * q + (off64 - mis);   // bit of quad entry 0 in the LDS bitmap
       atomicOr(&s_bits[bo >> 5], tiemask << (bo & 31u));
@@ -694,14 +718,14 @@ constexpr int MD_BITS = 9;
 constexpr int MD_RADIX = 1 << MD_BITS;
 static_assert(MD_RADIX == MS_THREADS, "one thread per digit in the scan");
 
-// The sort inside a run.  Fast path: ONE counting pass on the top 13 of the
-// bits that are left (LDS atomics; a bin holds the entries that share ~18.5
+// The sort inside a run.  Fast path: ONE counting pass on the top 12 of the
+// bits that are left (LDS atomics; a bin holds the entries that share ~18
 // symbols: one, seldom more), then every entry finds its place inside its bin by
 // comparing (rest of the bits, input order) with its bin mates -- exact and
 // stable whatever order the atomics came back in.  A tile with a bin above
 // MD_BIN_LIMIT (many copies of one 20-mer) takes the stable LSD passes instead
 // (three or four 9-bit digits, ballot-ranked like the scatter kernels).
-constexpr int MD_BINBITS = 13;
+constexpr int MD_BINBITS = 12;
 constexpr int MD_BINS = 1 << MD_BINBITS;
 constexpr u32 MD_BIN_LIMIT = 32;
 
@@ -711,38 +735,40 @@ __device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
 
 __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
-    u32 ntiles, int cb, int force_radix, MsdOut o) {
+    u32 ntiles, int cb, int force_radix, u32 *__restrict__ crowdlist,
+    u32 *__restrict__ counters, MsdOut o) {
   __shared__ u32 s_key[MS_TILE];
   __shared__ u32 s_val[MS_TILE];
   // bin counters (two 16-bit counters per word, one more for the end of the
-  // last bin) and the flag; the LSD passes keep their wave counters here too
+  // last bin) and the flag
   __shared__ __attribute__((aligned(16))) u32 s_binw[MD_BINS / 2 + 8];
   __shared__ u32 s_scan[MS_WAVES];
   __shared__ u32 s_bits[(MS_TILE + 128) / 32];
-  static_assert(MS_WAVES * MD_RADIX * 2 <= MD_BINS * 2, "wave counters fit the bin counters");
+  static_assert(MD_BINS / 2 == 4 * MS_THREADS, "four counter words per thread in the scan");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  ms_vu16 *s_cnt = (ms_vu16 *) s_binw;
-  ms_vu16 *cnt_w = s_cnt + w * MD_RADIX;
   u32 *s_c = s_key;     // (rest of the bits, input order) at the counting-sort place
   MsdAcc acc;
   acc.sum = acc.ties = 0;
   acc.mx = 0;
-  // The kernel is bound by latency, not by instructions or bytes (a run is
-  // 2500 entries: five per thread): the next run's entries are fetched while
-  // this run's tables are written, and no barrier waits for global memory.
-  u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
-  MdTile td;
-  td.begin = td.end = td.s16 = td.pad = 0;
+  // The kernel is bound by instructions (a run is ~3500 entries, seven per
+  // thread; what a thread does once per run -- its share of the bin scan, the
+  // loop, the barriers -- weighs as much as what it does per entry), then by
+  // the latency of its dozen phases.  So: big runs, no barrier that waits for
+  // global memory, the next run's entries fetched while this run's tables go
+  // out, the LDS reads of a phase issued for all entries before any is used.
+  u32 key[MD_ITEMS], val[MD_ITEMS], rk[MD_ITEMS];
+  const MdTile none = {0u, 0u, 0u, 0u};
+  MdTile td = none;
   u32 t = blockIdx.x;
   if (t < ntiles) td = tiles[t];
   auto fetch = [&](const MdTile &x) {
     const u32 cnt = x.end - x.begin;
-    if (cnt == 0 || cnt > (u32) MS_TILE) return;
+    if (cnt == 0 || cnt > MD_CAP) return;
     const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
     const u32 *kp = kin + x.begin;
     const u32 *pp = pin + x.begin;
 #pragma unroll
-    for (int j = 0; j < MS_ITEMS; j++) {
+    for (int j = 0; j < MD_ITEMS; j++) {
       const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
       if ((u32) j < items && e < cnt) {
         key[j] = kp[e];
@@ -753,175 +779,221 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
   fetch(td);
   while (t < ntiles) {
     const u32 tn = t + gridDim.x;
-    MdTile tdn;
-    tdn.begin = tdn.end = tdn.s16 = tdn.pad = 0;
+    MdTile tdn = none;
     if (tn < ntiles) tdn = tiles[tn];
     const u32 cnt = td.end - td.begin;
-    if (cnt == 0 || cnt > (u32) MS_TILE) {   // (oversize: k_msd_big, k_msd_emit_run)
-      fetch(tdn);
-      t = tn;
-      td = tdn;
-      continue;
+    bool skip = cnt == 0 || cnt > MD_CAP;   // (longer runs: the other kernels)
+    u32 base = 0;
+    if (!skip) {
+      // what is left to sort: K2 minus the first range's level-C digit
+      const int csh = 32 - cb;
+      const u32 span = td.pad >> 16;
+      base = cb ? (td.pad & 0xFFFFu) << csh : 0u;
+      const int nbits = cb ? csh + (span > 1u ? 32 - __clz((int) (span - 1u)) : 0) : 32;
+      // items per thread and the wave's chunk, so that a part-filled tile keeps
+      // all eight waves busy
+      const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
+      const u32 e0 = (u32) w * wchunk + lane;      // entry of item j: e0 + 64 j
+      // ---- counting pass
+      const int sb = nbits - 3;
+      const int binshift = sb > MD_BINBITS ? nbits - MD_BINBITS : 3;
+      const u32 lowmask = sb > MD_BINBITS ? (1u << (binshift - 3)) - 1u : 0u;
+      for (int i = tid; i < MD_BINS / 8 + 2; i += MS_THREADS)
+        reinterpret_cast<uint4 *>(s_binw)[i] = make_uint4(0, 0, 0, 0);
+      lds_barrier();
+#pragma unroll
+      for (int j = 0; j < MD_ITEMS; j++) {
+        if ((u32) j < items && e0 + 64u * j < cnt) {
+          key[j] -= base;
+          const u32 bin = key[j] >> binshift;
+          const u32 old = atomicAdd(&s_binw[bin >> 1], (bin & 1u) ? 65536u : 1u);
+          rk[j] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+        }
+      }
+      lds_barrier();
+      {
+        // thread tid owns bins 8 tid .. 8 tid + 7: counts -> exclusive starts
+        const uint4 q0 = reinterpret_cast<uint4 *>(s_binw)[tid];
+        u32 wd[4] = {q0.x, q0.y, q0.z, q0.w};
+        u32 run = 0, mx = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32 c0 = wd[k] & 0xFFFFu, c1 = wd[k] >> 16;
+          mx = c0 > mx ? c0 : mx;
+          mx = c1 > mx ? c1 : mx;
+          wd[k] = run | ((run + c0) << 16);
+          run += c0 + c1;
+        }
+        const u32 pre = ms_scan_excl(run, s_scan) * 0x10001u;
+        reinterpret_cast<uint4 *>(s_binw)[tid] =
+            make_uint4(wd[0] + pre, wd[1] + pre, wd[2] + pre, wd[3] + pre);
+        if (tid == 0) s_binw[MD_BINS / 2] = cnt;           // end of the last bin
+        if (mx > MD_BIN_LIMIT || force_radix) s_binw[MD_BINS / 2 + 1] = 1u;
+      }
+      lds_barrier();
+      if (s_binw[MD_BINS / 2 + 1] != 0) {     // (the same for every thread)
+        // a crowded bin: this run is left to k_msd_local_radix
+        if (tid == 0) crowdlist[atomicAdd(&counters[4], 1u)] = t;
+        skip = true;
+      } else {
+        // every entry to its bin, in the order the atomics came back, as
+        // (rest of the bits, input order)
+        u32 b0[MD_ITEMS];
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++)
+          b0[j] = ((u32) j < items && e0 + 64u * j < cnt) ? md_base(s_binw, key[j] >> binshift) : 0u;
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++)
+          if ((u32) j < items && e0 + 64u * j < cnt)
+            s_c[b0[j] + rk[j]] = (((key[j] >> 3) & lowmask) << 12) | (e0 + 64u * j);
+        lds_barrier();
+        // its place: the bin's start + the bin mates that are smaller.  The first
+        // two mates in one go (a bin seldom has more), the rest one by one.
+        u32 b1[MD_ITEMS], m0[MD_ITEMS], m1[MD_ITEMS];
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++) {
+          const bool ok = (u32) j < items && e0 + 64u * j < cnt;
+          b1[j] = ok ? md_base(s_binw, (key[j] >> binshift) + 1u) : 1u;
+          m0[j] = s_c[b0[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++) m1[j] = s_c[b0[j] + 1u < b1[j] ? b0[j] + 1u : b0[j]];
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++) {
+          const u32 c = (((key[j] >> 3) & lowmask) << 12) | (e0 + 64u * j);
+          u32 r = b0[j] + (m0[j] < c ? 1u : 0u) + (m1[j] < c ? 1u : 0u);   // (m1 = m0 if alone:
+          if (b0[j] + 1u >= b1[j]) r = b0[j];                              //  then the place is b0)
+          if (b1[j] - b0[j] > 2u)
+            for (u32 q = b0[j] + 2u; q < b1[j]; q++) r += s_c[q] < c ? 1u : 0u;
+          rk[j] = r;
+        }
+        lds_barrier();   // s_c is read, its space is s_key again
+#pragma unroll
+        for (int j = 0; j < MD_ITEMS; j++) {
+          if ((u32) j < items && e0 + 64u * j < cnt) {
+            s_key[rk[j]] = key[j];
+            s_val[rk[j]] = val[j];
+          }
+        }
+        lds_barrier();
+      }
     }
-    // what is left to sort: K2 minus the first range's level-C digit
+    // the next run's entries are on their way while this run's tables go out
+    fetch(tdn);
+    if (!skip) {
+      if (tid == 0) {
+        o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
+        o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
+      }
+      msd_emit(s_key, s_val, cnt, td.begin, base, false, 0u, o, s_bits, acc);
+    }
+    t = tn;
+    td = tdn;
+  }
+  __syncthreads();
+  msd_acc_flush(acc, o.stats);
+}
+
+// the runs k_msd_local has left (a crowded bin) or never had (above its 2044
+// entries): stable LSD passes on 9-bit digits, ballot-ranked like the scatter
+// kernels, up to 4096 entries
+__global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
+    const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
+    const u32 *__restrict__ crowdlist, const u32 *__restrict__ counters, int cb, MsdOut o) {
+  __shared__ u32 s_key[MS_TILE];
+  __shared__ u32 s_val[MS_TILE];
+  __shared__ u16 s_cnt_mem[MS_WAVES * MD_RADIX];
+  __shared__ u32 s_scan[MS_WAVES];
+  __shared__ u32 s_bits[(MS_TILE + 128) / 32];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+  ms_vu16 *cnt_w = s_cnt + w * MD_RADIX;
+  const u32 ncrowd = counters[4];
+  MsdAcc acc;
+  acc.sum = acc.ties = 0;
+  acc.mx = 0;
+  for (u32 ci = blockIdx.x; ci < ncrowd; ci += gridDim.x) {
+    const u32 t = crowdlist[ci];
+    const MdTile td = tiles[t];
+    const u32 cnt = td.end - td.begin;
     const int csh = 32 - cb;
     const u32 span = td.pad >> 16;
     const u32 base = cb ? (td.pad & 0xFFFFu) << csh : 0u;
     const int nbits = cb ? csh + (span > 1u ? 32 - __clz((int) (span - 1u)) : 0) : 32;
-    // items per thread and the wave's chunk, so that a part-filled tile keeps
-    // all eight waves busy
+    const int npass = (nbits - 3 + MD_BITS - 1) / MD_BITS;
     const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
-    // ---- counting pass
-    const int sb = nbits - 3;
-    const int binshift = sb > MD_BINBITS ? nbits - MD_BINBITS : 3;
-    const u32 lowmask = sb > MD_BINBITS ? (1u << (binshift - 3)) - 1u : 0u;
-    for (int i = tid; i < MD_BINS / 2 + 8; i += MS_THREADS) s_binw[i] = 0;
-    lds_barrier();
+    u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
 #pragma unroll
     for (int j = 0; j < MS_ITEMS; j++) {
       const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
       if ((u32) j < items && e < cnt) {
-        key[j] -= base;
-        const u32 bin = key[j] >> binshift;
-        const u32 old = atomicAdd(&s_binw[bin >> 1], (bin & 1u) ? 65536u : 1u);
-        rk[j] = (bin & 1u) ? old >> 16 : old & 0xFFFFu;
+        key[j] = kin[(u64) td.begin + e] - base;
+        val[j] = pin[(u64) td.begin + e];
       } else {
-        key[j] = ~0u;
+        key[j] = ~0u;      // behind every entry, in every pass
         val[j] = 0;
       }
     }
-    lds_barrier();
-    {
-      // thread tid owns bins 16 tid .. 16 tid + 15: counts -> exclusive starts
-      uint4 q0 = reinterpret_cast<uint4 *>(s_binw)[2 * tid];
-      uint4 q1 = reinterpret_cast<uint4 *>(s_binw)[2 * tid + 1];
-      u32 wd[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-      u32 run = 0, mx = 0;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const u32 c0 = wd[k] & 0xFFFFu, c1 = wd[k] >> 16;
-        mx = c0 > mx ? c0 : mx;
-        mx = c1 > mx ? c1 : mx;
-        wd[k] = run | ((run + c0) << 16);
-        run += c0 + c1;
-      }
-      const u32 pre = ms_scan_excl(run, s_scan);
-#pragma unroll
-      for (int k = 0; k < 8; k++) wd[k] += pre * 0x10001u;
-      reinterpret_cast<uint4 *>(s_binw)[2 * tid] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
-      reinterpret_cast<uint4 *>(s_binw)[2 * tid + 1] = make_uint4(wd[4], wd[5], wd[6], wd[7]);
-      if (tid == 0) s_binw[MD_BINS / 2] = cnt;           // end of the last bin
-      if (mx > MD_BIN_LIMIT || force_radix) s_binw[MD_BINS / 2 + 1] = 1u;
-    }
-    lds_barrier();
-    const bool crowded = s_binw[MD_BINS / 2 + 1] != 0;     // the same for every thread
-    if (!crowded) {
+    for (int p = 0; p < npass; p++) {
+      const int shift = 3 + MD_BITS * p;
+      for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS)
+        reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+      lds_barrier();
 #pragma unroll
       for (int j = 0; j < MS_ITEMS; j++) {
-        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-        if ((u32) j < items && e < cnt) {
-          const u32 b0 = md_base(s_binw, key[j] >> binshift);
-          s_c[b0 + rk[j]] = (((key[j] >> 3) & lowmask) << 12) | e;
+        if ((u32) j < items) {
+          const u32 d = (key[j] >> shift) & (u32) (MD_RADIX - 1);
+          u32 intra, group;
+          ms_match<MD_BITS>(d, intra, group);
+          const u32 old = cnt_w[d];
+          if (intra == 0) cnt_w[d] = (u16) (old + group);
+          rk[j] = ((old + intra) << MD_BITS) | d;
+        }
+      }
+      lds_barrier();
+      {
+        u32 c[MS_WAVES];
+        u32 tot = 0;
+#pragma unroll
+        for (int i = 0; i < MS_WAVES; i++) {
+          c[i] = s_cnt[i * MD_RADIX + tid];
+          tot += c[i];
+        }
+        u32 dbase = ms_scan_excl(tot, s_scan);
+#pragma unroll
+        for (int i = 0; i < MS_WAVES; i++) {
+          s_cnt[i * MD_RADIX + tid] = (u16) dbase;
+          dbase += c[i];
         }
       }
       lds_barrier();
 #pragma unroll
       for (int j = 0; j < MS_ITEMS; j++) {
-        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-        if ((u32) j < items && e < cnt) {
-          const u32 bin = key[j] >> binshift;
-          const u32 b0 = md_base(s_binw, bin), b1 = md_base(s_binw, bin + 1u);
-          const u32 c = (((key[j] >> 3) & lowmask) << 12) | e;
-          // the first four bin mates in one go (a bin seldom has more), the
-          // rest one by one
-          const u32 last = b1 - 1u;
-          const u32 c0 = s_c[b0], c1 = s_c[b0 + 1u < last ? b0 + 1u : last],
-                    c2 = s_c[b0 + 2u < last ? b0 + 2u : last],
-                    c3 = s_c[b0 + 3u < last ? b0 + 3u : last];
-          u32 r = b0 + (c0 < c ? 1u : 0u);
-          r += (b0 + 1u < b1 && c1 < c) ? 1u : 0u;
-          r += (b0 + 2u < b1 && c2 < c) ? 1u : 0u;
-          r += (b0 + 3u < b1 && c3 < c) ? 1u : 0u;
-          for (u32 q = b0 + 4u; q < b1; q++) r += s_c[q] < c ? 1u : 0u;
-          rk[j] = r;
-        }
-      }
-      lds_barrier();   // s_c is read, its space is s_key again
-#pragma unroll
-      for (int j = 0; j < MS_ITEMS; j++) {
-        const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-        if ((u32) j < items && e < cnt) {
-          s_key[rk[j]] = key[j];
-          s_val[rk[j]] = val[j];
+        if ((u32) j < items) {
+          const u32 d = rk[j] & (u32) (MD_RADIX - 1);
+          const u32 pos = (u32) cnt_w[d] + (rk[j] >> MD_BITS);
+          s_key[pos] = key[j];
+          s_val[pos] = val[j];
         }
       }
       lds_barrier();
-    } else {
-      const int npass = (sb + MD_BITS - 1) / MD_BITS;
-      for (int p = 0; p < npass; p++) {
-        const int shift = 3 + MD_BITS * p;
-        lds_barrier();
-        for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS) s_binw[i] = 0;
-        lds_barrier();
+      if (p + 1 < npass) {
 #pragma unroll
         for (int j = 0; j < MS_ITEMS; j++) {
           if ((u32) j < items) {
-            const u32 d = (key[j] >> shift) & (u32) (MD_RADIX - 1);
-            u32 intra, group;
-            ms_match<MD_BITS>(d, intra, group);
-            const u32 old = cnt_w[d];
-            if (intra == 0) cnt_w[d] = (u16) (old + group);
-            rk[j] = ((old + intra) << MD_BITS) | d;
+            const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
+            key[j] = s_key[e];
+            val[j] = s_val[e];
           }
         }
         lds_barrier();
-        {
-          u32 c[MS_WAVES];
-          u32 tot = 0;
-#pragma unroll
-          for (int i = 0; i < MS_WAVES; i++) {
-            c[i] = s_cnt[i * MD_RADIX + tid];
-            tot += c[i];
-          }
-          u32 dbase = ms_scan_excl(tot, s_scan);
-#pragma unroll
-          for (int i = 0; i < MS_WAVES; i++) {
-            s_cnt[i * MD_RADIX + tid] = (u16) dbase;
-            dbase += c[i];
-          }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int j = 0; j < MS_ITEMS; j++) {
-          if ((u32) j < items) {
-            const u32 d = rk[j] & (u32) (MD_RADIX - 1);
-            const u32 pos = (u32) cnt_w[d] + (rk[j] >> MD_BITS);
-            s_key[pos] = key[j];
-            s_val[pos] = val[j];
-          }
-        }
-        lds_barrier();
-        if (p + 1 < npass) {
-#pragma unroll
-          for (int j = 0; j < MS_ITEMS; j++) {
-            if ((u32) j < items) {
-              const u32 e = (u32) w * wchunk + (u32) j * 64 + lane;
-              key[j] = s_key[e];
-              val[j] = s_val[e];
-            }
-          }
-        }
       }
     }
-    // the next run's entries are on their way while this one's tables go out
-    fetch(tdn);
     if (tid == 0) {
       o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
       o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
     }
-    msd_emit(s_key, s_val, cnt, td.begin, base, td.s16, false, 0ull, o, s_bits, acc);
-    t = tn;
-    td = tdn;
+    msd_emit(s_key, s_val, cnt, td.begin, base, false, 0u, o, s_bits, acc);
   }
   __syncthreads();
   msd_acc_flush(acc, o.stats);
@@ -1049,7 +1121,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
       x = sp; sp = dp; dp = x;
     }
     // the sorted run is in (sk, sp); table entries chunk by chunk
-    u64 prevkey = 0;
+    u32 prevkey = 0;
     for (u32 c0 = 0; c0 < cnt; c0 += (u32) MS_TILE) {
       const u32 valid = cnt - c0 < (u32) MS_TILE ? cnt - c0 : (u32) MS_TILE;
 #pragma unroll
@@ -1065,9 +1137,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
         if (c0 == 0) o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
         if (c0 + valid == cnt) o.lastkey[t] = msd_full(td.s16, s_key[valid - 1] + base);
       }
-      const u64 lastk = msd_full(td.s16, s_key[valid - 1] + base);
-      msd_emit(s_key, s_val, valid, (u64) td.begin + c0, base, td.s16, c0 > 0, prevkey, o,
-               s_bits, acc);
+      const u32 lastk = s_key[valid - 1] + base;
+      msd_emit(s_key, s_val, valid, (u64) td.begin + c0, base, c0 > 0, prevkey, o, s_bits, acc);
       prevkey = lastk;
     }
   }
@@ -1100,8 +1171,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_emit_run(
     if (c0 == 0) o.firstkey[t] = msd_full(s16, s_key[0]);
     if (c0 + valid == cnt) o.lastkey[t] = msd_full(s16, s_key[valid - 1]);
   }
-  const u64 prevkey = c0 > 0 ? msd_full(s16, kin[(u64) begin + c0 - 1]) : 0ull;
-  msd_emit(s_key, s_val, valid, (u64) begin + c0, 0u, s16, c0 > 0, prevkey, o, s_bits, acc);
+  const u32 prevkey = c0 > 0 ? kin[(u64) begin + c0 - 1] : 0u;
+  msd_emit(s_key, s_val, valid, (u64) begin + c0, 0u, c0 > 0, prevkey, o, s_bits, acc);
   msd_acc_flush(acc, o.stats);
 }
 

@@ -52,7 +52,12 @@ from genometools_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 JOB_BYTES_PER_BP = 10.25       # 0.25 text + 8 suf + 1 lcp + 1 bwt
-SCATTER_BYTES_PER_PAIR = 24.0  # 8+4 read, 8+4 written per radix pass
+SCATTER_BYTES_PER_PAIR = 24.0  # k_rs_scatter: 8+4 read, 8+4 written per pair and radix pass
+MSD_LOCAL_BYTES_PER_ENTRY = 22.125  # k_msd_local: K2 + position read; suf 8, position 4,
+                                    # lcp 1, bwt 1, tie bit 1/8 written
+DOMINANT = {0: ("k_rs_scatter (radix scatter pass of the LSD sort)", SCATTER_BYTES_PER_PAIR),
+            1: ("k_msd_local (last level of the MSD sort: LDS sort of a run + table emission)",
+                MSD_LOCAL_BYTES_PER_ENTRY)}
 
 
 def cpu_baseline(model, seed, sample_n):
@@ -147,6 +152,8 @@ def main():
         tm = eng.timing()
         sc_ms += tm["scatter_ms"]
         sc_launches += tm["scatter_launches"]
+        dominant = tm["dominant_kernel"]
+        items_per_launch = tm["scatter_items"]
         total_dev_ms += tm["total_ms"]
     barrier()
     dt = time.perf_counter() - t0
@@ -167,25 +174,28 @@ def main():
         pairs_per_launch = float(t[2].item()) / world
         exchanged = float(t[3].item())
     else:
-        pairs_per_launch = float(n + 1)
+        pairs_per_launch = float(items_per_launch)
         exchanged = 0.0
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = n / (dt / a.steps) / 1e9
         sc_avg_s = sc_ms / max(sc_launches, 1) / 1e3
-        achieved = SCATTER_BYTES_PER_PAIR * pairs_per_launch / sc_avg_s / 1e9
-        # PMC traffic of the scatter kernel: only a measurement of THIS kernel
-        # source counts (tools/pmc_summary.py stamps the file with its hash)
+        kernel_name, kernel_bytes = DOMINANT[dominant]
+        achieved = kernel_bytes * pairs_per_launch / sc_avg_s / 1e9
+        # PMC traffic of that kernel: only a measurement of THIS kernel source
+        # counts (tools/pmc_summary.py stamps the file with the source's hash)
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and world == 1:
             with open(tf) as f:
                 tj = json.load(f)
-            with open(os.path.join(ROOT, "genometools_amd", "csrc", "esa_prims.hip"), "rb") as f:
+            srcfile = os.path.join(ROOT, "genometools_amd", "csrc", tj.get("kernel_source", "esa_prims.hip"))
+            with open(srcfile, "rb") as f:
                 src = hashlib.sha256(f.read()).hexdigest()
             if (tj.get("n") == n and tj.get("model") == a.model
+                    and kernel_name.startswith(tj.get("kernel", "?"))
                     and tj.get("kernel_source_sha256") == src):
-                traffic = tj.get("scatter_hbm_bytes_per_launch")
+                traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": "Gbp/s ESA build (suf+lcp+bwt), 3 Gbp DNA, 1/2/4/8 MI355X; bit-exact vs CPU",
             "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": a.steps,
@@ -208,7 +218,7 @@ def main():
                        "refine_rounds": st["refine_rounds"],
                        "largelcpvalues": st["largelcpvalues"],
                        "maxbranchdepth": st["maxbranchdepth"]},
-            "roofline": {"bound": "hbm", "kernel": "k_rs_scatter (radix scatter pass)",
+            "roofline": {"bound": "hbm", "kernel": kernel_name,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": sc_avg_s * 1e3,

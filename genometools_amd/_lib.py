@@ -64,7 +64,8 @@ class EsaTiming(ctypes.Structure):
                 ("comm_ms", ctypes.c_float),
                 ("comm_calls", ctypes.c_uint32),
                 ("comm_bytes", ctypes.c_uint64),
-                ("alloc_ms", ctypes.c_float)]
+                ("alloc_ms", ctypes.c_float),
+                ("dominant_kernel", ctypes.c_uint32)]
 
 
 class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd_encode.h

@@ -3037,7 +3037,7 @@ static int msd_level_prepare(gtamd_esa_ctx *c, const MsdWs &w, const u32 *pstart
 // k_finalize): *sa_out holds the positions in suffix order, (*fkey, *fval) are
 // free buffers of 8 / 4 bytes per entry, the tie bitmap and stats->numties are set
 static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_out,
-                         u64 **fkey, u32 **fval) {
+                         u64 **fkey, u32 **fval, u64 *local_entries) {
   const u64 N = c->N;
   hipStream_t st = c->st;
   const int cb = msd_cbits(N);
@@ -3123,9 +3123,11 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
     // (GTAMD_MSD_RADIX=1: every run takes the LSD passes a run with a crowded
     // bin of the counting pass is left to; tests)
     const char *fr = getenv("GTAMD_MSD_RADIX");
+    HIP_TRY(hipEventRecord(c->ev_scatter[0], st));
     k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
                                                         fr != nullptr && fr[0] == '1', w.crowdlist,
                                                         w.counters, o);
+    HIP_TRY(hipEventRecord(c->ev_scatter[1], st));
     HIP_TRY(hipGetLastError());
     k_msd_local_radix<<<ntD < 2048u ? ntD : 2048u, MS_THREADS, 0, st>>>(kf, pf, w.dtiles,
                                                                         w.crowdlist, w.counters,
@@ -3156,6 +3158,7 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   *sa_out = pf;
   *fkey = reinterpret_cast<u64 *>(ko);
   *fval = po;
+  *local_entries = N - nbigentries;
   return 0;
 }
 
@@ -3209,7 +3212,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // GTAMD_MSD=1 the MSD sort at any size (tests; by default from 2^24 entries)
   bool msd = false;
   u32 *msd_sa = nullptr, *msd_fval = nullptr;
-  u64 *msd_fkey = nullptr;
+  u64 *msd_fkey = nullptr, msd_local = 0;
   if (!dist && BITS == 2 && !WIDE && !(want & GTAMD_WANT_BCK) && N >= 64) {
     const char *e = getenv("GTAMD_MSD");
     msd = e != nullptr ? e[0] == '1' : N >= (1ull << 24);
@@ -3220,7 +3223,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     HIP_TRY(hipEventRecord(c->ev[0], st));
     const char *fz = getenv("GTAMD_FUSED_PASS0");
     if (msd) {
-      TRY(msd_sort_emit(c, want, prefixlength, &msd_sa, &msd_fkey, &msd_fval));
+      TRY(msd_sort_emit(c, want, prefixlength, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
       HIP_TRY(hipEventRecord(c->ev_emitted, st));   // (what the joins below wait for)
     } else if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
@@ -4294,9 +4297,14 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     HIP_TRY(hipEventElapsedTime(&ms, c->ev_scatter[2 * i], c->ev_scatter[2 * i + 1]));
     sc += ms;
   }
+  if (msd && msd_local > 0) {
+    HIP_TRY(hipEventElapsedTime(&sc, c->ev_scatter[0], c->ev_scatter[1]));
+    nev = 1;
+  }
   c->timing.scatter_ms = sc;
   c->timing.scatter_launches = (u32) nev;
-  c->timing.scatter_items = NL;
+  c->timing.scatter_items = msd ? msd_local : NL;
+  c->timing.dominant_kernel = msd ? 1u : 0u;
   c->timing.alloc_ms = c->alloc_ms;
   c->want = want;
   c->ran = true;

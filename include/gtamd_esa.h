@@ -84,9 +84,14 @@ typedef struct {
   float finalize_ms;   /* SA widening + LCP/BWT emission + tie detection */
   float refine_ms;     /* prefix-doubling rounds incl. rank table build */
   float tie_fix_ms;    /* LCP/BWT of tied suffixes + .llv */
-  float scatter_ms;    /* sum over the downsweep (scatter) kernel launches */
+  /* the dominant kernel of the first sort, timed with its own event pairs:
+     dominant_kernel 0 = k_rs_scatter (a radix pass of the LSD sort: 8 + 4 bytes
+     read and written per pair), 1 = k_msd_local (last level of the MSD sort of
+     a DNA whole-table build: sorts a run in LDS and writes the tables; 8 bytes
+     read, 8 + 4 + 1 + 1 written per entry) */
+  float scatter_ms;    /* sum over the launches of that kernel */
   uint32_t scatter_launches;
-  uint64_t scatter_items;  /* elements moved per launch (first sort) */
+  uint64_t scatter_items;  /* pairs / entries per launch */
   /* part builds: host time spent inside the collective callbacks (waiting for
      the other parts included), their number, and the bytes this part sent */
   float comm_ms;
@@ -96,6 +101,7 @@ typedef struct {
      allocated by the first run that needs it: a cold run pays seconds for
      ~140 GB at 3 Gbp, the following runs on the context nothing) */
   float alloc_ms;
+  uint32_t dominant_kernel;
 } gtamd_esa_timing;
 
 typedef struct gtamd_esa_ctx gtamd_esa_ctx;

@@ -2,7 +2,7 @@
 (genometools_amd/csrc/esa_msd.h): keygen fused with level A, two ragged-tile
 levels, the LDS sort that also emits the tables, the one-workgroup path for
 oversize runs and the device-wide path for giant ones.  By default the engine
-takes it from 2^24 entries; GTAMD_MSD=1 takes it at any size, so that all of it
+takes it from 2^25 entries; GTAMD_MSD=1 takes it at any size, so that all of it
 is checked bit for bit against the oracle and the reference's fixtures, and at
 sizes the oracle cannot reach against the LSD sort (GTAMD_MSD=0)."""
 import hashlib

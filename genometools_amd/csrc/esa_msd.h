@@ -360,10 +360,30 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_hist_lvl(
   if (t < tiles_ub) {
     const MsTile d = desc[t];
     const u32 valid = d.segvalid & 0x1FFFu;
+    // 16-byte loads from the first entry whose index is a multiple of four (the
+    // order inside the tile does not matter to a histogram); the up to three
+    // entries in front of it and behind the last whole quad one by one
+    u32 head = (4u - (d.start & 3u)) & 3u;
+    head = head < valid ? head : valid;
+    const u32 nq = (valid - head) >> 2, tail = valid - head - 4u * nq;
+    const u32 *kp = keys + d.start;
+    uint4 q[2];
 #pragma unroll
-    for (int j = 0; j < MS_ITEMS; j++) {
-      const u32 e = (u32) j * MS_THREADS + tid;
-      if (e < valid) atomicAdd(&h[w][keys[(u64) d.start + e] >> dsh], 1u);
+    for (int j = 0; j < 2; j++) {
+      const u32 i = (u32) j * MS_THREADS + tid;
+      if (i < nq) q[j] = *reinterpret_cast<const uint4 *>(kp + head + 4u * i);
+    }
+    if ((u32) tid < head) atomicAdd(&h[w][kp[tid] >> dsh], 1u);
+    if ((u32) tid < tail) atomicAdd(&h[w][kp[head + 4u * nq + tid] >> dsh], 1u);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const u32 i = (u32) j * MS_THREADS + tid;
+      if (i < nq) {
+        atomicAdd(&h[w][q[j].x >> dsh], 1u);
+        atomicAdd(&h[w][q[j].y >> dsh], 1u);
+        atomicAdd(&h[w][q[j].z >> dsh], 1u);
+        atomicAdd(&h[w][q[j].w >> dsh], 1u);
+      }
     }
   }
   __syncthreads();
@@ -727,7 +747,7 @@ static_assert(MD_RADIX == MS_THREADS, "one thread per digit in the scan");
 // (three or four 9-bit digits, ballot-ranked like the scatter kernels).
 constexpr int MD_BINBITS = 12;
 constexpr int MD_BINS = 1 << MD_BINBITS;
-constexpr u32 MD_BIN_LIMIT = 32;
+constexpr u32 MD_BIN_LIMIT = 128;
 
 __device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
   return (s_binw[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu;

@@ -2,6 +2,7 @@
 """Differential fuzzing on the GPU box: random structured sequences (repeats,
 tandem repeats, special runs, separators; DNA and protein) through
   * the engine (all tables + bucket table, random prefix length),
+  * DNA: the same build through the MSD first sort (forced, random depth),
   * a part build with 2..5 parts (thread transport on one device),
   * the device FASTA reader (random line widths, CRLF, blank lines),
 each compared with the CPU oracle / host reader.  Dev tool; stops at the first
@@ -85,6 +86,29 @@ def check_engine(rng, enc, sigma):
         assert res.stats["largelcpvalues"] == ora["stats"]["largelcpvalues"]
         assert res.stats["maxbranchdepth"] == ora["stats"]["maxbranchdepth"]
     return ora
+
+
+def check_msd(rng, enc, ora):
+    """the most-significant-digit-first sort of big DNA builds (esa_msd.h), forced
+    at this size, with a random depth of level C, a random limit of the
+    one-workgroup path and, one case in four, the LDS radix fallback in every run"""
+    env = {"GTAMD_MSD": "1", "GTAMD_MSD_CBITS": str(int(rng.integers(0, 9))),
+           "GTAMD_MSD_BIG_MAX": str(int(rng.choice([4096, 8192, 524288]))),
+           "GTAMD_MSD_RADIX": "1" if rng.integers(0, 4) == 0 else "0"}
+    os.environ.update(env)
+    try:
+        with esa.EsaEngine(enc.size, 4) as eng:
+            eng.set_sequence(enc)
+            eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT)
+            res = eng.result()
+            for name in ("suf", "lcp", "llv", "bwt"):
+                assert np.array_equal(getattr(res, name), ora[name]), "msd %s %s" % (name, env)
+            for k in ("longest", "largelcpvalues", "maxbranchdepth"):
+                assert res.stats[k] == ora["stats"][k], "msd %s %s" % (k, env)
+            assert res.stats["lcptabsum"] == int(ora["stats"]["lcptabsum"]), "msd lcptabsum %s" % env
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
 
 
 def check_parts(rng, enc, sigma, ora):
@@ -173,6 +197,8 @@ def main():
                 os.environ.pop("GTAMD_FORCE_WIDE", None)
             try:
                 ora = check_engine(rng, enc, sigma)
+                if sigma == 4 and case % 7 != 3 and enc.size >= 64:
+                    check_msd(rng, enc, ora)
                 if case % 3 == 0:
                     check_parts(rng, enc, sigma, ora)
                 if enc.size <= 20000 and case % 2 == 0:

@@ -104,6 +104,18 @@ __device__ __forceinline__ void dna_keys8(const Text &t, u64 p0, u64 (&key)[KP_P
     const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
     pay = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
   }
+  // no special among the KP_PER + SYMS - 1 positions the keys look at (all but
+  // the stretches around wildcard runs and sequence ends): a key is its window
+  // and the symbol in front of it
+  if ((S & ((1ull << (KP_PER + SYMS - 1)) - 1ull)) == 0) {
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) {
+      const u64 win = g ? (a_hi << (2 * g)) | (a_lo >> (64 - 2 * g)) : a_hi;
+      key[g] = (win & (~0ull << K::LOW_BITS)) | pay;
+      pay = (u32) (win >> 62);
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < KP_PER; g++) {
     const u64 win = g ? (a_hi << (2 * g)) | (a_lo >> (64 - 2 * g)) : a_hi;

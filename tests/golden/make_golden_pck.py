@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden_pck.json from the REFERENCE itself (run in the
+dev container).
+
+For fixtures of the reference's packed-index tests
+(testsuite/gt_packedindex_include.rb:67-127: the "simple sequences", the protein
+sample with -bsize 1) and some more of its suffixerator fixtures this builds
+the suffix-array project with oracle/_ref/gt_ref_sfx and then INDEX.bdx with
+oracle/_ref/gt_ref_pck -- the reference's `gt packedindex trsuftab`
+construction (src/match/eis-bwtseq-construct.c:64-92) compiled from
+/root/reference by oracle/Makefile.ref -- for several option sets, and stores
+md5 + size of every INDEX.bdx.  Only data is stored: the inputs are the
+fixtures already under tests/golden/fixtures, the outputs are digests.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SFX = os.path.join(ROOT, "oracle", "_ref", "gt_ref_sfx")
+PCK = os.path.join(ROOT, "oracle", "_ref", "gt_ref_pck")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# (bsize, blbuck, locfreq, locbitmap: None = option not given)
+OPTION_SETS = [
+    (8, 8, 16, None),      # the tool's defaults: locate information as counts
+    (8, 8, 16, True),      # -locbitmap yes
+    (8, 8, 16, False),
+    (8, 8, 0, None),       # -locfreq 0 (testsuite: "w/o locate")
+    (4, 4, 8, None),
+    (3, 5, 7, True),
+    (5, 2, 1, False),
+    (1, 3, 4, None),
+    (2, 1, 3, True),
+    (10, 3, 32, None),
+    (8, 8, 1, True),
+    (6, 7, 1000000, None),
+]
+DNA = ["RandomN.fna", "Random.fna", "Atinsert.fna", "TTT-small.fna",
+       "trna_glutamine.fna", "Random-Small.fna", "Duplicate.fna", "TTTN.fna",
+       "Verysmall.fna", "Small.fna", "Smalldup.fna", "Reads1.fna",
+       "Random159.fna", "Random160.fna", "Copysorttest.fna",
+       "Atinsert_seqrange_3-7.fna", "Arabidopsis-C99826.fna",
+       "extra/starts_ends_special.fna", "extra/long_runs.fna"]
+PROTEIN = [("sw100K2.fsa", [(1, 8, 16, None), (2, 8, 16, None), (2, 3, 5, True), (1, 1, 0, None)]),
+           ("extra/protein_specials.faa", [(1, 8, 16, None), (2, 4, 3, False), (3, 2, 16, True)])]
+
+
+def md5(path):
+    with open(path, "rb") as f:
+        return hashlib.md5(f.read()).hexdigest()
+
+
+def key(name, opts):
+    b, k, f, bm = opts
+    return "%s|bsize=%d|blbuck=%d|locfreq=%d|locbitmap=%s" % (
+        name, b, k, f, {None: "auto", True: "yes", False: "no"}[bm])
+
+
+def run_case(tmp, name, protein, opts):
+    src = os.path.join(OUT, "fixtures", name) if not name.startswith("extra/") \
+        else os.path.join(OUT, name)
+    idx = os.path.join(tmp, "idx")
+    for f in os.listdir(tmp):
+        os.unlink(os.path.join(tmp, f))
+    subprocess.run([SFX, "-protein" if protein else "-dna", "-suf", "-bwt", "-db", src,
+                    "-indexname", idx], check=True, stdout=subprocess.DEVNULL)
+    b, k, f, bm = opts
+    cmd = [PCK, "-bsize", str(b), "-blbuck", str(k), "-locfreq", str(f)]
+    if bm is not None:
+        cmd += ["-locbitmap", "yes" if bm else "no"]
+    out = subprocess.run(cmd + [idx], check=True, capture_output=True, text=True).stdout
+    toggles = int(out.split("featureToggles=")[1].split()[0])
+    return {"md5": md5(idx + ".bdx"), "size": os.path.getsize(idx + ".bdx"),
+            "featureToggles": toggles}
+
+
+def main():
+    golden = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in DNA:
+            sets = OPTION_SETS if name in ("Atinsert.fna", "Duplicate.fna", "RandomN.fna",
+                                           "TTTN.fna", "Verysmall.fna",
+                                           "extra/starts_ends_special.fna") \
+                else OPTION_SETS[:4]
+            for opts in sets:
+                golden[key(name, opts)] = run_case(tmp, name, False, opts)
+        for name, sets in PROTEIN:
+            for opts in sets:
+                golden[key(name, opts)] = run_case(tmp, name, True, opts)
+    with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
+        json.dump(golden, f, indent=1, sort_keys=True)
+    print("%d packed-index goldens" % len(golden))
+
+
+if __name__ == "__main__":
+    main()

@@ -34,12 +34,18 @@ class EsaStats(ctypes.Structure):
                 ("prefixlength", ctypes.c_uint32)]
 
 
+class PckParams(ctypes.Structure):
+    _fields_ = [("block_size", ctypes.c_uint), ("bucket_blocks", ctypes.c_uint),
+                ("locate_interval", ctypes.c_uint), ("feature_toggles", ctypes.c_int)]
+
+
 _lib = None
 
 
 def build():
     src = [os.path.join(ORACLE_DIR, f) for f in
-           ("esa_oracle.c", "esa_oracle.h", "esa_oracle_main.c")]
+           ("esa_oracle.c", "esa_oracle.h", "esa_oracle_main.c", "pck_oracle.c",
+            "pck_oracle.h")]
     if (not os.path.exists(ORACLE_LIB) or not os.path.exists(ORACLE_CLI) or
             any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in src)):
         subprocess.run(["make", "-C", ORACLE_DIR], check=True,
@@ -68,6 +74,11 @@ def lib():
         L.ora_esastats_compute.argtypes = [P, U64, P, P, U32,
                                            ctypes.POINTER(EsaStats)]
         L.ora_check_suffix_array.argtypes = [P, U64, P, ctypes.POINTER(U64)]
+        L.ora_pck_default_toggles.argtypes = [ctypes.c_uint, ctypes.c_uint, ctypes.c_uint,
+                                              ctypes.c_int]
+        L.ora_pck_bdx.argtypes = [P, P, P, U64, ctypes.c_uint, U64, ctypes.POINTER(PckParams),
+                                  ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]
+        L.ora_pck_free.argtypes = [P]
         _lib = L
     return _lib
 
@@ -198,3 +209,41 @@ def fixture_path(name):
     if name.startswith("extra/"):
         return os.path.join(GOLDEN_DIR, name)
     return os.path.join(GOLDEN_DIR, "fixtures", name)
+
+
+def pck_default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None):
+    """feature toggles `gt packedindex` derives from its options"""
+    return lib().ora_pck_default_toggles(bsize, blbuck, locfreq,
+                                         -1 if locbitmap is None else int(locbitmap))
+
+
+def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=None):
+    """bytes of INDEX.bdx (`gt packedindex trsuftab`) by the oracle's restatement"""
+    L = lib()
+    enc = np.ascontiguousarray(enc, dtype=np.uint8)
+    suf = np.ascontiguousarray(suf, dtype=np.uint64)
+    bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
+    longest = int(np.flatnonzero(suf == 0)[0])
+    pp = PckParams(bsize, blbuck, locfreq, pck_default_toggles(bsize, blbuck, locfreq, locbitmap))
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    rc = L.ora_pck_bdx(_p(bwt), _p(suf), _p(enc), enc.size + 1, numofchars, longest,
+                       ctypes.byref(pp), ctypes.byref(out), ctypes.byref(n))
+    if rc != 0:
+        raise ValueError("ora_pck_bdx: %d" % rc)
+    raw = ctypes.string_at(out, n.value)
+    L.ora_pck_free(out)
+    return raw
+
+
+def golden_pck():
+    with open(os.path.join(GOLDEN_DIR, "golden_pck.json")) as f:
+        return json.load(f)
+
+
+def parse_pck_key(key):
+    """'name|bsize=..|blbuck=..|locfreq=..|locbitmap=auto' -> (name, kwargs)"""
+    parts = key.split("|")
+    kw = dict(p.split("=") for p in parts[1:])
+    return parts[0], dict(bsize=int(kw["bsize"]), blbuck=int(kw["blbuck"]),
+                          locfreq=int(kw["locfreq"]),
+                          locbitmap={"auto": None, "yes": True, "no": False}[kw["locbitmap"]])

@@ -12,9 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in
-           ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip", "esa_encode.hip")]
+           ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip", "esa_encode.hip",
+            "esa_pck.hip")]
 HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h")] + \
-          [os.path.join(ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h")]
+          [os.path.join(ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h", "gtamd_pck.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -85,7 +86,19 @@ class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd
                 ("originaldistribution", ctypes.c_uint64 * 256)]
 
 
-# every symbol include/gtamd_esa.h and include/gtamd_encode.h declare:
+class PckParams(ctypes.Structure):       # gtamd_pck_params, include/gtamd_pck.h
+    _fields_ = [("block_size", ctypes.c_uint32), ("bucket_blocks", ctypes.c_uint32),
+                ("locate_interval", ctypes.c_uint32), ("feature_toggles", ctypes.c_int32)]
+
+
+class PckInfo(ctypes.Structure):         # gtamd_pck_info
+    _fields_ = [(name, ctypes.c_uint64) for name in
+                ("file_bytes", "cw_data_pos", "var_data_pos", "range_enc_pos",
+                 "num_buckets", "num_regions", "var_bits")] + \
+               [("cw_bits", ctypes.c_uint32), ("build_ms", ctypes.c_float)]
+
+
+# every symbol include/gtamd_esa.h, gtamd_encode.h and gtamd_pck.h declare:
 # (restype, argtypes)
 _P = ctypes.c_void_p
 _U64 = ctypes.c_uint64
@@ -139,6 +152,15 @@ ABI = {
                                         ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(_U64)]),
+    # include/gtamd_pck.h
+    "gtamd_pck_default_toggles": (_INT, [_U32, _U32, _U32, _INT]),
+    "gtamd_pck_create": (_P, [_INT]),
+    "gtamd_pck_destroy": (None, [_P]),
+    "gtamd_pck_build": (_INT, [_P, _P, _P, _U64, _U32, _U64, ctypes.POINTER(PckParams)]),
+    "gtamd_pck_build_from_esa": (_INT, [_P, _P, ctypes.POINTER(PckParams)]),
+    "gtamd_pck_get_info": (_INT, [_P, ctypes.POINTER(PckInfo)]),
+    "gtamd_pck_image_device": (_P, [_P]),
+    "gtamd_pck_image_copy": (_INT, [_P, _P, _U64, _U64]),
 }
 
 _lib = None

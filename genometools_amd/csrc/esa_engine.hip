@@ -4390,6 +4390,13 @@ extern "C" int gtamd_esa_table_copy(gtamd_esa_ctx *c, gtamd_table which,
                     hipMemcpyDeviceToHost));
   return 0;
 }
+// for the consumers inside the library (esa_pck.hip): where the tables live
+extern "C" int gtamd_esa_internal_info(const gtamd_esa_ctx *c, int *device, u32 *sigma,
+                                       u32 *numparts) {
+  if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
+  *device = c->device; *sigma = c->sigma; *numparts = c->numparts;
+  return 0;
+}
 extern "C" int gtamd_esa_get_stats(const gtamd_esa_ctx *c, gtamd_esa_stats *s) {
   if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
   *s = c->stats;

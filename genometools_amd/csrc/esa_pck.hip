@@ -1,0 +1,799 @@
+// esa_pck.hip -- the packed index of `gt packedindex` (INDEX.bdx) assembled on
+// the device from the resident BWT and suffix array (C ABI: include/gtamd_pck.h).
+//
+// File layout (src/match/eis-blockcomp.c:1888-2094, restated in DESIGN.md 9a):
+//   header | ext header (locate) | zeros up to 8192 | cw records of all buckets,
+//   one bit string | var parts of all buckets, one bit string | region list
+// A bucket covers L = blockSize x bucketBlocks positions of the BWT.  Its
+// constant-width record: number of occurrences of every letter before the
+// bucket, bit offset of its var part, bits of its permutation indices, the
+// composition index of each block, [one locate bit per position]; its var part:
+// the permutation index of each block (as many bits as its composition needs),
+// then the locate marks: [count, (position in bucket,] text position [)]...
+//
+// Two passes over the tables (tiles of <= 256 buckets, one thread per bucket):
+// k_pck_tile<false> counts per tile (letters, var bits, region starts/ends),
+// one small scan, k_pck_tile<true> recomputes the tile and writes every field
+// with atomicOr into the zeroed image (bit strings are most significant bit
+// first, so a field is OR-ed into byte-swapped 64-bit words).  Block -> index
+// pair through a table of sigma^blockSize entries built once per geometry.
+// The few bits the reference's staging buffers leave stale in the file (in the
+// last bucket only) are reproduced by the host from the image's own tail.
+#include <algorithm>
+#include <vector>
+#include "esa_common.h"
+#include "esa_devutil.h"
+#include "../../include/gtamd_pck.h"
+
+// from esa_engine.hip
+extern "C" int gtamd_esa_internal_info(const gtamd_esa_ctx *c, int *device, u32 *sigma,
+                                       u32 *numparts);
+
+namespace {
+
+constexpr int PCK_THREADS = 256;
+constexpr u32 PCK_TILE_POS = 16384;     // positions a tile stages in LDS at most
+constexpr u32 PCK_MAX_SIGMA = 30;
+constexpr u32 PCK_EXTRA_COLS = 3;       // var bits, region starts, region ends
+constexpr u32 LDS_SPECIAL = 30;         // LDS code of the wildcard; separator 31
+constexpr u32 LDS_MARK = 0x40;
+
+// gt_requiredUInt64Bits, src/core/bitpackstringop.c:60-79
+__host__ __device__ inline u32 reqbits(u64 v) {
+  u32 r = 1;
+  while (v >>= 1) r++;
+  return r;
+}
+
+struct PckGeom {
+  u64 N;                 // entries of the tables
+  u64 nb;                // buckets
+  u64 first_special_row; // rows from here on hold suffixes that start with a special
+  u64 cw_base_bit, var_base_bit;  // bit positions in the image
+  u64 lut_entries;       // sigma^B, 0: indices are computed, not looked up
+  u32 sigma, B, K, L, LP;
+  u32 T, ntiles;
+  u32 locint, locmask, loc_pow2, loc_bitmap, loc_count;
+  u32 comp_idx_bits, var_off_bits, cb_off_bits, bits_orig_pos;
+  u32 cw_bits, pre_var_idx, pre_cb_off, pre_comp_idx, pre_cw_ext;
+  u32 sym_bits[PCK_MAX_SIGMA + 2], sym_off[PCK_MAX_SIGMA + 2];
+};
+
+// ---- block -> (composition index, permutation index, bits) -------------------
+__host__ __device__ inline u64 binom(u32 n, u32 k) {
+  if (k > n) return 0;
+  if (k > n - k) k = n - k;
+  u64 r = 1;
+  for (u32 i = 1; i <= k; i++) r = r * (n - k + i) / i;
+  return r;
+}
+__host__ __device__ inline u64 factorial(u32 n) {
+  u64 r = 1;
+  while (n > 1) r *= n--;
+  return r;
+}
+__host__ __device__ inline u64 arrangements(const u32 *cnt, u32 sigma, u32 total) {
+  u64 r = factorial(total);
+  for (u32 s = 0; s < sigma; s++) r /= factorial(cnt[s]);
+  return r;
+}
+// index of the composition in ascending order of (count of letter 0, count of
+// letter 1, ...), src/match/eis-seqblocktranslate.c:156-246
+__host__ __device__ inline u64 composition_index(const u32 *cnt, u32 sigma, u32 B) {
+  u64 r = 0;
+  u32 left = B;
+  for (u32 i = 0; i + 1 < sigma; i++) {
+    const u32 k = sigma - i - 1;
+    for (u32 v = 0; v < cnt[i]; v++) r += binom(left - v + k - 1, k - 1);
+    left -= cnt[i];
+  }
+  return r;
+}
+// packed result: permutation index (bits 0..39) | composition index (40..57) |
+// bits of the permutation index (58..63)
+__host__ __device__ inline u64 pack_indices(u64 perm, u64 comp, u32 pbits) {
+  return perm | (comp << 40) | ((u64) pbits << 58);
+}
+// symbols of a block (letters only) -> packed indices; cnt is scratch for sigma counters
+__device__ inline u64 block_indices(const u8 *sym, u32 sigma, u32 B, u32 *cnt) {
+  for (u32 s = 0; s < sigma; s++) cnt[s] = 0;
+  for (u32 i = 0; i < B; i++) cnt[sym[i]]++;
+  const u64 comp = composition_index(cnt, sigma, B);
+  u64 m = arrangements(cnt, sigma, B);
+  const u32 pbits = m > 1 ? reqbits(m - 1) : 0;
+  // rank of the block among the arrangements of its multiset: of the m
+  // arrangements of what is left, m * cnt[s] / left start with letter s
+  u64 perm = 0;
+  u32 left = B;
+  for (u32 i = 0; i < B && m > 1; i++) {
+    u32 below = 0;
+    for (u32 s = 0; s < sym[i]; s++) below += cnt[s];
+    perm += m * below / left;
+    m = m * cnt[sym[i]] / left;
+    cnt[sym[i]]--;
+    left--;
+  }
+  return pack_indices(perm, comp, pbits);
+}
+
+__global__ void k_pck_lut(u64 entries, u32 sigma, u32 B, u64 *lut) {
+  const u64 idx = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= entries) return;
+  u8 sym[16];
+  u32 cnt[PCK_MAX_SIGMA + 2];
+  u64 v = idx;
+  for (int i = (int) B - 1; i >= 0; i--) { sym[i] = (u8) (v % sigma); v /= sigma; }
+  lut[idx] = block_indices(sym, sigma, B, cnt);
+}
+
+// ---- bit strings, most significant bit first ---------------------------------
+__device__ __forceinline__ void put_bits(u64 *img, u64 bit, u32 nbits, u64 v) {
+  if (nbits == 0) return;
+  const u64 w = bit >> 6;
+  const u32 o = (u32) (bit & 63);
+  if (o + nbits <= 64) {
+    const u64 x = v << (64 - o - nbits);
+    if (x) atomicOr((unsigned long long *) &img[w], (unsigned long long) __builtin_bswap64(x));
+  } else {
+    const u32 r = o + nbits - 64;
+    const u64 hi = v >> r, lo = v << (64 - r);
+    if (hi) atomicOr((unsigned long long *) &img[w], (unsigned long long) __builtin_bswap64(hi));
+    if (lo) atomicOr((unsigned long long *) &img[w + 1], (unsigned long long) __builtin_bswap64(lo));
+  }
+}
+
+__global__ void k_pck_count_specials(const u8 *bwt, u64 N, unsigned long long *out) {
+  __shared__ u32 s4[4];
+  u32 c = 0;
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64) gridDim.x * blockDim.x)
+    c += bwt[i] >= 254;
+  u32 tot;
+  (void) block_scan_excl_sum(c, &tot, s4);
+  if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long) tot);
+}
+
+// ---- the tile kernel -----------------------------------------------------------
+// tile_tot: (sigma + 3) columns of ntiles u64: COUNT writes the tile's totals,
+// the scan turns each column into exclusive prefixes, EMIT reads them.
+template <bool EMIT>
+__global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
+    PckGeom g, const u8 *__restrict__ bwt, const u64 *__restrict__ suf,
+    const u64 *__restrict__ lut, u64 *tile_tot, u64 *img, u64 *rstart, u64 *rend) {
+  extern __shared__ u8 smem[];
+  __shared__ u32 s4[4];
+  const u32 tid = threadIdx.x;
+  const u64 tile = blockIdx.x;
+  const u64 b0 = tile * g.T;                               // first bucket of the tile
+  const u32 nbk = (u32) min((u64) g.T, g.nb - b0);         // buckets in this tile
+  const u64 p0 = b0 * g.L;                                 // first position
+  const u32 npos = (u32) min((u64) nbk * g.L, g.N > p0 ? g.N - p0 : 0);
+  u8 *s_sym = smem;                                        // [T][LP]
+  u16 *s_cnt = (u16 *) (smem + (((size_t) g.T * g.LP + 15) & ~(size_t) 15));  // [sigma][T]
+
+  // stage the symbols (and the locate marks) of the tile, bucket-major with an
+  // odd word stride; positions behind the end read as letter 0 (the fill of the
+  // last block, eis-blockcomp.c:587-589)
+  for (u32 i = tid; i < nbk * g.L; i += PCK_THREADS) {
+    u32 code = 0;
+    if (i < npos) {
+      const u64 p = p0 + i;
+      const u32 c = bwt[p];
+      code = c >= 254 ? LDS_SPECIAL + (c - 254) : c;
+      if (g.locint) {
+        // addLocateInfo, eis-bwtseq-extinfo.c:420-441: every locint-th text
+        // position, and the positions where letters and specials meet
+        // (isSortModeTransition :343-382): the symbol before the suffix is the
+        // BWT symbol, the suffix starts with a special iff its row lies in the
+        // tail of the table
+        const u64 v = suf[p];
+        const bool hit = g.loc_pow2 ? (v & g.locmask) == 0 : (v % g.locint) == 0;
+        const bool tr = (c >= 254) != (p >= g.first_special_row);
+        if (hit || tr) code |= LDS_MARK;
+      }
+    }
+    s_sym[(i / g.L) * g.LP + i % g.L] = (u8) code;
+  }
+  for (u32 i = tid; i < g.sigma * g.T; i += PCK_THREADS) s_cnt[i] = 0;
+  __syncthreads();
+
+  // one thread per bucket
+  const bool live = tid < nbk;
+  const u64 bucket = b0 + tid;
+  const u64 bpos = bucket * g.L;
+  const u32 len = live ? (u32) min((u64) g.L, g.N > bpos ? g.N - bpos : 0) : 0;
+  const u32 nblk = (len + g.B - 1) / g.B;
+  const u8 *mine = s_sym + (size_t) tid * g.LP;
+  u32 pbits_sum = 0, nmarks = 0, nstart = 0, nend = 0;
+  if (live) {
+    // symbol before / behind the bucket (region borders)
+    u32 prev = 0xff, next = 0xff;
+    if (bpos > 0) prev = tid > 0 ? (mine[-(int) g.LP + (int) g.L - 1] & 63u)
+                                 : (bwt[bpos - 1] >= 254 ? LDS_SPECIAL + (bwt[bpos - 1] - 254) : 0u);
+    if (len && bpos + len < g.N)
+      next = (tid + 1 < nbk) ? (mine[g.LP] & 63u)
+                             : (bwt[bpos + len] >= 254 ? LDS_SPECIAL + (bwt[bpos + len] - 254) : 0u);
+    u32 cnt_scratch[PCK_MAX_SIGMA + 2];
+    for (u32 b = 0; b < nblk; b++) {
+      u64 code = 0;
+      u8 bs[16];
+      for (u32 i = 0; i < g.B; i++) {
+        const u32 off = b * g.B + i;
+        const u32 raw = mine[off];
+        const u32 c = raw & 63u;
+        const u32 letter = c >= LDS_SPECIAL ? 0u : c;     // region symbols fall back to letter 0
+        bs[i] = (u8) letter;
+        code = code * g.sigma + letter;
+        if (off < len) {
+          if (c < LDS_SPECIAL) s_cnt[c * g.T + tid]++;
+          else {
+            const u32 before = off ? (mine[off - 1] & 63u) : prev;
+            const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
+            nstart += before != c;
+            nend += after != c;
+          }
+          nmarks += (raw & LDS_MARK) != 0;
+        }
+      }
+      const u64 e = g.lut_entries ? lut[code] : block_indices(bs, g.sigma, g.B, cnt_scratch);
+      pbits_sum += (u32) (e >> 58);
+    }
+  }
+  // bits of the bucket's var part
+  u32 varbits = pbits_sum;
+  if (live && g.locint) {
+    if (g.loc_count) varbits += reqbits(len) + nmarks * (reqbits((u64) len - 1) + g.bits_orig_pos);
+    else varbits += nmarks * g.bits_orig_pos;
+  }
+  __syncthreads();
+
+  // prefix sums over the buckets of the tile
+  u32 tot;
+  const u32 var_ex = block_scan_excl_sum(live ? varbits : 0, &tot, s4);
+  const u64 ncols = g.sigma + PCK_EXTRA_COLS;
+  (void) ncols;
+  if (!EMIT) { if (tid == 0) tile_tot[(u64) g.sigma * g.ntiles + tile] = tot; }
+  const u32 st_ex = block_scan_excl_sum(nstart, &tot, s4);
+  if (!EMIT) { if (tid == 0) tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] = tot; }
+  const u32 en_ex = block_scan_excl_sum(nend, &tot, s4);
+  if (!EMIT) { if (tid == 0) tile_tot[(u64) (g.sigma + 2) * g.ntiles + tile] = tot; }
+
+  const u64 cwbit = g.cw_base_bit + bucket * g.cw_bits;
+  for (u32 s = 0; s < g.sigma; s++) {
+    const u32 ex = block_scan_excl_sum(live ? (u32) s_cnt[s * g.T + tid] : 0, &tot, s4);
+    if (!EMIT) { if (tid == 0) tile_tot[(u64) s * g.ntiles + tile] = tot; }
+    else if (live)   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
+      put_bits(img, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
+  }
+  if (!EMIT || !live) return;
+
+  const u64 var_off = tile_tot[(u64) g.sigma * g.ntiles + tile] + var_ex;
+  put_bits(img, cwbit + g.pre_var_idx, g.var_off_bits, var_off);
+  if (g.locint) put_bits(img, cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
+  u64 vbit = g.var_base_bit + var_off;
+  u64 ridx_s = tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] + st_ex;
+  u64 ridx_e = tile_tot[(u64) (g.sigma + 2) * g.ntiles + tile] + en_ex;
+  {
+    u32 prev = 0xff, next = 0xff;
+    if (bpos > 0) prev = tid > 0 ? (mine[-(int) g.LP + (int) g.L - 1] & 63u)
+                                 : (bwt[bpos - 1] >= 254 ? LDS_SPECIAL + (bwt[bpos - 1] - 254) : 0u);
+    if (len && bpos + len < g.N)
+      next = (tid + 1 < nbk) ? (mine[g.LP] & 63u)
+                             : (bwt[bpos + len] >= 254 ? LDS_SPECIAL + (bwt[bpos + len] - 254) : 0u);
+    u32 cnt_scratch[PCK_MAX_SIGMA + 2];
+    for (u32 b = 0; b < nblk; b++) {
+      u64 code = 0;
+      u8 bs[16];
+      for (u32 i = 0; i < g.B; i++) {
+        const u32 off = b * g.B + i;
+        const u32 c = mine[off] & 63u;
+        const u32 letter = c >= LDS_SPECIAL ? 0u : c;
+        bs[i] = (u8) letter;
+        code = code * g.sigma + letter;
+        if (off < len && c >= LDS_SPECIAL) {
+          // region list of the specials, gt_SRLAddPosition eis-seqranges.c:183-213
+          const u32 before = off ? (mine[off - 1] & 63u) : prev;
+          const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
+          if (before != c) rstart[ridx_s++] = (bpos + off) | ((u64) (c - LDS_SPECIAL) << 63);
+          if (after != c) rend[ridx_e++] = bpos + off + 1;
+        }
+      }
+      const u64 e = g.lut_entries ? lut[code] : block_indices(bs, g.sigma, g.B, cnt_scratch);
+      // append2IdxOutput, eis-blockcomp.c:1762-1775
+      put_bits(img, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits,
+               (e >> 40) & 0x3ffffu);
+      const u32 pb = (u32) (e >> 58);
+      put_bits(img, vbit, pb, e & 0xffffffffffull);
+      vbit += pb;
+    }
+  }
+  if (g.locint) {
+    // addLocateInfo, eis-bwtseq-extinfo.c:384-541
+    if (g.loc_bitmap) {
+      for (u32 o = 0; o < len; o += 64) {
+        const u32 m = min(64u, len - o);
+        u64 bitsv = 0;
+        for (u32 i = 0; i < m; i++) bitsv = (bitsv << 1) | ((mine[o + i] & LDS_MARK) ? 1u : 0u);
+        put_bits(img, cwbit + g.pre_cw_ext + o, m, bitsv);
+      }
+    }
+    const u32 bits_bwt_pos = reqbits((u64) len - 1);
+    if (g.loc_count) { const u32 bc = reqbits(len); put_bits(img, vbit, bc, nmarks); vbit += bc; }
+    for (u32 o = 0; o < len; o++)
+      if (mine[o] & LDS_MARK) {
+        if (g.loc_count) { put_bits(img, vbit, bits_bwt_pos, o); vbit += bits_bwt_pos; }
+        put_bits(img, vbit, g.bits_orig_pos, suf[bpos + o]);
+        vbit += g.bits_orig_pos;
+      }
+  }
+}
+
+// exclusive prefix sums of every column of tile_tot; totals[c] = column sum
+__global__ __launch_bounds__(PCK_THREADS) void k_pck_scan_cols(u64 *tile_tot, u32 ntiles, u64 *totals) {
+  __shared__ u64 s_w[4];
+  u64 *col = tile_tot + (u64) blockIdx.x * ntiles;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  u64 carry = 0;
+  for (u32 base = 0; base < ntiles; base += PCK_THREADS) {
+    const u32 i = base + threadIdx.x;
+    const u64 v = i < ntiles ? col[i] : 0;
+    u64 inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const u64 o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    u64 before = 0, all = 0;
+    for (int k = 0; k < 4; k++) { if (k < w) before += s_w[k]; all += s_w[k]; }
+    if (i < ntiles) col[i] = carry + before + inc - v;
+    carry += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// region records, struct seqRange eis-seqranges-priv.h:25-63: start (uint64),
+// then 1 symbol bit and 63 length bits, most significant first
+__global__ void k_pck_regions(const u64 *rstart, const u64 *rend, u64 nregions, u64 N, u32 B,
+                              u8 *dst) {
+  const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > nregions) return;
+  u64 start, len, sym;
+  if (i < nregions) {
+    start = rstart[i] & ~(1ull << 63);
+    sym = rstart[i] >> 63;
+    len = rend[i] - start;
+  } else {          // terminator just beyond the sequence, eis-blockcomp.c:2461-2464
+    start = N + B; len = 1; sym = 0;
+  }
+  u8 *r = dst + 16 * i;
+  const u64 be = (sym << 63) | len;
+  for (int k = 0; k < 8; k++) {
+    r[k] = (u8) (start >> (8 * k));
+    r[8 + k] = (u8) (be >> (8 * (7 - k)));
+  }
+}
+
+}  // namespace
+
+struct gtamd_pck {
+  int device;
+  hipStream_t st;
+  hipEvent_t ev0, ev1;
+  u64 *lut; u64 lut_entries; u32 lut_sigma, lut_B;
+  u8 *img; u64 img_cap;
+  u64 *tile_tot; u64 tile_tot_cap;
+  u64 *rlist; u64 rlist_cap;
+  u64 *d_totals;
+  gtamd_pck_info info;
+  bool built;
+};
+
+extern "C" int gtamd_pck_default_toggles(uint32_t block_size, uint32_t bucket_blocks,
+                                         uint32_t locate_interval, int locbitmap) {
+  // gt_computePackedIndexDefaults / estimateBestLocateTypeFeature,
+  // src/match/eis-bwtseq-param.c:69-103
+  if (locbitmap >= 0) return locbitmap ? GTAMD_PCK_LOCATE_BITMAP : GTAMD_PCK_LOCATE_COUNT;
+  if (!locate_interval) return 0;
+  const u32 seg = block_size * bucket_blocks;
+  if (seg > (seg + 1) * reqbits(seg) / locate_interval) return GTAMD_PCK_LOCATE_COUNT;
+  return GTAMD_PCK_LOCATE_BITMAP;
+}
+
+extern "C" gtamd_pck *gtamd_pck_create(int device) {
+  if (gtamd_device_count() <= device || device < 0) {
+    gtamd_set_error("no HIP device %d available (this library has no CPU fallback)", device);
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { gtamd_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+  gtamd_pck *p = new gtamd_pck();
+  memset(p, 0, sizeof *p);
+  p->device = device;
+  if (hipStreamCreate(&p->st) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
+      hipEventCreate(&p->ev1) != hipSuccess ||
+      hipMalloc(&p->d_totals, (PCK_MAX_SIGMA + 8) * sizeof(u64)) != hipSuccess) {
+    gtamd_set_error("cannot create the packed-index builder on device %d", device);
+    delete p;
+    return nullptr;
+  }
+  return p;
+}
+
+extern "C" void gtamd_pck_destroy(gtamd_pck *p) {
+  if (p == nullptr) return;
+  (void) hipSetDevice(p->device);
+  (void) hipStreamSynchronize(p->st);
+  if (p->lut) (void) hipFree(p->lut);
+  if (p->img) (void) hipFree(p->img);
+  if (p->tile_tot) (void) hipFree(p->tile_tot);
+  if (p->rlist) (void) hipFree(p->rlist);
+  if (p->d_totals) (void) hipFree(p->d_totals);
+  (void) hipEventDestroy(p->ev0);
+  (void) hipEventDestroy(p->ev1);
+  (void) hipStreamDestroy(p->st);
+  delete p;
+}
+
+template <typename T> static int grow(T **buf, u64 *cap, u64 need_bytes) {
+  if (*cap >= need_bytes && *buf != nullptr) return 0;
+  if (*buf) (void) hipFree(*buf);
+  *buf = nullptr; *cap = 0;
+  if (hipMalloc((void **) buf, need_bytes) != hipSuccess) {
+    gtamd_set_error("cannot allocate %llu bytes of device memory for the packed index",
+                    (unsigned long long) need_bytes);
+    return -1;
+  }
+  *cap = need_bytes;
+  return 0;
+}
+
+// ---- the bits the reference leaves stale in the last bucket --------------------
+// The reference assembles a bucket in a staging buffer that is never cleared,
+// writes the whole bytes to the file and moves the incomplete last byte to the
+// front (updateIdxOutput, eis-blockcomp.c:1807-1886).  Bits of the last
+// bucket's record that are not stored explicitly (composition indices of
+// blocks that do not exist, locate bits behind the end) and the unused bits of
+// the final byte keep what an earlier bucket left at that place of the buffer.
+// This replays the buffer for the last records of a bit string, from the
+// image's own bytes, tracking which bits are known, and returns the bytes the
+// reference wrote last.
+struct StaleRec { u64 gbit, nbits; };    // record: start in the stream, bits the buffer position advances by
+namespace {
+struct Replay {
+  std::vector<u8> buf, known;   // one entry per BIT (0/1), simple and small
+};
+// stream: bytes of the bit string from byte `stream_byte0` on (host copy)
+// recs: consecutive records, the last one is the last of the stream;
+// explicit_last: bit ranges (relative to the record start) the last record stores
+// out: bytes from byte (recs.back().gbit / 8) to the end of what the reference writes
+// returns false when a needed bit is unknown (window too small)
+bool replay_tail(const std::vector<u8> &stream, u64 stream_byte0, const std::vector<StaleRec> &recs,
+                 const std::vector<std::pair<u64, u64>> &explicit_last, bool from_stream_start,
+                 std::vector<u8> *out) {
+  u64 maxbits = 16;
+  for (const StaleRec &r : recs) maxbits = std::max(maxbits, (r.gbit & 7) + r.nbits + 16);
+  std::vector<u8> bit(maxbits, 0), kn(maxbits, from_stream_start ? 1 : 0);
+  auto stream_bit = [&](u64 gb) -> u8 {
+    const u64 byte = (gb >> 3) - stream_byte0;
+    return (stream[byte] >> (7 - (gb & 7))) & 1u;
+  };
+  for (size_t j = 0; j < recs.size(); j++) {
+    const StaleRec &r = recs[j];
+    const u64 old = r.gbit & 7;
+    const bool last = j + 1 == recs.size();
+    // the front byte carries the true tail of the record before
+    for (u64 q = 0; q < old; q++) { bit[q] = stream_bit(r.gbit - old + q); kn[q] = 1; }
+    if (!last) {
+      for (u64 q = 0; q < r.nbits; q++) { bit[old + q] = stream_bit(r.gbit + q); kn[old + q] = 1; }
+    } else {
+      for (const auto &rg : explicit_last)
+        for (u64 q = rg.first; q < rg.first + rg.second; q++) { bit[old + q] = stream_bit(r.gbit + q); kn[old + q] = 1; }
+    }
+    const u64 end = old + r.nbits, nbytes = end / 8;
+    if (last) {
+      const u64 total_bits = (end % 8) ? (nbytes + 1) * 8 : nbytes * 8;
+      out->assign((size_t) (total_bits / 8), 0);
+      for (u64 q = 0; q < total_bits; q++) {
+        // the final incomplete byte is written from the front of the buffer
+        // after the move; its bits are those of buffer byte nbytes
+        if (!kn[q]) return false;
+        if (bit[q]) (*out)[(size_t) (q >> 3)] |= (u8) (0x80u >> (q & 7));
+      }
+      return true;
+    }
+    if (end % 8)
+      for (u64 q = 0; q < 8; q++) { bit[q] = bit[nbytes * 8 + q]; kn[q] = kn[nbytes * 8 + q]; }
+  }
+  return true;
+}
+}  // namespace
+
+static u64 get_bits_host(const std::vector<u8> &s, u64 bit, u32 nbits) {
+  u64 v = 0;
+  for (u32 i = 0; i < nbits; i++) { const u64 b = bit + i; v = (v << 1) | ((s[(size_t) (b >> 3)] >> (7 - (b & 7))) & 1u); }
+  return v;
+}
+
+static int fix_stale_bits(gtamd_pck *p, const PckGeom &g, u64 var_bits_total) {
+  const u64 cw_data_pos = g.cw_base_bit / 8, var_data_pos = g.var_base_bit / 8;
+  const u64 last = g.nb - 1;
+  const u64 last_pos = last * g.L;
+  const u32 len_last = (u32) (g.N - last_pos);
+  const u32 nblk_last = (len_last + g.B - 1) / g.B;
+  // bits by which the buffer position advances for the last cw record: the full
+  // record when the locate callback runs (appendCallBackOutput sets the position
+  // behind the extension bits), else up to the last composition index stored
+  const u64 last_cw_adv = g.locint ? g.cw_bits : (u64) g.pre_comp_idx + (u64) nblk_last * g.comp_idx_bits;
+  for (u64 window = 64; ; window *= 4) {
+    const u64 j0 = last + 1 > window ? last + 1 - window : 0;
+    // ---- cw records
+    const u64 cw_first_byte = (j0 * g.cw_bits) / 8;
+    const u64 cw_end_bit = last * g.cw_bits + g.cw_bits;
+    const u64 cw_bytes = (cw_end_bit + 7) / 8 + 1 - cw_first_byte;
+    std::vector<u8> cws((size_t) cw_bytes + 8, 0);
+    {
+      const u64 avail = std::min<u64>(cw_bytes, var_data_pos - (cw_data_pos + cw_first_byte));
+      HIP_TRY(hipMemcpy(cws.data(), p->img + cw_data_pos + cw_first_byte, avail, hipMemcpyDeviceToHost));
+    }
+    std::vector<StaleRec> recs;
+    for (u64 j = j0; j <= last; j++) recs.push_back({j * g.cw_bits, j == last ? last_cw_adv : (u64) g.cw_bits});
+    std::vector<std::pair<u64, u64>> ex;
+    ex.push_back({0, (u64) g.pre_comp_idx + (u64) nblk_last * g.comp_idx_bits});
+    if (g.locint && g.loc_bitmap) ex.push_back({g.pre_cw_ext, len_last});
+    std::vector<u8> tail;
+    const bool ok_cw = replay_tail(cws, cw_first_byte, recs, ex, j0 == 0, &tail);
+    // ---- var parts: offsets from the cw records themselves
+    std::vector<StaleRec> vrecs;
+    for (u64 j = j0; j <= last; j++) {
+      const u64 off = get_bits_host(cws, j * g.cw_bits + g.pre_var_idx - cw_first_byte * 8, g.var_off_bits);
+      vrecs.push_back({off, 0});
+    }
+    for (size_t k = 0; k < vrecs.size(); k++)
+      vrecs[k].nbits = (k + 1 < vrecs.size() ? vrecs[k + 1].gbit : var_bits_total) - vrecs[k].gbit;
+    const u64 var_first_byte = vrecs[0].gbit / 8;
+    const u64 var_bytes = (var_bits_total + 7) / 8 - var_first_byte;
+    std::vector<u8> vs((size_t) var_bytes + 8, 0), vtail;
+    if (var_bytes)
+      HIP_TRY(hipMemcpy(vs.data(), p->img + var_data_pos + var_first_byte, var_bytes, hipMemcpyDeviceToHost));
+    std::vector<std::pair<u64, u64>> vex;
+    vex.push_back({0, vrecs.back().nbits});
+    const bool ok_var = replay_tail(vs, var_first_byte, vrecs, vex, j0 == 0, &vtail);
+    if ((!ok_cw || !ok_var) && j0 > 0) continue;
+    if (!ok_cw || !ok_var) { gtamd_set_error("packed index: replay of the staging buffers failed"); return -1; }
+    if (!tail.empty())
+      HIP_TRY(hipMemcpy(p->img + cw_data_pos + (last * g.cw_bits) / 8, tail.data(), tail.size(), hipMemcpyHostToDevice));
+    // the var part of the last bucket is written before the region list, whose
+    // first bytes follow the final byte: the final byte only
+    if (!vtail.empty())
+      HIP_TRY(hipMemcpy(p->img + var_data_pos + vrecs.back().gbit / 8, vtail.data(), vtail.size(), hipMemcpyHostToDevice));
+    return 0;
+  }
+}
+
+extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t *suf,
+                               uint64_t total_len, uint32_t sigma, uint64_t longest,
+                               const gtamd_pck_params *pp) {
+  if (p == nullptr || bwt == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build"); return -1; }
+  const u32 B = pp->block_size, K = pp->bucket_blocks, locint = pp->locate_interval;
+  const bool loc_bitmap = locint && (pp->feature_toggles & GTAMD_PCK_LOCATE_BITMAP);
+  const bool loc_count = locint && !loc_bitmap && (pp->feature_toggles & GTAMD_PCK_LOCATE_COUNT);
+  if (B < 1 || B > 16 || K < 1 || (u64) B * K > PCK_TILE_POS || sigma < 2 || sigma > PCK_MAX_SIGMA) {
+    gtamd_set_error("packed index: block size %u x %u blocks per bucket over %u letters is outside "
+                    "what the device builder supports (block size <= 16, bucket <= %u positions)",
+                    B, K, sigma, PCK_TILE_POS);
+    return -1;
+  }
+  if (locint && !loc_bitmap && !loc_count) { gtamd_set_error("packed index: locate information wanted but neither bitmap nor count mode chosen"); return -1; }
+  if (locint && suf == nullptr) { gtamd_set_error("packed index: locate information needs the suffix array"); return -1; }
+  if (total_len < 2) { gtamd_set_error("packed index: empty sequence"); return -1; }
+  if (pp->feature_toggles & ~(GTAMD_PCK_LOCATE_BITMAP | GTAMD_PCK_LOCATE_COUNT)) {
+    gtamd_set_error("packed index: feature toggles %d not supported (no -sprank)", (int) pp->feature_toggles);
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(p->device));
+  p->built = false;
+
+  PckGeom g;
+  memset(&g, 0, sizeof g);
+  g.N = total_len; g.sigma = sigma; g.B = B; g.K = K; g.L = B * K;
+  g.LP = 4 * (2 * ((g.L + 7) / 8) + 1);
+  g.nb = (total_len + 1) / g.L + (((total_len + 1) % g.L) ? 1 : 0);     // numBuckets, eis-blockcomp.c:1633-1638
+  g.T = std::max<u32>(1, std::min<u32>(PCK_THREADS, PCK_TILE_POS / g.L));
+  g.ntiles = (u32) div_up(g.nb, g.T);
+  g.locint = locint; g.loc_bitmap = loc_bitmap; g.loc_count = loc_count;
+  g.loc_pow2 = locint && (locint & (locint - 1)) == 0; g.locmask = locint ? locint - 1 : 0;
+  // widths: gt_newGenBlockEncIdxSeq eis-blockcomp.c:336-339, 477-501;
+  // symSumBitsDefaultSetup :757-774 (no sequence statistics on this path)
+  const u32 bits_per_ulong = reqbits(total_len - 1);
+  u32 off = 0;
+  for (u32 s = 0; s < sigma; s++) { g.sym_bits[s] = bits_per_ulong; g.sym_off[s] = off; off += bits_per_ulong; }
+  const u32 sym_sum_bits = off;
+  g.comp_idx_bits = reqbits(binom(B + sigma - 1, sigma - 1) - 1);
+  u32 even[PCK_MAX_SIGMA + 2];
+  for (u32 s = 0; s < sigma; s++) even[s] = B / sigma + (s < B % sigma ? 1u : 0u);
+  const u64 max_perms = arrangements(even, sigma, B);
+  const u32 max_perm_idx_bits = reqbits(max_perms - 1);
+  if (g.comp_idx_bits > 18 || max_perm_idx_bits > 40) {
+    gtamd_set_error("packed index: block size %u over %u letters needs wider indices than the device builder packs", B, sigma);
+    return -1;
+  }
+  const u64 cw_ext_bits = loc_bitmap ? g.L : 0;
+  g.cb_off_bits = locint ? reqbits((u64) max_perm_idx_bits * K) : 0;
+  // vwBits eis-blockcomp.c:1659-1689, locBitsUpperBounds eis-bwtseq-extinfo.c:195-251
+  u64 max_var_bits_total = g.nb * ((u64) max_perm_idx_bits * K), max_var_ext_bits_per_bucket = 0;
+  if (locint) {
+    const u64 last_pos = total_len - 1;
+    g.bits_orig_pos = reqbits(last_pos);
+    u64 extra = 0;
+    if (locint > 1) extra = std::min(total_len / 2, total_len - total_len / locint);
+    const u64 dlen[2] = { g.L, total_len % g.L };
+    const u64 drep[2] = { (total_len + 1) / g.L, ((total_len + 1) % g.L) ? 1ull : 0ull };
+    u64 max_seg = 0, tot = 0;
+    for (int i = 0; i < 2; i++) { max_seg = std::max(max_seg, dlen[i]); if (loc_count) tot += reqbits(dlen[i]) * drep[i]; }
+    tot += (total_len / locint + extra) * ((loc_count ? reqbits(max_seg) : 0) + g.bits_orig_pos);
+    max_var_ext_bits_per_bucket = max_seg * ((loc_count ? reqbits(last_pos) : 0) + g.bits_orig_pos)
+                                  + (loc_count ? reqbits(max_seg) : 0);
+    max_var_bits_total += tot;
+  }
+  g.var_off_bits = reqbits(max_var_bits_total);
+  g.pre_var_idx = sym_sum_bits;
+  g.pre_cb_off = g.pre_var_idx + g.var_off_bits;
+  g.pre_comp_idx = g.pre_cb_off + g.cb_off_bits;
+  g.pre_cw_ext = g.pre_comp_idx + g.comp_idx_bits * K;
+  g.cw_bits = g.pre_cw_ext + (u32) cw_ext_bits;
+  // header, blockEncIdxSeqHeaderLength eis-blockcomp.c:1919-1946
+  const u32 num_modes = 2;
+  u64 header_len = 4 + 4 + 8 + 8 + 12 + 12 + 8 + 8 + 8 + 4 * sigma + 8 + 8 + 8 + 12 + 4 * num_modes;
+  if (g.cb_off_bits) header_len += 8 + 12 + 12;
+  const u64 cw_data_pos = div_up(header_len + (locint ? 8 + 16 : 0), 8192) * 8192;
+  const u64 cw_len = ((u64) g.cw_bits * g.nb + 7) / 8;
+  const u64 var_data_pos = cw_data_pos + cw_len;
+  g.cw_base_bit = cw_data_pos * 8;
+  g.var_base_bit = var_data_pos * 8;
+
+  // block -> index pair table
+  u64 entries = 1;
+  for (u32 i = 0; i < B && entries <= (1ull << 24); i++) entries *= sigma;
+  if (entries > (1ull << 24)) entries = 0;
+  if (entries && (p->lut == nullptr || p->lut_sigma != sigma || p->lut_B != B)) {
+    if (p->lut) { (void) hipFree(p->lut); p->lut = nullptr; }
+    if (hipMalloc(&p->lut, entries * sizeof(u64)) != hipSuccess) { gtamd_set_error("packed index: cannot allocate the block table"); return -1; }
+    k_pck_lut<<<(u32) div_up(entries, 256), 256, 0, p->st>>>(entries, sigma, B, p->lut);
+    HIP_TRY(hipGetLastError());
+    p->lut_entries = entries; p->lut_sigma = sigma; p->lut_B = B;
+  }
+  g.lut_entries = entries;
+
+  const u64 ncols = sigma + PCK_EXTRA_COLS;
+  u64 tt_cap_bytes = p->tile_tot_cap;
+  TRY(grow(&p->tile_tot, &tt_cap_bytes, ncols * g.ntiles * sizeof(u64)));
+  p->tile_tot_cap = tt_cap_bytes;
+
+  HIP_TRY(hipEventRecord(p->ev0, p->st));
+  // rows from first_special_row on hold the suffixes that start with a special:
+  // as many as the BWT holds specials (every special position p is the symbol
+  // before suffix p + 1; the undefined symbol before suffix 0 stands for the
+  // virtual end)
+  HIP_TRY(hipMemsetAsync(p->d_totals, 0, (PCK_MAX_SIGMA + 8) * sizeof(u64), p->st));
+  k_pck_count_specials<<<1024, 256, 0, p->st>>>(bwt, total_len, (unsigned long long *) p->d_totals);
+  HIP_TRY(hipGetLastError());
+  u64 nspecial = 0;
+  HIP_TRY(hipStreamSynchronize(p->st));
+  HIP_TRY(hipMemcpy(&nspecial, p->d_totals, 8, hipMemcpyDeviceToHost));
+  g.first_special_row = total_len - nspecial;
+
+  const size_t lds = (((size_t) g.T * g.LP + 15) & ~(size_t) 15) + (size_t) sigma * g.T * sizeof(u16);
+  k_pck_tile<false><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, nullptr, nullptr, nullptr);
+  HIP_TRY(hipGetLastError());
+  k_pck_scan_cols<<<(u32) ncols, PCK_THREADS, 0, p->st>>>(p->tile_tot, g.ntiles, p->d_totals);
+  HIP_TRY(hipGetLastError());
+  u64 totals[PCK_MAX_SIGMA + 8];
+  HIP_TRY(hipStreamSynchronize(p->st));
+  HIP_TRY(hipMemcpy(totals, p->d_totals, ncols * sizeof(u64), hipMemcpyDeviceToHost));
+  const u64 var_bits_total = totals[sigma], nregions = totals[sigma + 1];
+  if (totals[sigma + 2] != nregions) { gtamd_set_error("packed index: region starts and ends disagree"); return -1; }
+  const u64 range_enc_pos = var_data_pos + var_bits_total / 8 + ((var_bits_total % 8) ? 1 : 0);
+  const u64 file_bytes = range_enc_pos + 8 + 16 * (nregions + 1);
+
+  u64 img_cap = p->img_cap;
+  TRY(grow(&p->img, &img_cap, ((file_bytes + 7) & ~7ull) + 64));
+  p->img_cap = img_cap;
+  u64 rl_cap = p->rlist_cap;
+  TRY(grow(&p->rlist, &rl_cap, std::max<u64>(1, nregions) * 2 * sizeof(u64)));
+  p->rlist_cap = rl_cap;
+  HIP_TRY(hipMemsetAsync(p->img, 0, ((file_bytes + 7) & ~7ull) + 64, p->st));
+  k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
+                                                         p->rlist, p->rlist + std::max<u64>(1, nregions));
+  HIP_TRY(hipGetLastError());
+  k_pck_regions<<<(u32) div_up(nregions + 1, 256), 256, 0, p->st>>>(
+      p->rlist, p->rlist + std::max<u64>(1, nregions), nregions, total_len, B, p->img + range_enc_pos + 8);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(p->ev1, p->st));
+  HIP_TRY(hipStreamSynchronize(p->st));
+
+  // header + extension header, writeIdxHeader eis-blockcomp.c:1984-2094,
+  // writeLocateInfoHeader eis-bwtseq-extinfo.c:59-76
+  {
+    std::vector<u8> h((size_t) header_len + 64, 0);
+    u64 o = 8;
+    auto put32 = [&](u64 v) { const u32 x = (u32) v; memcpy(&h[(size_t) o], &x, 4); o += 4; };
+    auto put64 = [&](u64 v) { memcpy(&h[(size_t) o], &v, 8); o += 8; };
+    memcpy(&h[0], "BDX", 4);
+    { const u32 x = (u32) (div_up(header_len, 8192) * 8192); memcpy(&h[4], &x, 4); }
+    put32(0x424b535a); put32(B);
+    put32(0x42424c4b); put32(K);
+    put32(0x564f4646); put64(var_data_pos);
+    put32(0x524f4646); put64(range_enc_pos);
+    put32(0x53454c45); put64(total_len);
+    put32(0x53504254); put32(bits_per_ulong);
+    put32(0x56444f42); put32(g.var_off_bits);
+    put32(0x53534254); put32(sigma);
+    for (u32 s = 0; s < sigma; s++) put32(g.sym_bits[s]);
+    put32(0x42454642); put32(0);
+    put32(0x52454642); put32(0);
+    put32(0x4e4d524e); put32(num_modes);
+    put32(1); put32(2);        // BLOCK_COMPOSITION_INCLUDE, REGIONS_LIST
+    if (g.cb_off_bits) {
+      put32(0x43424d42); put32(g.cb_off_bits);
+      put32(0x43455842); put64(cw_ext_bits);
+      put32(0x4d455842); put64(max_var_ext_bits_per_bucket);
+    }
+    if (o != header_len) { gtamd_set_error("packed index: header length mismatch"); return -1; }
+    if (locint) {
+      put32(0x45480000u | 1111u); put32(16);
+      put64(longest); put32(locint); put32((u32) pp->feature_toggles);
+    }
+    HIP_TRY(hipMemcpy(p->img, h.data(), (size_t) o, hipMemcpyHostToDevice));
+    const u64 nr = nregions + 1;
+    HIP_TRY(hipMemcpy(p->img + range_enc_pos, &nr, 8, hipMemcpyHostToDevice));
+  }
+  TRY(fix_stale_bits(p, g, var_bits_total));
+
+  memset(&p->info, 0, sizeof p->info);
+  p->info.file_bytes = file_bytes; p->info.cw_data_pos = cw_data_pos; p->info.var_data_pos = var_data_pos;
+  p->info.range_enc_pos = range_enc_pos; p->info.num_buckets = g.nb; p->info.num_regions = nregions + 1;
+  p->info.var_bits = var_bits_total; p->info.cw_bits = g.cw_bits;
+  HIP_TRY(hipEventElapsedTime(&p->info.build_ms, p->ev0, p->ev1));
+  p->built = true;
+  return 0;
+}
+
+extern "C" int gtamd_pck_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa,
+                                        const gtamd_pck_params *pp) {
+  if (p == nullptr || esa == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build_from_esa"); return -1; }
+  int device = 0; u32 sigma = 0, numparts = 0;
+  TRY(gtamd_esa_internal_info(esa, &device, &sigma, &numparts));
+  if (numparts != 1) { gtamd_set_error("packed index: needs the tables of a whole-table build"); return -1; }
+  if (device != p->device) { gtamd_set_error("packed index: the tables live on device %d, the builder on %d", device, p->device); return -1; }
+  const u8 *bwt = (const u8 *) gtamd_esa_table_device(esa, GTAMD_TAB_BWT);
+  const u64 *suf = (const u64 *) gtamd_esa_table_device(esa, GTAMD_TAB_SUF);
+  gtamd_esa_stats st;
+  TRY(gtamd_esa_get_stats(esa, &st));
+  if (bwt == nullptr || (suf == nullptr && pp->locate_interval)) {
+    gtamd_set_error("packed index: the last run did not produce the .bwt%s table", suf == nullptr ? " / .suf" : "");
+    return -1;
+  }
+  return gtamd_pck_build(p, bwt, suf, st.numberofallsortedsuffixes, sigma, st.longest, pp);
+}
+
+extern "C" int gtamd_pck_get_info(const gtamd_pck *p, gtamd_pck_info *info) {
+  if (p == nullptr || !p->built || info == nullptr) { gtamd_set_error("no packed index built"); return -1; }
+  *info = p->info;
+  return 0;
+}
+extern "C" const void *gtamd_pck_image_device(const gtamd_pck *p) {
+  return (p != nullptr && p->built) ? p->img : nullptr;
+}
+extern "C" int gtamd_pck_image_copy(gtamd_pck *p, void *dst, uint64_t offset, uint64_t count) {
+  if (p == nullptr || !p->built) { gtamd_set_error("no packed index built"); return -1; }
+  if (count == 0) return 0;
+  if (dst == nullptr || offset + count > p->info.file_bytes) {
+    gtamd_set_error("packed index: range [%llu,+%llu) outside the %llu bytes of the image",
+                    (unsigned long long) offset, (unsigned long long) count,
+                    (unsigned long long) p->info.file_bytes);
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipMemcpy(dst, p->img + offset, count, hipMemcpyDeviceToHost));
+  return 0;
+}

@@ -9,7 +9,7 @@ import pytest
 
 from genometools_amd import _lib
 
-HEADERS = [os.path.join(_lib.ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h")]
+HEADERS = [os.path.join(_lib.ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h", "gtamd_pck.h")]
 
 
 def _declared_symbols():

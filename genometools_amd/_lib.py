@@ -88,7 +88,8 @@ class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd
 
 class PckParams(ctypes.Structure):       # gtamd_pck_params, include/gtamd_pck.h
     _fields_ = [("block_size", ctypes.c_uint32), ("bucket_blocks", ctypes.c_uint32),
-                ("locate_interval", ctypes.c_uint32), ("feature_toggles", ctypes.c_int32)]
+                ("locate_interval", ctypes.c_uint32), ("feature_toggles", ctypes.c_int32),
+                ("with_statistics", ctypes.c_int32)]
 
 
 class PckInfo(ctypes.Structure):         # gtamd_pck_info
@@ -157,6 +158,7 @@ ABI = {
     "gtamd_pck_create": (_P, [_INT]),
     "gtamd_pck_destroy": (None, [_P]),
     "gtamd_pck_build": (_INT, [_P, _P, _P, _U64, _U32, _U64, ctypes.POINTER(PckParams)]),
+    "gtamd_pck_build_host": (_INT, [_P, _P, _P, _U64, _U32, _U64, ctypes.POINTER(PckParams)]),
     "gtamd_pck_build_from_esa": (_INT, [_P, _P, ctypes.POINTER(PckParams)]),
     "gtamd_pck_get_info": (_INT, [_P, ctypes.POINTER(PckInfo)]),
     "gtamd_pck_image_device": (_P, [_P]),

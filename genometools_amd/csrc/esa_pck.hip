@@ -586,6 +586,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   if (locint && !loc_bitmap && !loc_count) { gtamd_set_error("packed index: locate information wanted but neither bitmap nor count mode chosen"); return -1; }
   if (locint && suf == nullptr) { gtamd_set_error("packed index: locate information needs the suffix array"); return -1; }
   if (total_len < 2) { gtamd_set_error("packed index: empty sequence"); return -1; }
+  if (total_len >= (1ull << 40)) { gtamd_set_error("packed index: more than 2^40 positions"); return -1; }
   if (pp->feature_toggles & ~(GTAMD_PCK_LOCATE_BITMAP | GTAMD_PCK_LOCATE_COUNT)) {
     gtamd_set_error("packed index: feature toggles %d not supported (no -sprank)", (int) pp->feature_toggles);
     return -1;
@@ -602,12 +603,9 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   g.ntiles = (u32) div_up(g.nb, g.T);
   g.locint = locint; g.loc_bitmap = loc_bitmap; g.loc_count = loc_count;
   g.loc_pow2 = locint && (locint & (locint - 1)) == 0; g.locmask = locint ? locint - 1 : 0;
-  // widths: gt_newGenBlockEncIdxSeq eis-blockcomp.c:336-339, 477-501;
-  // symSumBitsDefaultSetup :757-774 (no sequence statistics on this path)
+  // widths the counting pass needs: gt_newGenBlockEncIdxSeq eis-blockcomp.c:336-339,
+  // 477-501; initAddLocateInfoState eis-bwtseq-extinfo.c:253-337
   const u32 bits_per_ulong = reqbits(total_len - 1);
-  u32 off = 0;
-  for (u32 s = 0; s < sigma; s++) { g.sym_bits[s] = bits_per_ulong; g.sym_off[s] = off; off += bits_per_ulong; }
-  const u32 sym_sum_bits = off;
   g.comp_idx_bits = reqbits(binom(B + sigma - 1, sigma - 1) - 1);
   u32 even[PCK_MAX_SIGMA + 2];
   for (u32 s = 0; s < sigma; s++) even[s] = B / sigma + (s < B % sigma ? 1u : 0u);
@@ -619,37 +617,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   }
   const u64 cw_ext_bits = loc_bitmap ? g.L : 0;
   g.cb_off_bits = locint ? reqbits((u64) max_perm_idx_bits * K) : 0;
-  // vwBits eis-blockcomp.c:1659-1689, locBitsUpperBounds eis-bwtseq-extinfo.c:195-251
-  u64 max_var_bits_total = g.nb * ((u64) max_perm_idx_bits * K), max_var_ext_bits_per_bucket = 0;
-  if (locint) {
-    const u64 last_pos = total_len - 1;
-    g.bits_orig_pos = reqbits(last_pos);
-    u64 extra = 0;
-    if (locint > 1) extra = std::min(total_len / 2, total_len - total_len / locint);
-    const u64 dlen[2] = { g.L, total_len % g.L };
-    const u64 drep[2] = { (total_len + 1) / g.L, ((total_len + 1) % g.L) ? 1ull : 0ull };
-    u64 max_seg = 0, tot = 0;
-    for (int i = 0; i < 2; i++) { max_seg = std::max(max_seg, dlen[i]); if (loc_count) tot += reqbits(dlen[i]) * drep[i]; }
-    tot += (total_len / locint + extra) * ((loc_count ? reqbits(max_seg) : 0) + g.bits_orig_pos);
-    max_var_ext_bits_per_bucket = max_seg * ((loc_count ? reqbits(last_pos) : 0) + g.bits_orig_pos)
-                                  + (loc_count ? reqbits(max_seg) : 0);
-    max_var_bits_total += tot;
-  }
-  g.var_off_bits = reqbits(max_var_bits_total);
-  g.pre_var_idx = sym_sum_bits;
-  g.pre_cb_off = g.pre_var_idx + g.var_off_bits;
-  g.pre_comp_idx = g.pre_cb_off + g.cb_off_bits;
-  g.pre_cw_ext = g.pre_comp_idx + g.comp_idx_bits * K;
-  g.cw_bits = g.pre_cw_ext + (u32) cw_ext_bits;
-  // header, blockEncIdxSeqHeaderLength eis-blockcomp.c:1919-1946
-  const u32 num_modes = 2;
-  u64 header_len = 4 + 4 + 8 + 8 + 12 + 12 + 8 + 8 + 8 + 4 * sigma + 8 + 8 + 8 + 12 + 4 * num_modes;
-  if (g.cb_off_bits) header_len += 8 + 12 + 12;
-  const u64 cw_data_pos = div_up(header_len + (locint ? 8 + 16 : 0), 8192) * 8192;
-  const u64 cw_len = ((u64) g.cw_bits * g.nb + 7) / 8;
-  const u64 var_data_pos = cw_data_pos + cw_len;
-  g.cw_base_bit = cw_data_pos * 8;
-  g.var_base_bit = var_data_pos * 8;
+  if (locint) g.bits_orig_pos = reqbits(total_len - 1);
 
   // block -> index pair table
   u64 entries = 1;
@@ -692,6 +660,58 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   HIP_TRY(hipMemcpy(totals, p->d_totals, ncols * sizeof(u64), hipMemcpyDeviceToHost));
   const u64 var_bits_total = totals[sigma], nregions = totals[sigma + 1];
   if (totals[sigma + 2] != nregions) { gtamd_set_error("packed index: region starts and ends disagree"); return -1; }
+
+  // widths of the occurrence counters: symSumBitsDefaultSetup eis-blockcomp.c:757-774
+  // without sequence statistics (trsuftab); with them (mkindex) as many bits as the
+  // occurrences of each letter need, eis-blockcomp.c:385-437 -- the counting pass
+  // has just counted them
+  u64 regular = 0;
+  u32 off = 0;
+  for (u32 s = 0; s < sigma; s++) {
+    regular += totals[s];
+    g.sym_bits[s] = pp->with_statistics ? reqbits(totals[s]) : bits_per_ulong;
+    g.sym_off[s] = off;
+    off += g.sym_bits[s];
+  }
+  const u32 sym_sum_bits = off;
+  // vwBits eis-blockcomp.c:1659-1689, locBitsUpperBounds eis-bwtseq-extinfo.c:195-251
+  u64 max_var_bits_total = g.nb * ((u64) max_perm_idx_bits * K), max_var_ext_bits_per_bucket = 0;
+  if (locint) {
+    const u64 last_pos = total_len - 1;
+    u64 extra = 0;
+    if (locint > 1) {
+      extra = std::min(total_len / 2, total_len - total_len / locint);
+      if (pp->with_statistics) {
+        // symbols outside the value-sorted range as newSeqStatsFromCharDist counts
+        // them (eis-suffixerator-interface.c:176-206, eis-bwtseq-extinfo.c:302-314)
+        const u64 nonval = total_len - regular + 1;
+        extra = std::min(extra, std::min(nonval, total_len - nonval));
+      }
+    }
+    const u64 dlen[2] = { g.L, total_len % g.L };
+    const u64 drep[2] = { (total_len + 1) / g.L, ((total_len + 1) % g.L) ? 1ull : 0ull };
+    u64 max_seg = 0, tot = 0;
+    for (int i = 0; i < 2; i++) { max_seg = std::max(max_seg, dlen[i]); if (loc_count) tot += reqbits(dlen[i]) * drep[i]; }
+    tot += (total_len / locint + extra) * ((loc_count ? reqbits(max_seg) : 0) + g.bits_orig_pos);
+    max_var_ext_bits_per_bucket = max_seg * ((loc_count ? reqbits(last_pos) : 0) + g.bits_orig_pos)
+                                  + (loc_count ? reqbits(max_seg) : 0);
+    max_var_bits_total += tot;
+  }
+  g.var_off_bits = reqbits(max_var_bits_total);
+  g.pre_var_idx = sym_sum_bits;
+  g.pre_cb_off = g.pre_var_idx + g.var_off_bits;
+  g.pre_comp_idx = g.pre_cb_off + g.cb_off_bits;
+  g.pre_cw_ext = g.pre_comp_idx + g.comp_idx_bits * K;
+  g.cw_bits = g.pre_cw_ext + (u32) cw_ext_bits;
+  // header, blockEncIdxSeqHeaderLength eis-blockcomp.c:1919-1946
+  const u32 num_modes = 2;
+  u64 header_len = 4 + 4 + 8 + 8 + 12 + 12 + 8 + 8 + 8 + 4 * sigma + 8 + 8 + 8 + 12 + 4 * num_modes;
+  if (g.cb_off_bits) header_len += 8 + 12 + 12;
+  const u64 cw_data_pos = div_up(header_len + (locint ? 8 + 16 : 0), 8192) * 8192;
+  const u64 cw_len = ((u64) g.cw_bits * g.nb + 7) / 8;
+  const u64 var_data_pos = cw_data_pos + cw_len;
+  g.cw_base_bit = cw_data_pos * 8;
+  g.var_base_bit = var_data_pos * 8;
   const u64 range_enc_pos = var_data_pos + var_bits_total / 8 + ((var_bits_total % 8) ? 1 : 0);
   const u64 file_bytes = range_enc_pos + 8 + 16 * (nregions + 1);
 
@@ -774,6 +794,29 @@ extern "C" int gtamd_pck_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa,
     return -1;
   }
   return gtamd_pck_build(p, bwt, suf, st.numberofallsortedsuffixes, sigma, st.longest, pp);
+}
+
+extern "C" int gtamd_pck_build_host(gtamd_pck *p, const uint8_t *bwt, const uint64_t *suf,
+                                    uint64_t total_len, uint32_t sigma, uint64_t longest,
+                                    const gtamd_pck_params *pp) {
+  if (p == nullptr || bwt == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build_host"); return -1; }
+  HIP_TRY(hipSetDevice(p->device));
+  u8 *d_bwt = nullptr;
+  u64 *d_suf = nullptr;
+  int rc = -1;
+  if (hipMalloc(&d_bwt, total_len) != hipSuccess ||
+      (suf != nullptr && hipMalloc(&d_suf, total_len * sizeof(u64)) != hipSuccess)) {
+    gtamd_set_error("packed index: cannot allocate device memory for the tables of %llu entries",
+                    (unsigned long long) total_len);
+  } else if (hipMemcpy(d_bwt, bwt, total_len, hipMemcpyHostToDevice) != hipSuccess ||
+             (suf != nullptr &&
+              hipMemcpy(d_suf, suf, total_len * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)) {
+    gtamd_set_error("packed index: cannot copy the tables to the device");
+  } else
+    rc = gtamd_pck_build(p, d_bwt, d_suf, total_len, sigma, longest, pp);
+  if (d_bwt) (void) hipFree(d_bwt);
+  if (d_suf) (void) hipFree(d_suf);
+  return rc;
 }
 
 extern "C" int gtamd_pck_get_info(const gtamd_pck *p, gtamd_pck_info *info) {

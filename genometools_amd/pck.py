@@ -53,19 +53,22 @@ class PackedIndex:
             pass
 
     @staticmethod
-    def _params(bsize, blbuck, locfreq, locbitmap):
+    def _params(bsize, blbuck, locfreq, locbitmap, mkindex):
         return PckParams(bsize, blbuck, locfreq,
-                         default_toggles(bsize, blbuck, locfreq, locbitmap))
+                         default_toggles(bsize, blbuck, locfreq, locbitmap), int(bool(mkindex)))
 
-    def build_from_esa(self, engine, bsize=8, blbuck=8, locfreq=16, locbitmap=None):
-        """from an EsaEngine whose last run produced .suf and .bwt"""
-        pp = self._params(bsize, blbuck, locfreq, locbitmap)
+    def build_from_esa(self, engine, bsize=8, blbuck=8, locfreq=16, locbitmap=None,
+                       mkindex=False):
+        """from an EsaEngine whose last run produced .suf and .bwt; mkindex: the
+        file of `gt packedindex mkindex` (with sequence statistics) instead of
+        the one of `gt packedindex trsuftab`"""
+        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex)
         check(self._lib.gtamd_pck_build_from_esa(self._p, engine._ctx, ctypes.byref(pp)))
 
     def build(self, bwt_ptr, suf_ptr, total_len, numofchars, longest, bsize=8, blbuck=8,
-              locfreq=16, locbitmap=None):
+              locfreq=16, locbitmap=None, mkindex=False):
         """from raw device pointers of the .bwt and .suf tables"""
-        pp = self._params(bsize, blbuck, locfreq, locbitmap)
+        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex)
         check(self._lib.gtamd_pck_build(self._p, bwt_ptr, suf_ptr, total_len, numofchars,
                                         longest, ctypes.byref(pp)))
 

@@ -249,6 +249,14 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen);
    device from the input indexes' INDEX.esq. */
 int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen);
 
+/* `gt packedindex trsuftab [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap
+   [yes|no]] [-v] INDEX` (tool function src/tools/gt_packedindex_trsuftab.c:44-79,
+   construction src/match/eis-bwtseq-construct.c:64-92): INDEX.bdx, the
+   block-compressed BWT of the packed index, from the project's INDEX.prj / .esq /
+   .bwt / .suf -- byte for byte the reference's file; built on
+   the device through include/gtamd_pck.h.  -sprank / -ctxilog are refused. */
+int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,14 @@ typedef struct {
   uint32_t bucket_blocks;    /* -blbuck  (default 8); block_size * bucket_blocks <= 16384 */
   uint32_t locate_interval;  /* -locfreq (default 16), 0 = no locate information */
   int32_t feature_toggles;   /* GTAMD_PCK_LOCATE_*; gtamd_pck_default_toggles() */
+  int32_t with_statistics;   /* 0: the file `gt packedindex trsuftab INDEX` writes (tables
+                                read back from files: the reference has no sequence
+                                statistics there), 1: the file `gt packedindex mkindex`
+                                writes (BWT straight from the suffixerator, with
+                                statistics: run_packedindexconstruction,
+                                src/match/sfx-run.c:369-425; they narrow the occurrence
+                                counters, src/match/eis-blockcomp.c:385-437, and one size
+                                bound, src/match/eis-bwtseq-extinfo.c:302-314) */
 } gtamd_pck_params;
 
 /* layout of the image, as the header fields of INDEX.bdx report it, and the
@@ -94,6 +102,13 @@ int gtamd_pck_build(gtamd_pck *pck, const uint8_t *bwt_device,
    GTAMD_WANT_BWT (whole-table build) */
 int gtamd_pck_build_from_esa(gtamd_pck *pck, const gtamd_esa_ctx *esa,
                              const gtamd_pck_params *params);
+
+/* the same from tables in HOST memory (read back from INDEX.bwt / INDEX.suf, as
+   `gt packedindex trsuftab` does): uploaded, then built as above */
+int gtamd_pck_build_host(gtamd_pck *pck, const uint8_t *bwt_host,
+                         const uint64_t *suf_host, uint64_t total_len,
+                         uint32_t numofchars, uint64_t longest,
+                         const gtamd_pck_params *params);
 
 int gtamd_pck_get_info(const gtamd_pck *pck, gtamd_pck_info *info);
 /* device pointer of the image (file_bytes bytes; valid until the next build /

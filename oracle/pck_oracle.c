@@ -156,6 +156,7 @@ typedef struct {
   int loc_bitmap, loc_count;
   uint64_t total_len, bucket_len;
   unsigned bits_per_ulong, comp_idx_bits, var_off_bits, cb_off_bits, bits_per_orig_pos;
+  const unsigned *sym_bits, *sym_off;
   uint64_t cw_ext_bits, pre_var_idx, pre_cb_off, pre_comp_idx, pre_cw_ext;
   uint64_t cw_data_pos, var_data_pos;
   /* struct appendState, eis-blockcomp.c:142-152 */
@@ -269,8 +270,7 @@ static void flush_bucket(pck_state *st, uint64_t len)
     unsigned s;
     uint64_t nbytes, vbytes;
     for (s = 0; s < st->sigma; s++)
-      bs_store(st->comp_cache, st->cw_mem_old + (uint64_t) s * st->bits_per_ulong,
-               st->bits_per_ulong, st->buck_last[s]);
+      bs_store(st->comp_cache, st->cw_mem_old + st->sym_off[s], st->sym_bits[s], st->buck_last[s]);
     bs_store(st->comp_cache, st->cw_mem_old + st->pre_var_idx, st->var_off_bits, st->var_disk_off);
     nbytes = st->cw_mem_pos / 8;
     out_pwrite(&st->o, st->cw_data_pos + st->cw_disk_off, st->comp_cache, (size_t) nbytes);
@@ -302,6 +302,8 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   uint64_t cw_ext_bits, max_var_ext_bits_per_bucket = 0, max_var_bits_total;
   uint64_t cw_bits, header_len, cw_data_pos, var_data_pos, cw_len, range_enc_pos;
   unsigned bits_per_orig_pos = 0, state_bits_per_ulong = 0;
+  unsigned sym_bits[256], sym_off[256];
+  uint64_t letter_count[256], regular = 0;
   pck_state st;
 
   if (!bsize || !bblocks || sigma < 1 || sigma > 250 || bsize > 20 || total_len < 2) return -1;
@@ -311,8 +313,22 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   /* gt_newGenBlockEncIdxSeq, eis-blockcomp.c:336-339 */
   bits_per_ulong = reqbits(total_len - 1);
   /* no sequence statistics on the trsuftab path (gt_initSuffixarrayFileInterface
-     passes none): symSumBitsDefaultSetup, eis-blockcomp.c:757-774 */
-  sym_sum_bits = sigma * bits_per_ulong;
+     passes none): symSumBitsDefaultSetup, eis-blockcomp.c:757-774; on the mkindex
+     path the counters are as wide as the number of occurrences of each letter
+     needs (eis-blockcomp.c:385-437; newSeqStatsFromCharDist,
+     eis-suffixerator-interface.c:176-206) */
+  {
+    unsigned s;
+    uint64_t i;
+    for (s = 0; s < sigma; s++) letter_count[s] = 0;
+    for (i = 0; i < total_len; i++) if (bwt[i] < sigma) { letter_count[bwt[i]]++; regular++; }
+    sym_sum_bits = 0;
+    for (s = 0; s < sigma; s++) {
+      sym_bits[s] = pp->with_statistics ? reqbits(letter_count[s]) : bits_per_ulong;
+      sym_off[s] = sym_sum_bits;
+      sym_sum_bits += sym_bits[s];
+    }
+  }
   /* gt_initCompositionList, eis-seqblocktranslate.c:168-183,244 */
   comp_idx_bits = reqbits(binom(bsize + sigma - 1, sigma - 1) - 1);
   max_perm_idx_bits = reqbits(max_perms(sigma, bsize) - 1);
@@ -330,7 +346,15 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
     if (locint > 1) {
       uint64_t std_marks = total_len / locint;
       uint64_t a = total_len / 2, b = total_len - std_marks;
-      extra = a < b ? a : b;                        /* no statistics: no third bound */
+      extra = a < b ? a : b;
+      if (pp->with_statistics) {
+        /* symbols outside the value-sorted range: wildcards, separators and the
+           undefined symbol before suffix 0, as newSeqStatsFromCharDist counts
+           them (eis-bwtseq-extinfo.c:302-314) */
+        uint64_t nonval = total_len - regular + 1, rest = total_len - nonval;
+        if (nonval < extra) extra = nonval;
+        if (rest < extra) extra = rest;
+      }
     }
     desc_rep[0] = (total_len + 1) / bucket_len; desc_len[0] = bucket_len;
     desc_rep[1] = ((total_len + 1) % bucket_len) ? 1 : 0; desc_len[1] = total_len % bucket_len;
@@ -358,6 +382,7 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   st.loc_bitmap = loc_bitmap; st.loc_count = loc_count;
   st.total_len = total_len; st.bucket_len = bucket_len;
   st.bits_per_ulong = bits_per_ulong; st.comp_idx_bits = comp_idx_bits;
+  st.sym_bits = sym_bits; st.sym_off = sym_off;
   st.var_off_bits = var_off_bits; st.cb_off_bits = cb_off_bits;
   st.bits_per_orig_pos = bits_per_orig_pos; st.cw_ext_bits = cw_ext_bits;
   st.pre_var_idx = sym_sum_bits; st.pre_cb_off = st.pre_var_idx + var_off_bits;
@@ -438,7 +463,7 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
     PUT32(0x53504254); PUT32(bits_per_ulong);
     PUT32(0x56444f42); PUT32(var_off_bits);
     PUT32(0x53534254); PUT32(sigma);
-    for (i = 0; i < sigma; i++) PUT32(bits_per_ulong);
+    for (i = 0; i < sigma; i++) PUT32(sym_bits[i]);
     PUT32(0x42454642); PUT32(0);
     PUT32(0x52454642); PUT32(0);
     PUT32(0x4e4d524e); PUT32(num_modes);

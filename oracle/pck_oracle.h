@@ -20,6 +20,9 @@ typedef struct {
   unsigned bucket_blocks;    /* -blbuck, default 8 */
   unsigned locate_interval;  /* -locfreq, default 16, 0 = no locate information */
   int feature_toggles;       /* ORA_PCK_LOCATE_* as gt_computePackedIndexDefaults chooses */
+  int with_statistics;       /* 0: `gt packedindex trsuftab` (tables from files, no
+                                sequence statistics), 1: `gt packedindex mkindex` (BWT
+                                from the suffixerator, with statistics) */
 } ora_pck_params;
 
 /* the feature toggles `gt packedindex` derives from its options

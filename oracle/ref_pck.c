@@ -15,8 +15,15 @@
   which we neither have nor fake).  Reads INDEX.prj/.esq/.suf/.bwt (written by
   oracle/_ref/gt_ref_sfx or by gt-suffixerator-amd), writes INDEX.bdx.
 
+  With -mkindex the index is built the way `gt packedindex mkindex` does
+  (gt_runsuffixerator(false, ...) -> run_packedindexconstruction,
+  src/match/sfx-run.c:369-425): the BWT comes from the suffixerator itself
+  through the sfxInterface, which also supplies sequence statistics (they
+  change the widths of the occurrence counters and one size bound); INDEX.esq
+  must exist (written by gt_ref_sfx).
+
   usage: gt_ref_pck [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap yes|no]
-                    INDEX
+                    [-mkindex] INDEX
 */
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,12 +43,17 @@
 #include "match/eis-bwtseq-param.h"
 #include "match/eis-bwtseq-context-param.h"
 #include "match/eis-encidxseq.h"
+#include "match/eis-suffixerator-interface.h"
+#include "match/sfx-apfxlen.h"
+#include "match/sfx-strategy.h"
+#include "core/alphabet_api.h"
+#include "core/encseq_api.h"
 
 int main(int argc, char **argv)
 {
   struct bwtParam params;
   unsigned bsize = 8, blbuck = 8, locfreq = 16;
-  int locbitmap = -1, i;
+  int locbitmap = -1, i, mkindex = 0;
   const char *index = NULL;
   GtError *err;
   GtLogger *logger;
@@ -53,6 +65,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-blbuck") && i + 1 < argc) blbuck = (unsigned) atoi(argv[++i]);
     else if (!strcmp(argv[i], "-locfreq") && i + 1 < argc) locfreq = (unsigned) atoi(argv[++i]);
     else if (!strcmp(argv[i], "-locbitmap") && i + 1 < argc) locbitmap = !strcmp(argv[++i], "yes");
+    else if (!strcmp(argv[i], "-mkindex")) mkindex = 1;
     else if (argv[i][0] != '-') index = argv[i];
     else { fprintf(stderr, "gt_ref_pck: unknown option %s\n", argv[i]); return 2; }
   }
@@ -90,7 +103,42 @@ int main(int argc, char **argv)
       params.featureToggles |= BWTLocateBitmap;
   }
   logger = gt_logger_new(false, GT_LOGGER_DEFLT_PREFIX, stdout);
-  bwtSeq = gt_trSuftab2BWTSeq(&params, logger, err);
+  if (!mkindex)
+    bwtSeq = gt_trSuftab2BWTSeq(&params, logger, err);
+  else {
+    /* run_packedindexconstruction, src/match/sfx-run.c:369-425 */
+    GtEncseqLoader *el = gt_encseq_loader_new();
+    GtEncseq *encseq;
+    Sfxstrategy strategy;
+    sfxInterface *si;
+    unsigned int numofchars, prefixlength;
+    gt_encseq_loader_disable_autosupport(el);
+    gt_encseq_loader_do_not_require_des_tab(el);
+    gt_encseq_loader_do_not_require_sds_tab(el);
+    gt_encseq_loader_do_not_require_ssp_tab(el);
+    encseq = gt_encseq_loader_load(el, index, err);
+    gt_encseq_loader_delete(el);
+    if (encseq == NULL) {
+      fprintf(stderr, "gt_ref_pck: error: %s\n", gt_error_get(err));
+      return 1;
+    }
+    numofchars = gt_alphabet_num_of_chars(gt_encseq_alphabet(encseq));
+    if (numofchars > 10U && params.seqParams.encParams.blockEnc.blockSize > 3U)
+      params.seqParams.encParams.blockEnc.blockSize = 3U;
+    prefixlength = gt_recommendedprefixlength(numofchars, gt_encseq_total_length(encseq),
+                                              GT_RECOMMENDED_MULTIPLIER_DEFAULT, true);
+    defaultsfxstrategy(&strategy, gt_encseq_bitwise_cmp_ok(encseq) ? false : true);
+    si = gt_newSfxInterface(GT_READMODE_FORWARD, prefixlength, 1U, 0UL, &strategy, encseq,
+                            NULL, false, gt_encseq_total_length(encseq) + 1, logger, err);
+    bwtSeq = si != NULL ? gt_createBWTSeqFromSfxI(&params, si, err) : NULL;
+    if (bwtSeq != NULL) {
+      printf("featureToggles=%d\n", params.featureToggles);
+      gt_deleteBWTSeq(bwtSeq);
+      gt_deleteSfxInterface(si);
+      gt_encseq_delete(encseq);
+      return 0;
+    }
+  }
   if (!bwtSeq) {
     fprintf(stderr, "gt_ref_pck: error: %s\n", gt_error_is_set(err) ? gt_error_get(err) : "?");
     return 1;

@@ -53,13 +53,14 @@ def md5(path):
         return hashlib.md5(f.read()).hexdigest()
 
 
-def key(name, opts):
+def key(name, opts, mkindex=False):
     b, k, f, bm = opts
     return "%s|bsize=%d|blbuck=%d|locfreq=%d|locbitmap=%s" % (
-        name, b, k, f, {None: "auto", True: "yes", False: "no"}[bm])
+        name, b, k, f, {None: "auto", True: "yes", False: "no"}[bm]) + \
+        ("|mode=mkindex" if mkindex else "")
 
 
-def run_case(tmp, name, protein, opts):
+def run_case(tmp, name, protein, opts, mkindex=False):
     src = os.path.join(OUT, "fixtures", name) if not name.startswith("extra/") \
         else os.path.join(OUT, name)
     idx = os.path.join(tmp, "idx")
@@ -71,6 +72,10 @@ def run_case(tmp, name, protein, opts):
     cmd = [PCK, "-bsize", str(b), "-blbuck", str(k), "-locfreq", str(f)]
     if bm is not None:
         cmd += ["-locbitmap", "yes" if bm else "no"]
+    if mkindex:
+        # the construction of `gt packedindex mkindex`: BWT from the suffixerator
+        # interface, with sequence statistics (src/match/sfx-run.c:369-425)
+        cmd.append("-mkindex")
     out = subprocess.run(cmd + [idx], check=True, capture_output=True, text=True).stdout
     toggles = int(out.split("featureToggles=")[1].split()[0])
     return {"md5": md5(idx + ".bdx"), "size": os.path.getsize(idx + ".bdx"),
@@ -90,6 +95,14 @@ def main():
         for name, sets in PROTEIN:
             for opts in sets:
                 golden[key(name, opts)] = run_case(tmp, name, True, opts)
+        # mkindex flavour (statistics): the suite's "simple sequences" with the
+        # defaults and without locate information, the protein sample with -bsize 1
+        for name in DNA:
+            for opts in (OPTION_SETS[:4] if name != "Atinsert.fna" else OPTION_SETS):
+                golden[key(name, opts, True)] = run_case(tmp, name, False, opts, True)
+        for name, sets in PROTEIN:
+            for opts in sets:
+                golden[key(name, opts, True)] = run_case(tmp, name, True, opts, True)
     with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("%d packed-index goldens" % len(golden))

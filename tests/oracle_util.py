@@ -36,7 +36,8 @@ class EsaStats(ctypes.Structure):
 
 class PckParams(ctypes.Structure):
     _fields_ = [("block_size", ctypes.c_uint), ("bucket_blocks", ctypes.c_uint),
-                ("locate_interval", ctypes.c_uint), ("feature_toggles", ctypes.c_int)]
+                ("locate_interval", ctypes.c_uint), ("feature_toggles", ctypes.c_int),
+                ("with_statistics", ctypes.c_int)]
 
 
 _lib = None
@@ -217,14 +218,17 @@ def pck_default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None):
                                          -1 if locbitmap is None else int(locbitmap))
 
 
-def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=None):
-    """bytes of INDEX.bdx (`gt packedindex trsuftab`) by the oracle's restatement"""
+def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=None,
+            mkindex=False):
+    """bytes of INDEX.bdx by the oracle's restatement: as `gt packedindex
+    trsuftab` writes it, or (mkindex) as `gt packedindex mkindex` does"""
     L = lib()
     enc = np.ascontiguousarray(enc, dtype=np.uint8)
     suf = np.ascontiguousarray(suf, dtype=np.uint64)
     bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
     longest = int(np.flatnonzero(suf == 0)[0])
-    pp = PckParams(bsize, blbuck, locfreq, pck_default_toggles(bsize, blbuck, locfreq, locbitmap))
+    pp = PckParams(bsize, blbuck, locfreq, pck_default_toggles(bsize, blbuck, locfreq, locbitmap),
+                   int(mkindex))
     out, n = ctypes.c_void_p(), ctypes.c_size_t()
     rc = L.ora_pck_bdx(_p(bwt), _p(suf), _p(enc), enc.size + 1, numofchars, longest,
                        ctypes.byref(pp), ctypes.byref(out), ctypes.byref(n))
@@ -244,6 +248,8 @@ def parse_pck_key(key):
     """'name|bsize=..|blbuck=..|locfreq=..|locbitmap=auto' -> (name, kwargs)"""
     parts = key.split("|")
     kw = dict(p.split("=") for p in parts[1:])
-    return parts[0], dict(bsize=int(kw["bsize"]), blbuck=int(kw["blbuck"]),
-                          locfreq=int(kw["locfreq"]),
-                          locbitmap={"auto": None, "yes": True, "no": False}[kw["locbitmap"]])
+    out = dict(bsize=int(kw["bsize"]), blbuck=int(kw["blbuck"]), locfreq=int(kw["locfreq"]),
+               locbitmap={"auto": None, "yes": True, "no": False}[kw["locbitmap"]])
+    if kw.get("mode") == "mkindex":
+        out["mkindex"] = True
+    return parts[0], out

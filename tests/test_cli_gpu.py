@@ -386,3 +386,32 @@ def test_mergeesa_equals_suffixerator_over_all_files(cli, files, tmp_path):
     r = subprocess.run([cli, "mergeesa", "-indexname", str(tmp_path / "x"), "-ii"] + idx,
                        capture_output=True, text=True)
     assert r.returncode == 1 and "gt dev mergeesa: error: cannot open file" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["Atinsert.fna", "Duplicate.fna", "sw100K2.fsa"])
+def test_packedindex_trsuftab_writes_the_reference_file(cli, name, tmp_path):
+    """`gt packedindex trsuftab` on a project written by the suffixerator tool:
+    INDEX.bdx equals the file the reference wrote (tests/golden/golden_pck.json)"""
+    golden = ou.golden_pck()
+    protein = name.endswith(".fsa")
+    idx = str(tmp_path / "pidx")
+    subprocess.run([cli, "-protein" if protein else "-dna", "-suf", "-bwt", "-indexname", idx,
+                    "-db", ou.fixture_path(name)], check=True)
+    for key in sorted(k for k in golden if k.split("|")[0] == name and "mode=" not in k):
+        _, kw = ou.parse_pck_key(key)
+        args = ["-bsize", str(kw["bsize"]), "-blbuck", str(kw["blbuck"]), "-locfreq", str(kw["locfreq"])]
+        if kw["locbitmap"] is not None:
+            args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]
+        if os.path.exists(idx + ".bdx"):
+            os.remove(idx + ".bdx")
+        out = subprocess.run([cli, "packedindex", "trsuftab", "-v"] + args + [idx], check=True,
+                             capture_output=True, text=True).stdout
+        assert "buckets" in out
+        with open(idx + ".bdx", "rb") as f:
+            raw = f.read()
+        assert len(raw) == golden[key]["size"], key
+        assert hashlib.md5(raw).hexdigest() == golden[key]["md5"], key
+    # without the .bwt table the tool says what it needs
+    os.remove(idx + ".bwt")
+    r = subprocess.run([cli, "packedindex", "trsuftab", idx], capture_output=True, text=True)
+    assert r.returncode == 1 and "gt packedindex trsuftab: error:" in r.stderr and ".bwt" in r.stderr

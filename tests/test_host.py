@@ -633,3 +633,29 @@ def test_mergeesa_option_errors(host, tmp_path):
     assert rc == -1 and "cannot open file" in msg and "nothere.suf" in msg
     rc, msg = run("-frobnicate")
     assert rc == -1 and "unknown option" in msg
+
+
+def test_packedindex_trsuftab_option_errors(host, tmp_path):
+    """`gt packedindex trsuftab` (include/gtamd_host.h gtamd_packedindex_trsuftab):
+    options and unreadable projects are reported before any device is touched"""
+    host.gtamd_packedindex_trsuftab.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                                ctypes.c_char_p, ctypes.c_size_t]
+
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"trsuftab", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        return host.gtamd_packedindex_trsuftab(len(args) + 1, argv, err, 2048), err.value.decode()
+
+    assert run()[0] == -1
+    rc, msg = run("-frobnicate", "x")
+    assert rc == -1 and "unknown option" in msg
+    rc, msg = run("-bsize")
+    assert rc == -1 and "missing argument" in msg
+    rc, msg = run("-bsize", "0", "x")
+    assert rc == -1 and '"-bsize" must be an integer >= 1' in msg
+    rc, msg = run("-sprank", "x")
+    assert rc == -1 and "not supported" in msg
+    rc, msg = run(str(tmp_path / "nothere"))
+    assert rc == -1 and "nothere.prj" in msg
+    rc, msg = run("a", "b")
+    assert rc == -1 and "superfluous" in msg

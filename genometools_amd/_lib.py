@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in
            ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip", "esa_encode.hip",
             "esa_pck.hip")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h")] + \
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h", "esa_msd.h",
+                                                     "esa_pck_replay.h")] + \
           [os.path.join(ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h", "gtamd_pck.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 

@@ -23,6 +23,7 @@
 #include <vector>
 #include "esa_common.h"
 #include "esa_devutil.h"
+#include "esa_pck_replay.h"
 #include "../../include/gtamd_pck.h"
 
 // from esa_engine.hip
@@ -35,6 +36,7 @@ constexpr int PCK_THREADS = 256;
 constexpr u32 PCK_TILE_POS = 16384;     // positions a tile stages in LDS at most
 constexpr u32 PCK_MAX_SIGMA = 30;
 constexpr u32 PCK_EXTRA_COLS = 3;       // var bits, region starts, region ends
+constexpr u64 PCK_TAIL_RECORDS = 65536; // var offsets of the last buckets kept for the replay
 constexpr u32 LDS_SPECIAL = 30;         // LDS code of the wildcard; separator 31
 constexpr u32 LDS_MARK = 0x40;
 
@@ -129,6 +131,9 @@ __global__ void k_pck_lut(u64 entries, u32 sigma, u32 B, u64 *lut) {
 // ---- bit strings, most significant bit first ---------------------------------
 __device__ __forceinline__ void put_bits(u64 *img, u64 bit, u32 nbits, u64 v) {
   if (nbits == 0) return;
+  // the reference's gt_bsStore* keep the low nbits bits of a value that does not
+  // fit (its size bound for the var part can be too small)
+  if (nbits < 64) v &= (1ull << nbits) - 1;
   const u64 w = bit >> 6;
   const u32 o = (u32) (bit & 63);
   if (o + nbits <= 64) {
@@ -158,7 +163,8 @@ __global__ void k_pck_count_specials(const u8 *bwt, u64 N, unsigned long long *o
 template <bool EMIT>
 __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     PckGeom g, const u8 *__restrict__ bwt, const u64 *__restrict__ suf,
-    const u64 *__restrict__ lut, u64 *tile_tot, u64 *img, u64 *rstart, u64 *rend) {
+    const u64 *__restrict__ lut, u64 *tile_tot, u64 *img, u64 *rstart, u64 *rend,
+    u64 *tail_off, u64 tail_first) {
   extern __shared__ u8 smem[];
   __shared__ u32 s4[4];
   const u32 tid = threadIdx.x;
@@ -268,6 +274,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
 
   const u64 var_off = tile_tot[(u64) g.sigma * g.ntiles + tile] + var_ex;
   put_bits(img, cwbit + g.pre_var_idx, g.var_off_bits, var_off);
+  if (bucket >= tail_first) tail_off[bucket - tail_first] = var_off;   // for the replay of the last records
   if (g.locint) put_bits(img, cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
   u64 vbit = g.var_base_bit + var_off;
   u64 ridx_s = tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] + st_ex;
@@ -385,6 +392,7 @@ struct gtamd_pck {
   u64 *tile_tot; u64 tile_tot_cap;
   u64 *rlist; u64 rlist_cap;
   u64 *d_totals;
+  u64 *d_tail;
   gtamd_pck_info info;
   bool built;
 };
@@ -411,7 +419,8 @@ extern "C" gtamd_pck *gtamd_pck_create(int device) {
   p->device = device;
   if (hipStreamCreate(&p->st) != hipSuccess || hipEventCreate(&p->ev0) != hipSuccess ||
       hipEventCreate(&p->ev1) != hipSuccess ||
-      hipMalloc(&p->d_totals, (PCK_MAX_SIGMA + 8) * sizeof(u64)) != hipSuccess) {
+      hipMalloc(&p->d_totals, (PCK_MAX_SIGMA + 8) * sizeof(u64)) != hipSuccess ||
+      hipMalloc(&p->d_tail, PCK_TAIL_RECORDS * sizeof(u64)) != hipSuccess) {
     gtamd_set_error("cannot create the packed-index builder on device %d", device);
     delete p;
     return nullptr;
@@ -428,6 +437,7 @@ extern "C" void gtamd_pck_destroy(gtamd_pck *p) {
   if (p->tile_tot) (void) hipFree(p->tile_tot);
   if (p->rlist) (void) hipFree(p->rlist);
   if (p->d_totals) (void) hipFree(p->d_totals);
+  if (p->d_tail) (void) hipFree(p->d_tail);
   (void) hipEventDestroy(p->ev0);
   (void) hipEventDestroy(p->ev1);
   (void) hipStreamDestroy(p->st);
@@ -447,127 +457,27 @@ template <typename T> static int grow(T **buf, u64 *cap, u64 need_bytes) {
   return 0;
 }
 
-// ---- the bits the reference leaves stale in the last bucket --------------------
-// The reference assembles a bucket in a staging buffer that is never cleared,
-// writes the whole bytes to the file and moves the incomplete last byte to the
-// front (updateIdxOutput, eis-blockcomp.c:1807-1886).  Bits of the last
-// bucket's record that are not stored explicitly (composition indices of
-// blocks that do not exist, locate bits behind the end) and the unused bits of
-// the final byte keep what an earlier bucket left at that place of the buffer.
-// This replays the buffer for the last records of a bit string, from the
-// image's own bytes, tracking which bits are known, and returns the bytes the
-// reference wrote last.
-struct StaleRec { u64 gbit, nbits; };    // record: start in the stream, bits the buffer position advances by
-namespace {
-struct Replay {
-  std::vector<u8> buf, known;   // one entry per BIT (0/1), simple and small
-};
-// stream: bytes of the bit string from byte `stream_byte0` on (host copy)
-// recs: consecutive records, the last one is the last of the stream;
-// explicit_last: bit ranges (relative to the record start) the last record stores
-// out: bytes from byte (recs.back().gbit / 8) to the end of what the reference writes
-// returns false when a needed bit is unknown (window too small)
-bool replay_tail(const std::vector<u8> &stream, u64 stream_byte0, const std::vector<StaleRec> &recs,
-                 const std::vector<std::pair<u64, u64>> &explicit_last, bool from_stream_start,
-                 std::vector<u8> *out) {
-  u64 maxbits = 16;
-  for (const StaleRec &r : recs) maxbits = std::max(maxbits, (r.gbit & 7) + r.nbits + 16);
-  std::vector<u8> bit(maxbits, 0), kn(maxbits, from_stream_start ? 1 : 0);
-  auto stream_bit = [&](u64 gb) -> u8 {
-    const u64 byte = (gb >> 3) - stream_byte0;
-    return (stream[byte] >> (7 - (gb & 7))) & 1u;
-  };
-  for (size_t j = 0; j < recs.size(); j++) {
-    const StaleRec &r = recs[j];
-    const u64 old = r.gbit & 7;
-    const bool last = j + 1 == recs.size();
-    // the front byte carries the true tail of the record before
-    for (u64 q = 0; q < old; q++) { bit[q] = stream_bit(r.gbit - old + q); kn[q] = 1; }
-    if (!last) {
-      for (u64 q = 0; q < r.nbits; q++) { bit[old + q] = stream_bit(r.gbit + q); kn[old + q] = 1; }
-    } else {
-      for (const auto &rg : explicit_last)
-        for (u64 q = rg.first; q < rg.first + rg.second; q++) { bit[old + q] = stream_bit(r.gbit + q); kn[old + q] = 1; }
-    }
-    const u64 end = old + r.nbits, nbytes = end / 8;
-    if (last) {
-      const u64 total_bits = (end % 8) ? (nbytes + 1) * 8 : nbytes * 8;
-      out->assign((size_t) (total_bits / 8), 0);
-      for (u64 q = 0; q < total_bits; q++) {
-        // the final incomplete byte is written from the front of the buffer
-        // after the move; its bits are those of buffer byte nbytes
-        if (!kn[q]) return false;
-        if (bit[q]) (*out)[(size_t) (q >> 3)] |= (u8) (0x80u >> (q & 7));
-      }
-      return true;
-    }
-    if (end % 8)
-      for (u64 q = 0; q < 8; q++) { bit[q] = bit[nbytes * 8 + q]; kn[q] = kn[nbytes * 8 + q]; }
-  }
-  return true;
+// ---- the bits the reference leaves stale in the last bucket: esa_pck_replay.h --
+static int img_read(void *user, uint64_t offset, uint64_t count, uint8_t *dst) {
+  gtamd_pck *p = (gtamd_pck *) user;
+  return hipMemcpy(dst, p->img + offset, count, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
-}  // namespace
-
-static u64 get_bits_host(const std::vector<u8> &s, u64 bit, u32 nbits) {
-  u64 v = 0;
-  for (u32 i = 0; i < nbits; i++) { const u64 b = bit + i; v = (v << 1) | ((s[(size_t) (b >> 3)] >> (7 - (b & 7))) & 1u); }
-  return v;
+static int img_write(void *user, uint64_t offset, uint64_t count, const uint8_t *src) {
+  gtamd_pck *p = (gtamd_pck *) user;
+  return hipMemcpy(p->img + offset, src, count, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
 }
-
-static int fix_stale_bits(gtamd_pck *p, const PckGeom &g, u64 var_bits_total) {
-  const u64 cw_data_pos = g.cw_base_bit / 8, var_data_pos = g.var_base_bit / 8;
-  const u64 last = g.nb - 1;
-  const u64 last_pos = last * g.L;
-  const u32 len_last = (u32) (g.N - last_pos);
-  const u32 nblk_last = (len_last + g.B - 1) / g.B;
-  // bits by which the buffer position advances for the last cw record: the full
-  // record when the locate callback runs (appendCallBackOutput sets the position
-  // behind the extension bits), else up to the last composition index stored
-  const u64 last_cw_adv = g.locint ? g.cw_bits : (u64) g.pre_comp_idx + (u64) nblk_last * g.comp_idx_bits;
-  for (u64 window = 64; ; window *= 4) {
-    const u64 j0 = last + 1 > window ? last + 1 - window : 0;
-    // ---- cw records
-    const u64 cw_first_byte = (j0 * g.cw_bits) / 8;
-    const u64 cw_end_bit = last * g.cw_bits + g.cw_bits;
-    const u64 cw_bytes = (cw_end_bit + 7) / 8 + 1 - cw_first_byte;
-    std::vector<u8> cws((size_t) cw_bytes + 8, 0);
-    {
-      const u64 avail = std::min<u64>(cw_bytes, var_data_pos - (cw_data_pos + cw_first_byte));
-      HIP_TRY(hipMemcpy(cws.data(), p->img + cw_data_pos + cw_first_byte, avail, hipMemcpyDeviceToHost));
-    }
-    std::vector<StaleRec> recs;
-    for (u64 j = j0; j <= last; j++) recs.push_back({j * g.cw_bits, j == last ? last_cw_adv : (u64) g.cw_bits});
-    std::vector<std::pair<u64, u64>> ex;
-    ex.push_back({0, (u64) g.pre_comp_idx + (u64) nblk_last * g.comp_idx_bits});
-    if (g.locint && g.loc_bitmap) ex.push_back({g.pre_cw_ext, len_last});
-    std::vector<u8> tail;
-    const bool ok_cw = replay_tail(cws, cw_first_byte, recs, ex, j0 == 0, &tail);
-    // ---- var parts: offsets from the cw records themselves
-    std::vector<StaleRec> vrecs;
-    for (u64 j = j0; j <= last; j++) {
-      const u64 off = get_bits_host(cws, j * g.cw_bits + g.pre_var_idx - cw_first_byte * 8, g.var_off_bits);
-      vrecs.push_back({off, 0});
-    }
-    for (size_t k = 0; k < vrecs.size(); k++)
-      vrecs[k].nbits = (k + 1 < vrecs.size() ? vrecs[k + 1].gbit : var_bits_total) - vrecs[k].gbit;
-    const u64 var_first_byte = vrecs[0].gbit / 8;
-    const u64 var_bytes = (var_bits_total + 7) / 8 - var_first_byte;
-    std::vector<u8> vs((size_t) var_bytes + 8, 0), vtail;
-    if (var_bytes)
-      HIP_TRY(hipMemcpy(vs.data(), p->img + var_data_pos + var_first_byte, var_bytes, hipMemcpyDeviceToHost));
-    std::vector<std::pair<u64, u64>> vex;
-    vex.push_back({0, vrecs.back().nbits});
-    const bool ok_var = replay_tail(vs, var_first_byte, vrecs, vex, j0 == 0, &vtail);
-    if ((!ok_cw || !ok_var) && j0 > 0) continue;
-    if (!ok_cw || !ok_var) { gtamd_set_error("packed index: replay of the staging buffers failed"); return -1; }
-    if (!tail.empty())
-      HIP_TRY(hipMemcpy(p->img + cw_data_pos + (last * g.cw_bits) / 8, tail.data(), tail.size(), hipMemcpyHostToDevice));
-    // the var part of the last bucket is written before the region list, whose
-    // first bytes follow the final byte: the final byte only
-    if (!vtail.empty())
-      HIP_TRY(hipMemcpy(p->img + var_data_pos + vrecs.back().gbit / 8, vtail.data(), vtail.size(), hipMemcpyHostToDevice));
-    return 0;
-  }
+static int fix_stale_bits(gtamd_pck *p, const PckGeom &g, u64 var_bits_total,
+                          const std::vector<u64> &tail_off) {
+  PckTailGeom t;
+  t.N = g.N; t.nb = g.nb; t.L = g.L; t.B = g.B; t.locint = g.locint; t.loc_bitmap = g.loc_bitmap;
+  t.cw_bits = g.cw_bits; t.pre_comp_idx = g.pre_comp_idx; t.pre_cw_ext = g.pre_cw_ext;
+  t.comp_idx_bits = g.comp_idx_bits;
+  t.cw_data_pos = g.cw_base_bit / 8; t.var_data_pos = g.var_base_bit / 8;
+  const int rc = pck_fix_stale_bits(t, var_bits_total, tail_off, img_read, img_write, p);
+  if (rc == -1) gtamd_set_error("packed index: cannot copy the tail of the image between device and host");
+  if (rc == -2) gtamd_set_error("packed index: the replay of the staging buffers needs more than the last %llu buckets",
+                                (unsigned long long) tail_off.size());
+  return rc == 0 ? 0 : -1;
 }
 
 extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t *suf,
@@ -651,7 +561,8 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   g.first_special_row = total_len - nspecial;
 
   const size_t lds = (((size_t) g.T * g.LP + 15) & ~(size_t) 15) + (size_t) sigma * g.T * sizeof(u16);
-  k_pck_tile<false><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, nullptr, nullptr, nullptr);
+  k_pck_tile<false><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, nullptr, nullptr, nullptr,
+                                                          nullptr, 0);
   HIP_TRY(hipGetLastError());
   k_pck_scan_cols<<<(u32) ncols, PCK_THREADS, 0, p->st>>>(p->tile_tot, g.ntiles, p->d_totals);
   HIP_TRY(hipGetLastError());
@@ -722,8 +633,10 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   TRY(grow(&p->rlist, &rl_cap, std::max<u64>(1, nregions) * 2 * sizeof(u64)));
   p->rlist_cap = rl_cap;
   HIP_TRY(hipMemsetAsync(p->img, 0, ((file_bytes + 7) & ~7ull) + 64, p->st));
+  const u64 tail_n = std::min<u64>(g.nb, PCK_TAIL_RECORDS);
   k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
-                                                         p->rlist, p->rlist + std::max<u64>(1, nregions));
+                                                         p->rlist, p->rlist + std::max<u64>(1, nregions),
+                                                         p->d_tail, g.nb - tail_n);
   HIP_TRY(hipGetLastError());
   k_pck_regions<<<(u32) div_up(nregions + 1, 256), 256, 0, p->st>>>(
       p->rlist, p->rlist + std::max<u64>(1, nregions), nregions, total_len, B, p->img + range_enc_pos + 8);
@@ -767,7 +680,11 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
     const u64 nr = nregions + 1;
     HIP_TRY(hipMemcpy(p->img + range_enc_pos, &nr, 8, hipMemcpyHostToDevice));
   }
-  TRY(fix_stale_bits(p, g, var_bits_total));
+  {
+    std::vector<u64> tail_off((size_t) tail_n);
+    HIP_TRY(hipMemcpy(tail_off.data(), p->d_tail, tail_n * sizeof(u64), hipMemcpyDeviceToHost));
+    TRY(fix_stale_bits(p, g, var_bits_total, tail_off));
+  }
 
   memset(&p->info, 0, sizeof p->info);
   p->info.file_bytes = file_bytes; p->info.cw_data_pos = cw_data_pos; p->info.var_data_pos = var_data_pos;

@@ -285,6 +285,11 @@ static void flush_bucket(pck_state *st, uint64_t len)
   }
 }
 
+static uint64_t last_var_bits;
+/* bits of the variable-width part of the last file made (for tests of the
+   product's own replay of the staging buffers) */
+uint64_t ora_pck_last_var_bits(void) { return last_var_bits; }
+
 int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
                 uint64_t total_len, unsigned sigma, uint64_t longest,
                 const ora_pck_params *pp, uint8_t **out, size_t *out_len)
@@ -424,6 +429,7 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   if (st.cw_mem_old) { out_pwrite(&st.o, cw_data_pos + st.cw_disk_off, st.comp_cache, 1); st.cw_disk_off++; }
   if (st.var_mem_old) out_pwrite(&st.o, var_data_pos + st.var_disk_off / 8, st.perm_cache, 1);
   range_enc_pos = var_data_pos + st.var_disk_off / 8 + ((st.var_disk_off % 8) ? 1 : 0);
+  last_var_bits = st.var_disk_off;
   {
     /* gt_SRLSaveToStream, eis-seqranges.c:459-468, after the terminator region
        just beyond the sequence (symbol 0 of the range alphabet) */

@@ -80,6 +80,7 @@ def lib():
         L.ora_pck_bdx.argtypes = [P, P, P, U64, ctypes.c_uint, U64, ctypes.POINTER(PckParams),
                                   ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]
         L.ora_pck_free.argtypes = [P]
+        L.ora_pck_last_var_bits.restype = U64
         _lib = L
     return _lib
 

@@ -1,0 +1,124 @@
+"""Host logic of the packed-index builder without a GPU: the replay of the
+reference's staging buffers (genometools_amd/csrc/esa_pck_replay.h, the code
+esa_pck.hip runs on the tail of the device image) compiled with g++ and run on
+images made by the oracle, whose stale bits are zeroed first: it has to bring
+back the file the reference wrote (tests/golden/golden_pck.json)."""
+import ctypes
+import hashlib
+import math
+import os
+import struct
+import subprocess
+
+import pytest
+
+import oracle_util as ou
+
+ROOT = ou.ROOT
+SHIM_SRC = os.path.join(ROOT, "tests", "pck_replay_shim.cpp")
+HEADER = os.path.join(ROOT, "genometools_amd", "csrc", "esa_pck_replay.h")
+SHIM = os.path.join(ROOT, "oracle", "_build", "libpck_replay_shim.so")
+GOLDEN = ou.golden_pck()
+
+
+class TailGeom(ctypes.Structure):      # PckTailGeom
+    _fields_ = [("N", ctypes.c_uint64), ("nb", ctypes.c_uint64)] + \
+               [(k, ctypes.c_uint32) for k in ("L", "B", "locint", "loc_bitmap", "cw_bits",
+                                               "pre_comp_idx", "pre_cw_ext", "comp_idx_bits")] + \
+               [("cw_data_pos", ctypes.c_uint64), ("var_data_pos", ctypes.c_uint64)]
+
+
+@pytest.fixture(scope="module")
+def shim():
+    ou.build()
+    if (not os.path.exists(SHIM) or
+            max(os.path.getmtime(SHIM_SRC), os.path.getmtime(HEADER)) > os.path.getmtime(SHIM)):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-shared", "-fPIC", "-o", SHIM,
+                        SHIM_SRC], check=True)
+    lib = ctypes.CDLL(SHIM)
+    lib.pck_replay_run.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(TailGeom),
+                                   ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]
+    return lib
+
+
+_tables = {}
+
+
+def _project(name):
+    if name not in _tables:
+        protein = name.endswith((".fsa", ".faa"))
+        enc = ou.encode_fasta(ou.fixture_path(name), protein)
+        r = ou.esa(enc, 20 if protein else 4)
+        _tables[name] = (enc, 20 if protein else 4, r["suf"], r["bwt"])
+    return _tables[name]
+
+
+def _reqbits(v):
+    return max(1, int(v).bit_length())
+
+
+def _geometry(raw, sigma, locfreq):
+    """layout of an INDEX.bdx from its own header (src/match/eis-blockcomp.c:1984-2094)"""
+    def u32(o):
+        return struct.unpack_from("<I", raw, o)[0]
+
+    def u64(o):
+        return struct.unpack_from("<Q", raw, o)[0]
+    B, K, voff, N, vdob, ss = u32(12), u32(20), u64(28), u64(52), u32(72), u32(80)
+    symbits = [u32(84 + 4 * i) for i in range(ss)]
+    o = 84 + 4 * ss + 32
+    cb, cex = (u32(o + 4), u64(o + 12)) if u32(o) == 0x43424d42 else (0, 0)
+    g = TailGeom()
+    g.N, g.B, g.L = N, B, B * K
+    g.nb = (N + 1) // g.L + (1 if (N + 1) % g.L else 0)
+    g.locint, g.loc_bitmap = locfreq, 1 if cex else 0
+    g.comp_idx_bits = _reqbits(math.comb(B + sigma - 1, sigma - 1) - 1)
+    g.pre_comp_idx = sum(symbits) + vdob + cb
+    g.pre_cw_ext = g.pre_comp_idx + g.comp_idx_bits * K
+    g.cw_bits = g.pre_cw_ext + cex
+    g.cw_data_pos, g.var_data_pos = u32(4), voff
+    return g, sum(symbits), vdob
+
+
+@pytest.mark.parametrize("key", sorted(GOLDEN))
+def test_replay_restores_the_reference_file(key, shim):
+    name, kw = ou.parse_pck_key(key)
+    enc, sigma, suf, bwt = _project(name)
+    raw = ou.pck_bdx(enc, sigma, suf, bwt, **kw)
+    var_bits = ou.lib().ora_pck_last_var_bits()
+    g, pre_var_idx, vdob = _geometry(raw, sigma, kw["locfreq"])
+    # true offsets of the var parts: the fields, unwrapped where the reference
+    # lost high bits
+    cw = int.from_bytes(raw[g.cw_data_pos:g.var_data_pos], "big")
+    nbits = (g.var_data_pos - g.cw_data_pos) * 8
+    tail, prev = [], 0
+    for j in range(g.nb):
+        v = (cw >> (nbits - (j * g.cw_bits + pre_var_idx) - vdob)) & ((1 << vdob) - 1)
+        while v < prev:
+            v += 1 << vdob
+        tail.append(v)
+        prev = v
+    tail = tail[-65536:]
+    # an image as the device kernels leave it: nothing in the places the last
+    # bucket does not store explicitly, nothing behind the end of the bit strings
+    img = bytearray(raw)
+    last = g.nb - 1
+    len_last = g.N - last * g.L
+    nblk_last = (len_last + g.B - 1) // g.B
+
+    def clear(stream_pos, first_bit, end_bit):
+        for b in range(first_bit, end_bit):
+            img[stream_pos + b // 8] &= 0xff ^ (0x80 >> (b % 8))
+    rec = last * g.cw_bits
+    cw_end = rec + (g.cw_bits if g.locint else g.pre_comp_idx + nblk_last * g.comp_idx_bits)
+    clear(g.cw_data_pos, rec + g.pre_comp_idx + nblk_last * g.comp_idx_bits,
+          rec + g.pre_cw_ext if g.locint else cw_end)
+    if g.loc_bitmap:
+        clear(g.cw_data_pos, rec + g.pre_cw_ext + len_last, rec + g.cw_bits)
+    clear(g.cw_data_pos, cw_end, (cw_end + 7) // 8 * 8)
+    clear(g.var_data_pos, var_bits, (var_bits + 7) // 8 * 8)
+    buf = (ctypes.c_uint8 * len(img)).from_buffer(img)
+    arr = (ctypes.c_uint64 * len(tail))(*tail)
+    rc = shim.pck_replay_run(buf, len(img), ctypes.byref(g), var_bits, arr, len(tail))
+    assert rc == 0
+    assert hashlib.md5(bytes(img)).hexdigest() == GOLDEN[key]["md5"]

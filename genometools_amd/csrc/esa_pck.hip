@@ -59,6 +59,7 @@ struct PckGeom {
   u32 comp_idx_bits, var_off_bits, cb_off_bits, bits_orig_pos;
   u32 cw_bits, pre_var_idx, pre_cb_off, pre_comp_idx, pre_cw_ext;
   u32 sym_bits[PCK_MAX_SIGMA + 2], sym_off[PCK_MAX_SIGMA + 2];
+  u32 lds_cw_off, lds_cw_words, lds_var_off, lds_var_words;   // EMIT: LDS copies of the tile's bit strings (0 words: none)
 };
 
 // ---- block -> (composition index, permutation index, bits) -------------------
@@ -147,10 +148,56 @@ __device__ __forceinline__ void put_bits(u64 *img, u64 bit, u32 nbits, u64 v) {
   }
 }
 
+// where the fields of a tile go: into an LDS copy of the tile's part of the bit
+// string (words relative to w0, in bit-string order: byte-swapped when they
+// leave), or straight into the image when the tile's part does not fit
+struct BitSink {
+  u64 *lds;   // nullptr: global
+  u64 w0;     // first 64-bit word of the tile's part
+  u64 *img;
+};
+__device__ __forceinline__ void sink_put(const BitSink &k, u64 bit, u32 nbits, u64 v) {
+  if (k.lds == nullptr) { put_bits(k.img, bit, nbits, v); return; }
+  if (nbits == 0) return;
+  if (nbits < 64) v &= (1ull << nbits) - 1;
+  const u64 w = (bit >> 6) - k.w0;
+  const u32 o = (u32) (bit & 63);
+  if (o + nbits <= 64) {
+    const u64 x = v << (64 - o - nbits);
+    if (x) atomicOr((unsigned long long *) &k.lds[w], (unsigned long long) x);
+  } else {
+    const u32 r = o + nbits - 64;
+    const u64 hi = v >> r, lo = v << (64 - r);
+    if (hi) atomicOr((unsigned long long *) &k.lds[w], (unsigned long long) hi);
+    if (lo) atomicOr((unsigned long long *) &k.lds[w + 1], (unsigned long long) lo);
+  }
+}
+// the tile's words leave in whole lines; the first and the last word may be
+// shared with the neighbouring tiles (or the other bit string)
+__device__ __forceinline__ void sink_flush(const BitSink &k, u32 nwords) {
+  if (k.lds == nullptr) return;
+  for (u32 i = threadIdx.x; i < nwords; i += blockDim.x) {
+    const u64 x = __builtin_bswap64(k.lds[i]);
+    if (i == 0 || i + 1 == nwords) { if (x) atomicOr((unsigned long long *) &k.img[k.w0 + i], (unsigned long long) x); }
+    else k.img[k.w0 + i] = x;
+  }
+}
+
 __global__ void k_pck_count_specials(const u8 *bwt, u64 N, unsigned long long *out) {
   __shared__ u32 s4[4];
   u32 c = 0;
-  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64) gridDim.x * blockDim.x)
+  const u64 nvec = (((uintptr_t) bwt) & 15) == 0 ? N / 16 : 0;   // 16 bytes per load when aligned
+  for (u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (u64) gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4 *>(bwt)[i];
+    const u32 w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      // bytes >= 254: all of the top seven bits set
+      const u32 t = w[k] & (w[k] >> 1) & (w[k] >> 2) & (w[k] >> 3) & (w[k] >> 4) & (w[k] >> 5) & (w[k] >> 6);
+      c += (u32) __popc(t & 0x02020202u);
+    }
+  }
+  for (u64 i = nvec * 16 + (u64) blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64) gridDim.x * blockDim.x)
     c += bwt[i] >= 254;
   u32 tot;
   (void) block_scan_excl_sum(c, &tot, s4);
@@ -255,8 +302,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   // prefix sums over the buckets of the tile
   u32 tot;
   const u32 var_ex = block_scan_excl_sum(live ? varbits : 0, &tot, s4);
-  const u64 ncols = g.sigma + PCK_EXTRA_COLS;
-  (void) ncols;
+  const u32 tile_var_bits = tot;
   if (!EMIT) { if (tid == 0) tile_tot[(u64) g.sigma * g.ntiles + tile] = tot; }
   const u32 st_ex = block_scan_excl_sum(nstart, &tot, s4);
   if (!EMIT) { if (tid == 0) tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] = tot; }
@@ -264,18 +310,38 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   if (!EMIT) { if (tid == 0) tile_tot[(u64) (g.sigma + 2) * g.ntiles + tile] = tot; }
 
   const u64 cwbit = g.cw_base_bit + bucket * g.cw_bits;
+  // EMIT: the tile's parts of the two bit strings are put together in LDS and
+  // leave in whole lines (a tile whose part does not fit writes straight into
+  // the image)
+  BitSink cw_sink = { nullptr, 0, img }, var_sink = { nullptr, 0, img };
+  u32 cw_nw = 0, var_nw = 0;
+  if (EMIT) {
+    const u64 cw_first = g.cw_base_bit + b0 * g.cw_bits, cw_end = cw_first + (u64) nbk * g.cw_bits;
+    const u64 var_first = g.var_base_bit + tile_tot[(u64) g.sigma * g.ntiles + tile],
+              var_end = var_first + tile_var_bits;
+    const u64 cwn = ((cw_end + 63) >> 6) - (cw_first >> 6), vn = ((var_end + 63) >> 6) - (var_first >> 6);
+    if (g.lds_cw_words && cwn <= g.lds_cw_words) {
+      cw_sink.lds = (u64 *) (smem + g.lds_cw_off); cw_sink.w0 = cw_first >> 6; cw_nw = (u32) cwn;
+    }
+    if (g.lds_var_words && tile_var_bits && vn <= g.lds_var_words) {
+      var_sink.lds = (u64 *) (smem + g.lds_var_off); var_sink.w0 = var_first >> 6; var_nw = (u32) vn;
+    }
+    for (u32 i = tid; i < cw_nw; i += PCK_THREADS) cw_sink.lds[i] = 0;
+    for (u32 i = tid; i < var_nw; i += PCK_THREADS) var_sink.lds[i] = 0;
+    __syncthreads();
+  }
   for (u32 s = 0; s < g.sigma; s++) {
     const u32 ex = block_scan_excl_sum(live ? (u32) s_cnt[s * g.T + tid] : 0, &tot, s4);
     if (!EMIT) { if (tid == 0) tile_tot[(u64) s * g.ntiles + tile] = tot; }
     else if (live)   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
-      put_bits(img, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
+      sink_put(cw_sink, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
   }
-  if (!EMIT || !live) return;
-
+  if (!EMIT) return;
+  if (live) {
   const u64 var_off = tile_tot[(u64) g.sigma * g.ntiles + tile] + var_ex;
-  put_bits(img, cwbit + g.pre_var_idx, g.var_off_bits, var_off);
+  sink_put(cw_sink, cwbit + g.pre_var_idx, g.var_off_bits, var_off);
   if (bucket >= tail_first) tail_off[bucket - tail_first] = var_off;   // for the replay of the last records
-  if (g.locint) put_bits(img, cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
+  if (g.locint) sink_put(cw_sink, cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
   u64 vbit = g.var_base_bit + var_off;
   u64 ridx_s = tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] + st_ex;
   u64 ridx_e = tile_tot[(u64) (g.sigma + 2) * g.ntiles + tile] + en_ex;
@@ -306,10 +372,10 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
       }
       const u64 e = g.lut_entries ? lut[code] : block_indices(bs, g.sigma, g.B, cnt_scratch);
       // append2IdxOutput, eis-blockcomp.c:1762-1775
-      put_bits(img, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits,
+      sink_put(cw_sink, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits,
                (e >> 40) & 0x3ffffu);
       const u32 pb = (u32) (e >> 58);
-      put_bits(img, vbit, pb, e & 0xffffffffffull);
+      sink_put(var_sink, vbit, pb, e & 0xffffffffffull);
       vbit += pb;
     }
   }
@@ -320,18 +386,22 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
         const u32 m = min(64u, len - o);
         u64 bitsv = 0;
         for (u32 i = 0; i < m; i++) bitsv = (bitsv << 1) | ((mine[o + i] & LDS_MARK) ? 1u : 0u);
-        put_bits(img, cwbit + g.pre_cw_ext + o, m, bitsv);
+        sink_put(cw_sink, cwbit + g.pre_cw_ext + o, m, bitsv);
       }
     }
     const u32 bits_bwt_pos = reqbits((u64) len - 1);
-    if (g.loc_count) { const u32 bc = reqbits(len); put_bits(img, vbit, bc, nmarks); vbit += bc; }
+    if (g.loc_count) { const u32 bc = reqbits(len); sink_put(var_sink, vbit, bc, nmarks); vbit += bc; }
     for (u32 o = 0; o < len; o++)
       if (mine[o] & LDS_MARK) {
-        if (g.loc_count) { put_bits(img, vbit, bits_bwt_pos, o); vbit += bits_bwt_pos; }
-        put_bits(img, vbit, g.bits_orig_pos, suf[bpos + o]);
+        if (g.loc_count) { sink_put(var_sink, vbit, bits_bwt_pos, o); vbit += bits_bwt_pos; }
+        sink_put(var_sink, vbit, g.bits_orig_pos, suf[bpos + o]);
         vbit += g.bits_orig_pos;
       }
   }
+  }  // live
+  __syncthreads();
+  sink_flush(cw_sink, cw_nw);
+  sink_flush(var_sink, var_nw);
 }
 
 // exclusive prefix sums of every column of tile_tot; totals[c] = column sum
@@ -634,7 +704,19 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   p->rlist_cap = rl_cap;
   HIP_TRY(hipMemsetAsync(p->img, 0, ((file_bytes + 7) & ~7ull) + 64, p->st));
   const u64 tail_n = std::min<u64>(g.nb, PCK_TAIL_RECORDS);
-  k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
+  // LDS copies of a tile's parts of the bit strings: the whole cw part when it
+  // fits 16 KB, the var part up to 24 KB (a tile with more writes straight
+  // into the image)
+  size_t lds_emit = (lds + 15) & ~(size_t) 15;
+  {
+    const u64 cw_words = ((u64) g.T * g.cw_bits + 63) / 64 + 2;
+    if (cw_words * 8 <= 16384 && lds_emit + cw_words * 8 + 3072 * 8 <= 65536 &&
+        getenv("GTAMD_PCK_DIRECT") == nullptr) {
+      g.lds_cw_off = (u32) lds_emit; g.lds_cw_words = (u32) cw_words; lds_emit += cw_words * 8;
+      g.lds_var_off = (u32) lds_emit; g.lds_var_words = 3072; lds_emit += 3072 * 8;
+    }
+  }
+  k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds_emit, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
                                                          p->rlist, p->rlist + std::max<u64>(1, nregions),
                                                          p->d_tail, g.nb - tail_n);
   HIP_TRY(hipGetLastError());

@@ -710,10 +710,12 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   size_t lds_emit = (lds + 15) & ~(size_t) 15;
   {
     const u64 cw_words = ((u64) g.T * g.cw_bits + 63) / 64 + 2;
-    if (cw_words * 8 <= 16384 && lds_emit + cw_words * 8 + 3072 * 8 <= 65536 &&
+    const char *vw = getenv("GTAMD_PCK_VARWORDS");
+    const u64 var_words = vw != nullptr && atoll(vw) > 0 ? (u64) atoll(vw) : 3072;
+    if (cw_words * 8 <= 16384 && lds_emit + cw_words * 8 + var_words * 8 <= 65536 &&
         getenv("GTAMD_PCK_DIRECT") == nullptr) {
       g.lds_cw_off = (u32) lds_emit; g.lds_cw_words = (u32) cw_words; lds_emit += cw_words * 8;
-      g.lds_var_off = (u32) lds_emit; g.lds_var_words = 3072; lds_emit += 3072 * 8;
+      g.lds_var_off = (u32) lds_emit; g.lds_var_words = (u32) var_words; lds_emit += var_words * 8;
     }
   }
   k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds_emit, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,

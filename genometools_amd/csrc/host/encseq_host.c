@@ -944,6 +944,35 @@ void gtamd_seqstats_mirror(gtamd_seqstats *st, int last_symbol_is_wildcard)
   st->numofsequences *= 2;
 }
 
+/* INDEX.prj of a `gt packedindex mkindex` run: gt_outprjfile with no suffixes
+   written and `longest` undefined (src/match/sfx-run.c:600-690 with doesa false,
+   src/match/sfx-outprj.c:38-83) */
+int gtamd_write_prj_packedindex(const char *path, const gtamd_seqstats *ss,
+                                uint32_t prefixlength, int readmode, int mirrored)
+{
+  FILE *fp = fopen(path, "wb");
+  if (fp == NULL) return -1;
+  fprintf(fp, "totallength=%llu\n", (unsigned long long) ss->totallength);
+  fprintf(fp, "specialcharacters=%llu\n", (unsigned long long) ss->specialcharacters);
+  fprintf(fp, "specialranges=%llu\n", (unsigned long long) ss->specialranges);
+  fprintf(fp, "realspecialranges=%llu\n", (unsigned long long) ss->realspecialranges);
+  fprintf(fp, "lengthofspecialprefix=%llu\n", (unsigned long long) ss->lengthofspecialprefix);
+  fprintf(fp, "lengthofspecialsuffix=%llu\n", (unsigned long long) ss->lengthofspecialsuffix);
+  fprintf(fp, "wildcards=%llu\n", (unsigned long long) ss->wildcards);
+  fprintf(fp, "wildcardranges=%llu\n", (unsigned long long) ss->wildcardranges);
+  fprintf(fp, "realwildcardranges=%llu\n", (unsigned long long) ss->realwildcardranges);
+  fprintf(fp, "lengthofwildcardprefix=%llu\n", (unsigned long long) ss->lengthofwildcardprefix);
+  fprintf(fp, "lengthofwildcardsuffix=%llu\n", (unsigned long long) ss->lengthofwildcardsuffix);
+  fprintf(fp, "numofsequences=%llu\n", (unsigned long long) ss->numofsequences);
+  fprintf(fp, "numofdbsequences=%llu\n", (unsigned long long) ss->numofsequences);
+  fprintf(fp, "numofquerysequences=0\nnumberofallsortedsuffixes=0\n");
+  fprintf(fp, "prefixlength=%u\n", prefixlength);
+  fprintf(fp, "largelcpvalues=0\naveragelcp=0.00\nmaxbranchdepth=0\n");
+  fprintf(fp, "integersize=64\nlittleendian=1\nreadmode=%d\nmirrored=%d\n",
+          readmode, mirrored ? 1 : 0);
+  return fclose(fp) == 0 ? 0 : -1;
+}
+
 int gtamd_write_prj(const char *path, const gtamd_seqstats *ss,
                     const gtamd_esa_stats *es, int with_lcp, int readmode,
                     int mirrored)

@@ -1,7 +1,7 @@
 /* gt-suffixerator-amd: command line entry, behaves like `gt suffixerator`
    (exit code 1 and "gt suffixerator: error: ..." on stderr, src/gt.c:48-52);
    `gt-suffixerator-amd mergeesa ...` is `gt dev mergeesa ...`,
-   `gt-suffixerator-amd packedindex trsuftab ...` is `gt packedindex trsuftab ...` */
+   `gt-suffixerator-amd packedindex mkindex|trsuftab ...` is `gt packedindex ...` */
 #include <stdio.h>
 #include <string.h>
 #include "gtamd_host.h"
@@ -17,9 +17,15 @@ int main(int argc, char **argv)
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "packedindex")) {
+    if (argc > 2 && !strcmp(argv[2], "mkindex")) {
+      if (gtamd_packedindex_mkindex(argc - 2, (const char **) argv + 2, err, sizeof err) != 0) {
+        fprintf(stderr, "gt packedindex mkindex: error: %s\n", err);
+        return 1;
+      }
+      return 0;
+    }
     if (argc < 3 || strcmp(argv[2], "trsuftab")) {
-      fprintf(stderr, "gt packedindex: error: tool trsuftab expected (mkindex: run suffixerator "
-                      "-suf -bwt, then packedindex trsuftab)\n");
+      fprintf(stderr, "gt packedindex: error: tool mkindex or trsuftab expected\n");
       return 1;
     }
     if (gtamd_packedindex_trsuftab(argc - 2, (const char **) argv + 2, err, sizeof err) != 0) {

@@ -4,6 +4,7 @@
    Option names and defaults follow src/core/encseq_options.c:181-290 and
    src/match/index_options.c:298-515; file suffixes src/match/esa-fileend.h. */
 #include "gtamd_host.h"
+#include "gtamd_pck.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -167,7 +168,115 @@ static int yesno(int argc, const char **argv, int *i)
 /* (Measured and dropped: allocating the engine's workspace -- 2.4 s of hipMalloc
    at 3 Gbp -- on a second thread while the device reader runs.  The runtime
    serialises the two: the reader's stage grew by what the allocation took.) */
+/* `gt packedindex mkindex` (gt_parseargsandcallsuffixerator(false, ...),
+   src/tools/gt_packedindex.c:33-36): the suffixerator run below with the
+   packed index as its only table (run_packedindexconstruction,
+   src/match/sfx-run.c:369-425) */
+typedef struct {
+  gtamd_pck_params params;
+  int locbitmap;                 /* -1: option not given */
+} pck_request;
+
+static int write_bdx(gtamd_esa_ctx *ctx, const pck_request *pr, uint32_t numofchars,
+                     const char *indexname, int verbose, char *err, size_t errlen)
+{
+  gtamd_pck_params pp = pr->params;
+  gtamd_pck *pck;
+  gtamd_pck_info info;
+  char path[4096];
+  FILE *fp = NULL;
+  uint8_t *buf = NULL;
+  const uint64_t chunk = 64u << 20;
+  int rc = -1;
+  /* sfx-run.c:389-393 */
+  if (numofchars > 10U && pp.block_size > 3U) pp.block_size = 3U;
+  pp.feature_toggles = gtamd_pck_default_toggles(pp.block_size, pp.bucket_blocks,
+                                                 pp.locate_interval, pr->locbitmap);
+  pp.with_statistics = 1;
+  if ((pck = gtamd_pck_create(0)) == NULL || gtamd_pck_build_from_esa(pck, ctx, &pp) != 0 ||
+      gtamd_pck_get_info(pck, &info) != 0) {
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+    goto done;
+  }
+  snprintf(path, sizeof path, "%s.bdx", indexname);
+  if ((fp = fopen(path, "wb")) == NULL || (buf = malloc(chunk)) == NULL) {
+    fail(err, errlen, "cannot open file '%s' for writing", path);
+    goto done;
+  }
+  for (uint64_t off = 0; off < info.file_bytes; off += chunk) {
+    const uint64_t cnt = info.file_bytes - off < chunk ? info.file_bytes - off : chunk;
+    if (gtamd_pck_image_copy(pck, buf, off, cnt) != 0) { snprintf(err, errlen, "%s", gtamd_esa_last_error()); goto done; }
+    if (fwrite(buf, 1, cnt, fp) != cnt) { fail(err, errlen, "cannot write file '%s'", path); goto done; }
+  }
+  if (verbose)
+    printf("# packed index: blocksize=%u, blocks-per-bucket=%u, locfreq=%u: %llu bytes, %.2f ms on the device\n",
+           pp.block_size, pp.bucket_blocks, pp.locate_interval,
+           (unsigned long long) info.file_bytes, info.build_ms);
+  rc = 0;
+done:
+  if (fp != NULL && fclose(fp) != 0 && rc == 0) rc = fail(err, errlen, "cannot close file '%s'", path);
+  free(buf);
+  gtamd_pck_destroy(pck);
+  return rc;
+}
+
+static int suffixerator_run(int argc, const char **argv, char *err, size_t errlen,
+                            const pck_request *pr);
+
 int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
+{
+  return suffixerator_run(argc, argv, err, errlen, NULL);
+}
+
+static int uint_arg(int argc, const char **argv, int *i, uint32_t *out, char *err, size_t errlen)
+{
+  char *end;
+  unsigned long v;
+  if (*i + 1 >= argc) return fail(err, errlen, "missing argument to option \"%s\"", argv[*i]);
+  v = strtoul(argv[*i + 1], &end, 10);
+  if (*end != 0 || argv[*i + 1][0] == '-')
+    return fail(err, errlen, "argument to option \"%s\" must be a non-negative integer", argv[*i]);
+  *out = (uint32_t) v;
+  (*i)++;
+  return 0;
+}
+
+int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t errlen)
+{
+  pck_request pr = { { 8, 8, 16, 0, 1 }, -1 };
+  const char **rest = malloc(sizeof *rest * (size_t) (argc + 1));
+  int nrest = 0, rc;
+  if (rest == NULL) return fail(err, errlen, "out of memory (%s)", "packedindex mkindex");
+  rest[nrest++] = argc > 0 ? argv[0] : "mkindex";
+  for (int i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    rc = 0;
+    if (!strcmp(a, "-bsize")) rc = uint_arg(argc, argv, &i, &pr.params.block_size, err, errlen);
+    else if (!strcmp(a, "-blbuck")) rc = uint_arg(argc, argv, &i, &pr.params.bucket_blocks, err, errlen);
+    else if (!strcmp(a, "-locfreq")) rc = uint_arg(argc, argv, &i, &pr.params.locate_interval, err, errlen);
+    else if (!strcmp(a, "-locbitmap")) pr.locbitmap = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-sprank") || !strcmp(a, "-sprankilog") || !strcmp(a, "-ctxilog"))
+      rc = fail(err, errlen, "option \"%s\" is not supported by the MI355X packed-index builder", a);
+    else if (!strcmp(a, "-suf") || !strcmp(a, "-lcp") || !strcmp(a, "-bwt") || !strcmp(a, "-bck") ||
+             !strcmp(a, "-suftabuint"))
+      /* the index options of the packed-index variant have no table switches
+         (src/match/index_options.c: gt_index_options_register_packedidx) */
+      rc = fail(err, errlen, "unknown option: %s (try -help)", a);
+    else rest[nrest++] = a;
+    if (rc != 0) { free(rest); return -1; }
+  }
+  if (pr.params.block_size < 1 || pr.params.bucket_blocks < 1) {
+    free(rest);
+    return fail(err, errlen, "argument to option \"-%s\" must be an integer >= 1",
+                pr.params.block_size < 1 ? "bsize" : "blbuck");
+  }
+  rc = suffixerator_run(nrest, rest, err, errlen, &pr);
+  free(rest);
+  return rc;
+}
+
+static int suffixerator_run(int argc, const char **argv, char *err, size_t errlen,
+                            const pck_request *pr)
 {
   const char *db[MAXDB], *indexname = NULL, *inputindex = NULL, *sat = NULL, *smap = NULL;
   gtamd_alphabet alpha;
@@ -270,6 +379,7 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
     } else
       return fail(err, errlen, "unknown option: %s (try -help)", a);
   }
+  if (pr != NULL) want = GTAMD_WANT_SUF | GTAMD_WANT_BWT;   /* what the packed index is made from */
   /* src/match/sfx-opt.c:78-88 */
   if (numdb == 0 && inputindex == NULL)
     return fail(err, errlen, "either option \"-db\" or option \"-%s\" is mandatory", "ii");
@@ -453,6 +563,19 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen)
   if (verbose)
     printf("# prefixlength=%u\n# tied suffixes after the first sort=%llu, refinement rounds=%u\n",
            es.prefixlength, (unsigned long long) es.tied_suffixes, es.refine_rounds);
+  if (pr != NULL) {
+    /* the packed index is the only table of this run; the project file says so:
+       no suffixes written, no longest (src/match/sfx-run.c:600-690 with doesa false) */
+    char path[4096];
+    if (write_bdx(ctx, pr, ss.numofchars, indexname, verbose, err, errlen) != 0) goto done;
+    snprintf(path, sizeof path, "%s.prj", indexname);
+    if (gtamd_write_prj_packedindex(path, &ss, es.prefixlength, readmode, mirrored) != 0) {
+      fail(err, errlen, "cannot open file '%s' for writing", path);
+      goto done;
+    }
+    rc = 0;
+    goto done;
+  }
   if ((want & GTAMD_WANT_SUF) &&
       write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", suftabuint ? 4 : 8, err, errlen) != 0) goto done;
   if ((want & GTAMD_WANT_BCK) && write_bcktab(ctx, indexname, err, errlen) != 0) goto done;

@@ -257,6 +257,17 @@ int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen);
    the device through include/gtamd_pck.h.  -sprank / -ctxilog are refused. */
 int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen);
 
+/* `gt packedindex mkindex` (src/tools/gt_packedindex.c:33-36:
+   gt_parseargsandcallsuffixerator(false, ...)): the command line of
+   gtamd_suffixerator without the table switches, plus -bsize -blbuck -locfreq
+   -locbitmap; writes the sequence-side files, INDEX.bdx as the reference's
+   run_packedindexconstruction does (src/match/sfx-run.c:369-425: with sequence
+   statistics, block size 3 for alphabets of more than 10 letters) and INDEX.prj
+   (no suffixes written, no `longest`). */
+int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t errlen);
+int gtamd_write_prj_packedindex(const char *path, const gtamd_seqstats *ss,
+                                uint32_t prefixlength, int readmode, int mirrored);
+
 #ifdef __cplusplus
 }
 #endif

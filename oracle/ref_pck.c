@@ -46,6 +46,8 @@
 #include "match/eis-suffixerator-interface.h"
 #include "match/sfx-apfxlen.h"
 #include "match/sfx-strategy.h"
+#include "match/sfx-outprj.h"
+#include "core/defined-types.h"
 #include "core/alphabet_api.h"
 #include "core/encseq_api.h"
 
@@ -132,6 +134,17 @@ int main(int argc, char **argv)
                             NULL, false, gt_encseq_total_length(encseq) + 1, logger, err);
     bwtSeq = si != NULL ? gt_createBWTSeqFromSfxI(&params, si, err) : NULL;
     if (bwtSeq != NULL) {
+      /* the project file of such a run: gt_runsuffixerator calls gt_outprjfile
+         with what its outfileinfo holds when no suffix table went through it
+         (src/match/sfx-run.c:598-604 initial values, :661-690) */
+      Definedunsignedlong longest;
+      longest.defined = false;
+      longest.valueunsignedlong = 0;
+      if (gt_outprjfile(index, GT_READMODE_FORWARD, encseq, 0, prefixlength, 0, 0.0, 0,
+                        &longest, err) != 0) {
+        fprintf(stderr, "gt_ref_pck: error: %s\n", gt_error_get(err));
+        return 1;
+      }
       printf("featureToggles=%d\n", params.featureToggles);
       gt_deleteBWTSeq(bwtSeq);
       gt_deleteSfxInterface(si);

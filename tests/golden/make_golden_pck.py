@@ -78,8 +78,12 @@ def run_case(tmp, name, protein, opts, mkindex=False):
         cmd.append("-mkindex")
     out = subprocess.run(cmd + [idx], check=True, capture_output=True, text=True).stdout
     toggles = int(out.split("featureToggles=")[1].split()[0])
-    return {"md5": md5(idx + ".bdx"), "size": os.path.getsize(idx + ".bdx"),
-            "featureToggles": toggles}
+    e = {"md5": md5(idx + ".bdx"), "size": os.path.getsize(idx + ".bdx"),
+         "featureToggles": toggles}
+    if mkindex:
+        with open(idx + ".prj") as f:
+            e["prj"] = f.read()
+    return e
 
 
 def main():

@@ -415,3 +415,44 @@ def test_packedindex_trsuftab_writes_the_reference_file(cli, name, tmp_path):
     os.remove(idx + ".bwt")
     r = subprocess.run([cli, "packedindex", "trsuftab", idx], capture_output=True, text=True)
     assert r.returncode == 1 and "gt packedindex trsuftab: error:" in r.stderr and ".bwt" in r.stderr
+
+
+@pytest.mark.parametrize("name", ["Atinsert.fna", "TTTN.fna", "sw100K2.fsa"])
+def test_packedindex_mkindex_writes_the_reference_files(cli, name, tmp_path):
+    """`gt packedindex mkindex`: INDEX.bdx (statistics flavour) and INDEX.prj
+    equal what the reference's construction writes; the sequence-side files are
+    the suffixerator's"""
+    golden = ou.golden_pck()
+    protein = name.endswith(".fsa")
+    kind = "-protein" if protein else "-dna"
+    ref = str(tmp_path / "ref")
+    subprocess.run([cli, kind, "-indexname", ref, "-db", ou.fixture_path(name)], check=True)
+    for key in sorted(k for k in golden if k.split("|")[0] == name and "mode=mkindex" in k):
+        _, kw = ou.parse_pck_key(key)
+        idx = str(tmp_path / "mk")
+        args = ["-bsize", str(kw["bsize"]), "-blbuck", str(kw["blbuck"]), "-locfreq", str(kw["locfreq"])]
+        if kw["locbitmap"] is not None:
+            args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]
+        subprocess.run([cli, "packedindex", "mkindex", kind, "-indexname", idx, "-db",
+                        ou.fixture_path(name)] + args, check=True)
+        with open(idx + ".bdx", "rb") as f:
+            raw = f.read()
+        assert len(raw) == golden[key]["size"], key
+        assert hashlib.md5(raw).hexdigest() == golden[key]["md5"], key
+        with open(idx + ".prj") as f:
+            assert f.read() == golden[key]["prj"], key
+        assert not os.path.exists(idx + ".suf") and not os.path.exists(idx + ".bwt")
+        for ext in ("ssp", "des", "sds", "md5"):
+            with open(idx + "." + ext, "rb") as a, open(ref + "." + ext, "rb") as b:
+                assert a.read() == b.read(), ext
+    # protein: block sizes above 3 fall back to 3 (src/match/sfx-run.c:389-393)
+    if protein:
+        subprocess.run([cli, "packedindex", "mkindex", kind, "-indexname", str(tmp_path / "a"),
+                        "-db", ou.fixture_path(name)], check=True)
+        subprocess.run([cli, "packedindex", "mkindex", kind, "-bsize", "3", "-indexname",
+                        str(tmp_path / "b"), "-db", ou.fixture_path(name)], check=True)
+        with open(str(tmp_path / "a.bdx"), "rb") as a, open(str(tmp_path / "b.bdx"), "rb") as b:
+            assert a.read() == b.read()
+    r = subprocess.run([cli, "packedindex", "mkindex", kind, "-suf", "-db", ou.fixture_path(name)],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "gt packedindex mkindex: error: unknown option: -suf" in r.stderr

@@ -659,3 +659,27 @@ def test_packedindex_trsuftab_option_errors(host, tmp_path):
     assert rc == -1 and "nothere.prj" in msg
     rc, msg = run("a", "b")
     assert rc == -1 and "superfluous" in msg
+
+
+def test_packedindex_mkindex_option_errors(host, tmp_path):
+    """`gt packedindex mkindex`: the packed-index options are checked and the
+    suffixerator's own checks apply before any device is touched"""
+    host.gtamd_packedindex_mkindex.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                               ctypes.c_char_p, ctypes.c_size_t]
+
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"mkindex", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        return host.gtamd_packedindex_mkindex(len(args) + 1, argv, err, 2048), err.value.decode()
+
+    assert run("-dna") == (-1, 'either option "-db" or option "-ii" is mandatory')
+    rc, msg = run("-bwt", "-db", "x")
+    assert rc == -1 and "unknown option: -bwt" in msg
+    rc, msg = run("-blbuck", "0", "-db", "x")
+    assert rc == -1 and '"-blbuck" must be an integer >= 1' in msg
+    rc, msg = run("-locfreq", "-db", "x")
+    assert rc == -1 and "non-negative integer" in msg
+    rc, msg = run("-ctxilog", "3", "-db", "x")
+    assert rc == -1 and "not supported" in msg
+    rc, msg = run("-dna", "-db", str(tmp_path / "nothere.fna"))
+    assert rc == -1 and ("nothere.fna" in msg or "no HIP device" in msg)

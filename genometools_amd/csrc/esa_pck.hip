@@ -60,6 +60,9 @@ struct PckGeom {
   u32 cw_bits, pre_var_idx, pre_cb_off, pre_comp_idx, pre_cw_ext;
   u32 sym_bits[PCK_MAX_SIGMA + 2], sym_off[PCK_MAX_SIGMA + 2];
   u32 lds_cw_off, lds_cw_words, lds_var_off, lds_var_words;   // EMIT: LDS copies of the tile's bit strings (0 words: none)
+  u32 reversible, bits_orig_rank;   // -sprank: specials sorted reversibly, bits per rank
+  u64 total_specials;
+  u32 dbg_skip;          // timing experiments only (GTAMD_PCK_SKIP): parts of the emission left out
 };
 
 // ---- block -> (composition index, permutation index, bits) -------------------
@@ -204,6 +207,28 @@ __global__ void k_pck_count_specials(const u8 *bwt, u64 N, unsigned long long *o
   if (threadIdx.x == 0 && tot) atomicAdd(out, (unsigned long long) tot);
 }
 
+// ---- -sprank: ranks of the specials of the text ---------------------------------
+// The text is not at hand here, the tables are: position q of the text holds a
+// special iff some row r has a special BWT symbol and suf[r] == q + 1.
+__global__ void k_pck_special_bitmap(const u8 *__restrict__ bwt, const u64 *__restrict__ suf, u64 N,
+                                     unsigned long long *bits) {
+  for (u64 r = (u64) blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (u64) gridDim.x * blockDim.x)
+    if (bwt[r] >= 254) {
+      const u64 v = suf[r];
+      if (v) atomicOr(&bits[(v - 1) >> 6], 1ull << ((v - 1) & 63));
+    }
+}
+__global__ void k_pck_popc_words(const u64 *__restrict__ bits, u64 nwords, u32 *__restrict__ cnt) {
+  const u64 i = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) cnt[i] = (u32) __popcll(bits[i]);
+}
+// specials in text[0, q): specialsRank, src/match/eis-specialsrank.c:160-190
+__device__ __forceinline__ u64 special_rank(const u64 *__restrict__ bits, const u32 *__restrict__ pre, u64 q) {
+  const u64 w = q >> 6;
+  const u32 o = (u32) (q & 63);
+  return (u64) pre[w] + (o ? (u64) __popcll(bits[w] & ((1ull << o) - 1)) : 0);
+}
+
 // ---- the tile kernel -----------------------------------------------------------
 // tile_tot: (sigma + 3) columns of ntiles u64: COUNT writes the tile's totals,
 // the scan turns each column into exclusive prefixes, EMIT reads them.
@@ -211,7 +236,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     PckGeom g, const u8 *__restrict__ bwt, const u64 *__restrict__ suf,
     const u64 *__restrict__ lut, u64 *tile_tot, u64 *img, u64 *rstart, u64 *rend,
-    u64 *tail_off, u64 tail_first) {
+    u64 *tail_off, u64 tail_first, const u64 *__restrict__ spbits, const u32 *__restrict__ sppre) {
   extern __shared__ u8 smem[];
   __shared__ u32 s4[4];
   const u32 tid = threadIdx.x;
@@ -240,7 +265,8 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
         // tail of the table
         const u64 v = suf[p];
         const bool hit = g.loc_pow2 ? (v & g.locmask) == 0 : (v % g.locint) == 0;
-        const bool tr = (c >= 254) != (p >= g.first_special_row);
+        // (-sprank: the specials are sorted reversibly, no marks where they meet letters)
+        const bool tr = !g.reversible && (c >= 254) != (p >= g.first_special_row);
         if (hit || tr) code |= LDS_MARK;
       }
     }
@@ -256,7 +282,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   const u32 len = live ? (u32) min((u64) g.L, g.N > bpos ? g.N - bpos : 0) : 0;
   const u32 nblk = (len + g.B - 1) / g.B;
   const u8 *mine = s_sym + (size_t) tid * g.LP;
-  u32 pbits_sum = 0, nmarks = 0, nstart = 0, nend = 0;
+  u32 pbits_sum = 0, nmarks = 0, nstart = 0, nend = 0, nranks = 0;
   if (live) {
     // symbol before / behind the bucket (region borders)
     u32 prev = 0xff, next = 0xff;
@@ -283,6 +309,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
             const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
             nstart += before != c;
             nend += after != c;
+            nranks++;
           }
           nmarks += (raw & LDS_MARK) != 0;
         }
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   if (live && g.locint) {
     if (g.loc_count) varbits += reqbits(len) + nmarks * (reqbits((u64) len - 1) + g.bits_orig_pos);
     else varbits += nmarks * g.bits_orig_pos;
+    varbits += nranks * g.bits_orig_rank;
   }
   __syncthreads();
 
@@ -333,7 +361,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   for (u32 s = 0; s < g.sigma; s++) {
     const u32 ex = block_scan_excl_sum(live ? (u32) s_cnt[s * g.T + tid] : 0, &tot, s4);
     if (!EMIT) { if (tid == 0) tile_tot[(u64) s * g.ntiles + tile] = tot; }
-    else if (live)   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
+    else if (live && !(g.dbg_skip & 4))   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
       sink_put(cw_sink, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
   }
   if (!EMIT) return;
@@ -353,6 +381,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
       next = (tid + 1 < nbk) ? (mine[g.LP] & 63u)
                              : (bwt[bpos + len] >= 254 ? LDS_SPECIAL + (bwt[bpos + len] - 254) : 0u);
     u32 cnt_scratch[PCK_MAX_SIGMA + 2];
+    if (!(g.dbg_skip & 2))
     for (u32 b = 0; b < nblk; b++) {
       u64 code = 0;
       u8 bs[16];
@@ -391,12 +420,24 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     }
     const u32 bits_bwt_pos = reqbits((u64) len - 1);
     if (g.loc_count) { const u32 bc = reqbits(len); sink_put(var_sink, vbit, bc, nmarks); vbit += bc; }
+    if (!(g.dbg_skip & 1))
     for (u32 o = 0; o < len; o++)
       if (mine[o] & LDS_MARK) {
         if (g.loc_count) { sink_put(var_sink, vbit, bits_bwt_pos, o); vbit += bits_bwt_pos; }
-        sink_put(var_sink, vbit, g.bits_orig_pos, suf[bpos + o]);
+        u64 v = (g.dbg_skip & 8) ? o : suf[bpos + o];
+        if (g.reversible) v = g.loc_pow2 ? v >> __popc(g.locmask) : v / g.locint;
+        sink_put(var_sink, vbit, g.bits_orig_pos, v);
         vbit += g.bits_orig_pos;
       }
+    if (g.bits_orig_rank)
+      // the symbols sorted by rank (specials, the undefined symbol before suffix 0):
+      // their rank among the specials of the text, eis-bwtseq-extinfo.c:452-471, 528-541
+      for (u32 o = 0; o < len; o++)
+        if ((mine[o] & 63u) >= LDS_SPECIAL) {
+          const u64 v = suf[bpos + o];
+          sink_put(var_sink, vbit, g.bits_orig_rank, v ? special_rank(spbits, sppre, v - 1) : g.total_specials);
+          vbit += g.bits_orig_rank;
+        }
   }
   }  // live
   __syncthreads();
@@ -463,6 +504,9 @@ struct gtamd_pck {
   u64 *rlist; u64 rlist_cap;
   u64 *d_totals;
   u64 *d_tail;
+  u64 *spbits; u64 spbits_cap;     // -sprank: bitmap of the text's specials, word prefix counts,
+  u32 *sppre; u64 sppre_cap;       // scan workspace
+  u32 *spws; u64 spws_cap;
   gtamd_pck_info info;
   bool built;
 };
@@ -508,6 +552,9 @@ extern "C" void gtamd_pck_destroy(gtamd_pck *p) {
   if (p->rlist) (void) hipFree(p->rlist);
   if (p->d_totals) (void) hipFree(p->d_totals);
   if (p->d_tail) (void) hipFree(p->d_tail);
+  if (p->spbits) (void) hipFree(p->spbits);
+  if (p->sppre) (void) hipFree(p->sppre);
+  if (p->spws) (void) hipFree(p->spws);
   (void) hipEventDestroy(p->ev0);
   (void) hipEventDestroy(p->ev1);
   (void) hipStreamDestroy(p->st);
@@ -557,6 +604,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   const u32 B = pp->block_size, K = pp->bucket_blocks, locint = pp->locate_interval;
   const bool loc_bitmap = locint && (pp->feature_toggles & GTAMD_PCK_LOCATE_BITMAP);
   const bool loc_count = locint && !loc_bitmap && (pp->feature_toggles & GTAMD_PCK_LOCATE_COUNT);
+  const bool reversible = locint && (pp->feature_toggles & GTAMD_PCK_REVERSIBLY_SORTED);
   if (B < 1 || B > 16 || K < 1 || (u64) B * K > PCK_TILE_POS || sigma < 2 || sigma > PCK_MAX_SIGMA) {
     gtamd_set_error("packed index: block size %u x %u blocks per bucket over %u letters is outside "
                     "what the device builder supports (block size <= 16, bucket <= %u positions)",
@@ -567,10 +615,11 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   if (locint && suf == nullptr) { gtamd_set_error("packed index: locate information needs the suffix array"); return -1; }
   if (total_len < 2) { gtamd_set_error("packed index: empty sequence"); return -1; }
   if (total_len >= (1ull << 40)) { gtamd_set_error("packed index: more than 2^40 positions"); return -1; }
-  if (pp->feature_toggles & ~(GTAMD_PCK_LOCATE_BITMAP | GTAMD_PCK_LOCATE_COUNT)) {
-    gtamd_set_error("packed index: feature toggles %d not supported (no -sprank)", (int) pp->feature_toggles);
+  if (pp->feature_toggles & ~(GTAMD_PCK_LOCATE_BITMAP | GTAMD_PCK_LOCATE_COUNT | GTAMD_PCK_REVERSIBLY_SORTED)) {
+    gtamd_set_error("packed index: feature toggles %d not supported", (int) pp->feature_toggles);
     return -1;
   }
+  if (reversible && suf == nullptr) { gtamd_set_error("packed index: -sprank needs the suffix array"); return -1; }
   HIP_TRY(hipSetDevice(p->device));
   p->built = false;
 
@@ -597,7 +646,9 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   }
   const u64 cw_ext_bits = loc_bitmap ? g.L : 0;
   g.cb_off_bits = locint ? reqbits((u64) max_perm_idx_bits * K) : 0;
-  if (locint) g.bits_orig_pos = reqbits(total_len - 1);
+  // initAddLocateInfoState, eis-bwtseq-extinfo.c:279-285
+  if (locint) g.bits_orig_pos = reversible ? reqbits((total_len - 1) / locint) : reqbits(total_len - 1);
+  g.reversible = reversible;
 
   // block -> index pair table
   u64 entries = 1;
@@ -629,10 +680,28 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   HIP_TRY(hipStreamSynchronize(p->st));
   HIP_TRY(hipMemcpy(&nspecial, p->d_totals, 8, hipMemcpyDeviceToHost));
   g.first_special_row = total_len - nspecial;
+  if (reversible) {
+    // buildSpRTable / gt_createBWTSeqGeneric, eis-bwtseq-construct.c:206-229,
+    // eis-bwtseq-extinfo.c:585-600: one rank per special of the text (the BWT holds
+    // them all, plus the undefined symbol before suffix 0)
+    g.total_specials = nspecial - 1;
+    if (g.total_specials >= (1ull << 32)) { gtamd_set_error("packed index: -sprank with more than 2^32 specials"); return -1; }
+    g.bits_orig_rank = reqbits(g.total_specials);
+    const u64 nwords = total_len / 64 + 1;
+    u64 cap = p->spbits_cap; TRY(grow(&p->spbits, &cap, nwords * 8)); p->spbits_cap = cap;
+    cap = p->sppre_cap; TRY(grow(&p->sppre, &cap, nwords * 4)); p->sppre_cap = cap;
+    cap = p->spws_cap; TRY(grow(&p->spws, &cap, scan_workspace_words(nwords) * 4 + 64)); p->spws_cap = cap;
+    HIP_TRY(hipMemsetAsync(p->spbits, 0, nwords * 8, p->st));
+    k_pck_special_bitmap<<<2048, 256, 0, p->st>>>(bwt, suf, total_len, (unsigned long long *) p->spbits);
+    HIP_TRY(hipGetLastError());
+    k_pck_popc_words<<<(u32) div_up(nwords, 256), 256, 0, p->st>>>(p->spbits, nwords, p->sppre);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, p->sppre, p->sppre, nwords, false, p->spws, p->st));
+  }
 
   const size_t lds = (((size_t) g.T * g.LP + 15) & ~(size_t) 15) + (size_t) sigma * g.T * sizeof(u16);
   k_pck_tile<false><<<g.ntiles, PCK_THREADS, lds, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, nullptr, nullptr, nullptr,
-                                                          nullptr, 0);
+                                                          nullptr, 0, nullptr, nullptr);
   HIP_TRY(hipGetLastError());
   k_pck_scan_cols<<<(u32) ncols, PCK_THREADS, 0, p->st>>>(p->tile_tot, g.ntiles, p->d_totals);
   HIP_TRY(hipGetLastError());
@@ -660,7 +729,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   if (locint) {
     const u64 last_pos = total_len - 1;
     u64 extra = 0;
-    if (locint > 1) {
+    if (locint > 1 && !reversible) {
       extra = std::min(total_len / 2, total_len - total_len / locint);
       if (pp->with_statistics) {
         // symbols outside the value-sorted range as newSeqStatsFromCharDist counts
@@ -674,7 +743,16 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
     u64 max_seg = 0, tot = 0;
     for (int i = 0; i < 2; i++) { max_seg = std::max(max_seg, dlen[i]); if (loc_count) tot += reqbits(dlen[i]) * drep[i]; }
     tot += (total_len / locint + extra) * ((loc_count ? reqbits(max_seg) : 0) + g.bits_orig_pos);
-    max_var_ext_bits_per_bucket = max_seg * ((loc_count ? reqbits(last_pos) : 0) + g.bits_orig_pos)
+    if (g.bits_orig_rank) {
+      // specialsRank(seqLen): the specials and the terminator -- which the reference's
+      // sample table counts twice when seqLen falls on a sample position
+      // (eis-specialsrank.c:108-128, 160-190; interval 2^bits(bits(seqLen)),
+      // eis-bwtseq-construct.c:217-222)
+      u64 bound = g.total_specials + 1;
+      if (g.total_specials && total_len % (1ull << reqbits(reqbits(total_len))) == 0) bound++;
+      tot += bound * g.bits_orig_rank;
+    }
+    max_var_ext_bits_per_bucket = max_seg * ((loc_count ? reqbits(last_pos) : 0) + g.bits_orig_pos + g.bits_orig_rank)
                                   + (loc_count ? reqbits(max_seg) : 0);
     max_var_bits_total += tot;
   }
@@ -688,7 +766,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   const u32 num_modes = 2;
   u64 header_len = 4 + 4 + 8 + 8 + 12 + 12 + 8 + 8 + 8 + 4 * sigma + 8 + 8 + 8 + 12 + 4 * num_modes;
   if (g.cb_off_bits) header_len += 8 + 12 + 12;
-  const u64 cw_data_pos = div_up(header_len + (locint ? 8 + 16 : 0), 8192) * 8192;
+  const u64 cw_data_pos = div_up(header_len + (locint ? 8 + 16 : 0) + (g.bits_orig_rank ? 8 + 8 : 0), 8192) * 8192;
   const u64 cw_len = ((u64) g.cw_bits * g.nb + 7) / 8;
   const u64 var_data_pos = cw_data_pos + cw_len;
   g.cw_base_bit = cw_data_pos * 8;
@@ -718,9 +796,10 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
       g.lds_var_off = (u32) lds_emit; g.lds_var_words = (u32) var_words; lds_emit += var_words * 8;
     }
   }
+  if (getenv("GTAMD_PCK_SKIP") != nullptr) g.dbg_skip = (u32) atoi(getenv("GTAMD_PCK_SKIP"));
   k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds_emit, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
                                                          p->rlist, p->rlist + std::max<u64>(1, nregions),
-                                                         p->d_tail, g.nb - tail_n);
+                                                         p->d_tail, g.nb - tail_n, p->spbits, p->sppre);
   HIP_TRY(hipGetLastError());
   k_pck_regions<<<(u32) div_up(nregions + 1, 256), 256, 0, p->st>>>(
       p->rlist, p->rlist + std::max<u64>(1, nregions), nregions, total_len, B, p->img + range_enc_pos + 8);
@@ -731,7 +810,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   // header + extension header, writeIdxHeader eis-blockcomp.c:1984-2094,
   // writeLocateInfoHeader eis-bwtseq-extinfo.c:59-76
   {
-    std::vector<u8> h((size_t) header_len + 64, 0);
+    std::vector<u8> h((size_t) header_len + 128, 0);
     u64 o = 8;
     auto put32 = [&](u64 v) { const u32 x = (u32) v; memcpy(&h[(size_t) o], &x, 4); o += 4; };
     auto put64 = [&](u64 v) { memcpy(&h[(size_t) o], &v, 8); o += 8; };
@@ -759,6 +838,14 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
     if (locint) {
       put32(0x45480000u | 1111u); put32(16);
       put64(longest); put32(locint); put32((u32) pp->feature_toggles);
+      if (g.bits_orig_rank) {
+        // writeRankSortHeader, eis-bwtseq-extinfo.c:106-122: SORTMODE_VALUE 0, SORTMODE_RANK 2
+        put32(0x45480000u | 1112u); put32(8);
+        put32(g.bits_orig_rank);
+        const uint16_t m0 = 0, m2 = 2;
+        memcpy(&h[(size_t) o], &m0, 2); o += 2;
+        memcpy(&h[(size_t) o], &m2, 2); o += 2;
+      }
     }
     HIP_TRY(hipMemcpy(p->img, h.data(), (size_t) o, hipMemcpyHostToDevice));
     const u64 nr = nregions + 1;

@@ -62,7 +62,7 @@ static int uint_option(int argc, const char **argv, int *i, uint32_t *out, char 
 int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen)
 {
   gtamd_pck_params pp = { 8, 8, 16, 0, 0 };
-  int locbitmap = -1, verbose = 0, rc = -1, protein = 0;
+  int locbitmap = -1, verbose = 0, rc = -1, protein = 0, sprank = 0;
   const char *index = NULL;
   char path[4096];
   unsigned long long totallength, longest, integersize = 64;
@@ -83,7 +83,16 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
       if (i + 1 < argc && (!strcmp(argv[i + 1], "yes") || !strcmp(argv[i + 1], "no")))
         locbitmap = !strcmp(argv[++i], "yes");
     } else if (!strcmp(a, "-v")) verbose = 1;
-    else if (!strcmp(a, "-sprank") || !strcmp(a, "-sprankilog") || !strcmp(a, "-ctxilog"))
+    else if (!strcmp(a, "-sprank")) {
+      sprank = 1;
+      if (i + 1 < argc && (!strcmp(argv[i + 1], "yes") || !strcmp(argv[i + 1], "no")))
+        sprank = !strcmp(argv[++i], "yes");
+    } else if (!strcmp(a, "-sprankilog")) {
+      /* the sampling interval of the reference's in-memory rank table: no effect on
+         the file, but a value >= 0 switches the rank sort on (eis-bwtseq-param.c:98-100) */
+      if (i + 1 >= argc) return pfail(err, errlen, "missing argument to option \"%s\"", a);
+      if (atoi(argv[++i]) >= 0) sprank = 1;
+    } else if (!strcmp(a, "-ctxilog"))
       return pfail(err, errlen, "option \"%s\" is not supported by the MI355X packed-index builder", a);
     else if (a[0] == '-') return pfail(err, errlen, "unknown option: %s (try -help)", a);
     else if (index != NULL) return pfail(err, errlen, "superfluous argument \"%s\"", a);
@@ -93,7 +102,8 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
   /* the option parser's minima (gt_option_new_uint_min, eis-blockcomp-param.c) */
   if (pp.block_size < 1) return pfail(err, errlen, "argument to option \"-%s\" must be an integer >= 1", "bsize");
   if (pp.bucket_blocks < 1) return pfail(err, errlen, "argument to option \"-%s\" must be an integer >= 1", "blbuck");
-  pp.feature_toggles = gtamd_pck_default_toggles(pp.block_size, pp.bucket_blocks, pp.locate_interval, locbitmap);
+  pp.feature_toggles = gtamd_pck_default_toggles(pp.block_size, pp.bucket_blocks, pp.locate_interval, locbitmap)
+                       | (sprank ? GTAMD_PCK_REVERSIBLY_SORTED : 0);
 
   snprintf(path, sizeof path, "%s.prj", index);
   if (prj_value(path, "totallength", &totallength) != 0 || prj_value(path, "longest", &longest) != 0)
@@ -111,7 +121,7 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
     pfail(err, errlen, "cannot read the %s table of the project (run suffixerator with -bwt)", path);
     goto done;
   }
-  if (pp.locate_interval) {
+  if (pp.locate_interval) {   /* (-sprank without locate information stores nothing either) */
     snprintf(path, sizeof path, "%s.suf", index);
     if ((suf = read_whole(path, 8 * (totallength + 1))) == NULL) {
       pfail(err, errlen, "suffix array project %s does not hold required suffix array (.suf) "

@@ -175,6 +175,7 @@ static int yesno(int argc, const char **argv, int *i)
 typedef struct {
   gtamd_pck_params params;
   int locbitmap;                 /* -1: option not given */
+  int sprank;
 } pck_request;
 
 static int write_bdx(gtamd_esa_ctx *ctx, const pck_request *pr, uint32_t numofchars,
@@ -191,7 +192,8 @@ static int write_bdx(gtamd_esa_ctx *ctx, const pck_request *pr, uint32_t numofch
   /* sfx-run.c:389-393 */
   if (numofchars > 10U && pp.block_size > 3U) pp.block_size = 3U;
   pp.feature_toggles = gtamd_pck_default_toggles(pp.block_size, pp.bucket_blocks,
-                                                 pp.locate_interval, pr->locbitmap);
+                                                 pp.locate_interval, pr->locbitmap)
+                       | (pr->sprank ? GTAMD_PCK_REVERSIBLY_SORTED : 0);
   pp.with_statistics = 1;
   if ((pck = gtamd_pck_create(0)) == NULL || gtamd_pck_build_from_esa(pck, ctx, &pp) != 0 ||
       gtamd_pck_get_info(pck, &info) != 0) {
@@ -243,7 +245,7 @@ static int uint_arg(int argc, const char **argv, int *i, uint32_t *out, char *er
 
 int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t errlen)
 {
-  pck_request pr = { { 8, 8, 16, 0, 1 }, -1 };
+  pck_request pr = { { 8, 8, 16, 0, 1 }, -1, 0 };
   const char **rest = malloc(sizeof *rest * (size_t) (argc + 1));
   int nrest = 0, rc;
   if (rest == NULL) return fail(err, errlen, "out of memory (%s)", "packedindex mkindex");
@@ -255,7 +257,11 @@ int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t err
     else if (!strcmp(a, "-blbuck")) rc = uint_arg(argc, argv, &i, &pr.params.bucket_blocks, err, errlen);
     else if (!strcmp(a, "-locfreq")) rc = uint_arg(argc, argv, &i, &pr.params.locate_interval, err, errlen);
     else if (!strcmp(a, "-locbitmap")) pr.locbitmap = yesno(argc, argv, &i);
-    else if (!strcmp(a, "-sprank") || !strcmp(a, "-sprankilog") || !strcmp(a, "-ctxilog"))
+    else if (!strcmp(a, "-sprank")) pr.sprank = yesno(argc, argv, &i);
+    else if (!strcmp(a, "-sprankilog")) {
+      if (i + 1 >= argc) rc = fail(err, errlen, "missing argument to option \"%s\"", a);
+      else if (atoi(argv[++i]) >= 0) pr.sprank = 1;
+    } else if (!strcmp(a, "-ctxilog"))
       rc = fail(err, errlen, "option \"%s\" is not supported by the MI355X packed-index builder", a);
     else if (!strcmp(a, "-suf") || !strcmp(a, "-lcp") || !strcmp(a, "-bwt") || !strcmp(a, "-bck") ||
              !strcmp(a, "-suftabuint"))

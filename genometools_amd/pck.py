@@ -16,14 +16,15 @@ import numpy as np
 from . import _lib
 from ._lib import PckInfo, PckParams, check
 
-LOCATE_BITMAP, LOCATE_COUNT = 1, 2
+LOCATE_BITMAP, LOCATE_COUNT, REVERSIBLY_SORTED = 1, 2, 4
 
 
-def default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None):
+def default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None, sprank=False):
     """the feature toggles gt_computePackedIndexDefaults derives
     (src/match/eis-bwtseq-param.c:89-103); locbitmap None = option not given"""
     return _lib.load().gtamd_pck_default_toggles(
-        bsize, blbuck, locfreq, -1 if locbitmap is None else int(bool(locbitmap)))
+        bsize, blbuck, locfreq, -1 if locbitmap is None else int(bool(locbitmap))) | \
+        (REVERSIBLY_SORTED if sprank else 0)
 
 
 class PackedIndex:
@@ -53,22 +54,23 @@ class PackedIndex:
             pass
 
     @staticmethod
-    def _params(bsize, blbuck, locfreq, locbitmap, mkindex):
+    def _params(bsize, blbuck, locfreq, locbitmap, mkindex, sprank):
         return PckParams(bsize, blbuck, locfreq,
-                         default_toggles(bsize, blbuck, locfreq, locbitmap), int(bool(mkindex)))
+                         default_toggles(bsize, blbuck, locfreq, locbitmap, sprank),
+                         int(bool(mkindex)))
 
     def build_from_esa(self, engine, bsize=8, blbuck=8, locfreq=16, locbitmap=None,
-                       mkindex=False):
+                       mkindex=False, sprank=False):
         """from an EsaEngine whose last run produced .suf and .bwt; mkindex: the
         file of `gt packedindex mkindex` (with sequence statistics) instead of
         the one of `gt packedindex trsuftab`"""
-        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex)
+        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex, sprank)
         check(self._lib.gtamd_pck_build_from_esa(self._p, engine._ctx, ctypes.byref(pp)))
 
     def build(self, bwt_ptr, suf_ptr, total_len, numofchars, longest, bsize=8, blbuck=8,
-              locfreq=16, locbitmap=None, mkindex=False):
+              locfreq=16, locbitmap=None, mkindex=False, sprank=False):
         """from raw device pointers of the .bwt and .suf tables"""
-        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex)
+        pp = self._params(bsize, blbuck, locfreq, locbitmap, mkindex, sprank)
         check(self._lib.gtamd_pck_build(self._p, bwt_ptr, suf_ptr, total_len, numofchars,
                                         longest, ctypes.byref(pp)))
 

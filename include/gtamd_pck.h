@@ -25,9 +25,10 @@
   image is byte-identical to the reference's file (also where the reference's
   staging buffers leave stale bits in the last bucket).
 
-  Covered: the tool's default feature set -- block encoding, locate
-  information as counts or as bitmap (-locfreq, -locbitmap), none (-locfreq 0).
-  Not covered: -sprank (BWTReversiblySorted) and -ctxilog (context map file).
+  Covered: block encoding, locate information as counts or as bitmap
+  (-locfreq, -locbitmap), none (-locfreq 0), reversibly sorted specials
+  (-sprank: the ranks of the text's specials in the var parts and the sort-mode
+  extension header).  Not covered: -ctxilog (context map, a second file).
 
   Conventions as in gtamd_esa.h: 0 / -1, message from gtamd_esa_last_error().
   Plain C; no CPU fallback.
@@ -46,12 +47,15 @@ extern "C" {
 /* enum BWTFeatures, src/match/eis-bwtseq-param.h:78-94 */
 #define GTAMD_PCK_LOCATE_BITMAP 1
 #define GTAMD_PCK_LOCATE_COUNT  2
+#define GTAMD_PCK_REVERSIBLY_SORTED 4  /* -sprank / -sprankilog */
 
 typedef struct {
   uint32_t block_size;       /* -bsize   (default 8), 1..16 */
   uint32_t bucket_blocks;    /* -blbuck  (default 8); block_size * bucket_blocks <= 16384 */
   uint32_t locate_interval;  /* -locfreq (default 16), 0 = no locate information */
-  int32_t feature_toggles;   /* GTAMD_PCK_LOCATE_*; gtamd_pck_default_toggles() */
+  int32_t feature_toggles;   /* GTAMD_PCK_LOCATE_*; gtamd_pck_default_toggles(), | GTAMD_PCK_REVERSIBLY_SORTED
+                                for -sprank (gt_computePackedIndexDefaults,
+                                src/match/eis-bwtseq-param.c:98-100) */
   int32_t with_statistics;   /* 0: the file `gt packedindex trsuftab INDEX` writes (tables
                                 read back from files: the reference has no sequence
                                 statistics there), 1: the file `gt packedindex mkindex`

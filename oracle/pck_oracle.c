@@ -173,6 +173,11 @@ typedef struct {
   uint64_t suf_next;
   uint64_t *mark_bwt, *mark_orig;
   uint8_t *block;
+  /* -sprank (BWTReversiblySorted): ranks of the specials of the text */
+  int reversible;
+  unsigned bits_per_orig_rank;
+  const uint64_t *sprank;       /* sprank[q] = specials in seq[0, q) */
+  uint64_t *rank_queue;
   outbuf o;
 } pck_state;
 
@@ -240,10 +245,22 @@ static void flush_bucket(pck_state *st, uint64_t len)
     unsigned bits_bwt_pos = reqbits(len - 1);
     bs_store(st->comp_cache, st->cw_mem_old + st->pre_cb_off, st->cb_off_bits,
              st->var_mem_pos - st->var_mem_old);
+    uint64_t nranks = 0;
     for (i = 0; i < len; i++) {
       uint64_t v = st->suf[st->suf_next++];
-      int mark = (v % st->locint) == 0 || sort_mode_transition(st->seq, st->total_len, v);
-      if (mark) { st->mark_bwt[nmarks] = i; st->mark_orig[nmarks] = v; nmarks++; }
+      /* reversibly sorted specials: no extra marks where letters and specials
+         meet, the mark stores the text position divided by the interval
+         (eis-bwtseq-extinfo.c:415-441) */
+      int mark = (v % st->locint) == 0 ||
+                 (!st->reversible && sort_mode_transition(st->seq, st->total_len, v));
+      if (mark) { st->mark_bwt[nmarks] = i; st->mark_orig[nmarks] = st->reversible ? v / st->locint : v; nmarks++; }
+      if (st->bits_per_orig_rank) {
+        /* eis-bwtseq-extinfo.c:452-471: the symbol before the suffix is sorted by
+           rank (a special, or the undefined symbol before suffix 0): its rank
+           among the specials of the text, specialsRank (eis-specialsrank.c:160-190) */
+        unsigned sym = v ? st->seq[v - 1] : 254u;
+        if (sym >= 254u) st->rank_queue[nranks++] = st->sprank[v ? v - 1 : st->total_len - 1];
+      }
       if (st->loc_bitmap)
         bs_store(st->comp_cache, st->cw_mem_old + st->pre_cw_ext + i, 1, (uint64_t) mark);
     }
@@ -259,6 +276,10 @@ static void flush_bucket(pck_state *st, uint64_t len)
       }
       bs_store(st->perm_cache, st->var_mem_pos + written, st->bits_per_orig_pos, st->mark_orig[i]);
       written += st->bits_per_orig_pos;
+    }
+    for (i = 0; i < nranks; i++) {
+      bs_store(st->perm_cache, st->var_mem_pos + written, st->bits_per_orig_rank, st->rank_queue[i]);
+      written += st->bits_per_orig_rank;
     }
     st->cw_mem_pos = st->pre_cw_ext + st->cw_mem_old + st->cw_ext_bits;
     st->var_mem_pos += written;
@@ -299,7 +320,10 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   const int toggles = pp->feature_toggles;
   const int loc_bitmap = (toggles & ORA_PCK_LOCATE_BITMAP) != 0;
   const int loc_count = (toggles & ORA_PCK_LOCATE_COUNT) != 0;
+  const int reversible = locint && (toggles & ORA_PCK_REVERSIBLY_SORTED) != 0;
   const uint64_t bucket_len = (uint64_t) bsize * bblocks;
+  uint64_t *sprank = NULL, total_specials = 0;
+  unsigned bits_per_orig_rank = 0;
   /* numBuckets, eis-blockcomp.c:1633-1638 */
   const uint64_t nbuckets = (total_len + 1) / bucket_len + (((total_len + 1) % bucket_len) ? 1 : 0);
   unsigned bits_per_ulong, comp_idx_bits, max_perm_idx_bits;
@@ -347,8 +371,18 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
     uint64_t last_pos = total_len - 1, extra = 0, desc_len[2], desc_rep[2], max_seg = 0, tot = 0;
     int i;
     state_bits_per_ulong = reqbits(last_pos);
-    bits_per_orig_pos = reqbits(last_pos);          /* not reversibly sorted */
-    if (locint > 1) {
+    bits_per_orig_pos = reversible ? reqbits(last_pos / locint) : reqbits(last_pos);
+    if (reversible) {
+      /* buildSpRTable / gt_createBWTSeqGeneric, eis-bwtseq-construct.c:206-229,
+         eis-bwtseq-extinfo.c:585-600 */
+      uint64_t q;
+      sprank = malloc((size_t) (total_len + 1) * sizeof *sprank);
+      sprank[0] = 0;
+      for (q = 0; q + 1 < total_len; q++) sprank[q + 1] = sprank[q] + (seq[q] >= 254u ? 1 : 0);
+      total_specials = sprank[total_len - 1];
+      bits_per_orig_rank = reqbits(total_specials);
+    }
+    if (!reversible && locint > 1) {
       uint64_t std_marks = total_len / locint;
       uint64_t a = total_len / 2, b = total_len - std_marks;
       extra = a < b ? a : b;
@@ -368,8 +402,18 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
       if (loc_count) tot += reqbits(desc_len[i]) * desc_rep[i];
     }
     tot += (total_len / locint + extra) * ((loc_count ? reqbits(max_seg) : 0) + bits_per_orig_pos);
+    /* specialsRank(seqLen): the specials and the terminator -- which the
+       reference's sample table counts twice when seqLen falls on a sample
+       position (the last sample then covers the terminator and
+       specialsRankFromSampleTable adds it again, eis-specialsrank.c:108-128,
+       160-190); sample interval 2^bits(bits(seqLen)), eis-bwtseq-construct.c:217-222 */
+    if (bits_per_orig_rank) {
+      uint64_t bound = total_specials + 1;
+      if (total_specials && total_len % ((uint64_t) 1 << reqbits(reqbits(total_len))) == 0) bound++;
+      tot += bound * bits_per_orig_rank;
+    }
     max_var_ext_bits_per_bucket =
-      max_seg * ((loc_count ? state_bits_per_ulong : 0) + bits_per_orig_pos)
+      max_seg * ((loc_count ? state_bits_per_ulong : 0) + bits_per_orig_pos + bits_per_orig_rank)
       + (loc_count ? reqbits(max_seg) : 0);
     max_var_bits_total += tot;
   }
@@ -379,7 +423,8 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   /* blockEncIdxSeqHeaderLength, eis-blockcomp.c:1919-1946 */
   header_len = 4 + 4 + 8 + 8 + 12 + 12 + 8 + 8 + 8 + 4 * sigma + 8 + 8 + 8 + 12 + 4 * num_modes;
   if (cb_off_bits) header_len += 8 + 12 + 12;
-  cw_data_pos = round_up(header_len + (locint ? 8 + 16 : 0), 8192);  /* initOnDiskBlockCompIdx, :1715-1722 */
+  cw_data_pos = round_up(header_len + (locint ? 8 + 16 : 0) + (bits_per_orig_rank ? 8 + 8 : 0),
+                         8192);                     /* initOnDiskBlockCompIdx, :1715-1722 */
   cw_len = (cw_bits * nbuckets + 7) / 8;            /* cwSize, :1640-1649 */
   var_data_pos = cw_data_pos + cw_len;
 
@@ -410,6 +455,8 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   st.mark_bwt = malloc((size_t) bucket_len * sizeof *st.mark_bwt);
   st.mark_orig = malloc((size_t) bucket_len * sizeof *st.mark_orig);
   st.block = malloc(bsize);
+  st.reversible = reversible; st.bits_per_orig_rank = bits_per_orig_rank; st.sprank = sprank;
+  st.rank_queue = malloc((size_t) bucket_len * sizeof *st.rank_queue);
 
   /* the construction loop, eis-blockcomp.c:529-609 */
   {
@@ -450,10 +497,10 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
   }
   free(st.comp_cache); free(st.perm_cache); free(st.buck); free(st.buck_last);
   free(st.r_start); free(st.r_len); free(st.r_sym); free(st.block);
-  free(st.mark_bwt); free(st.mark_orig);
+  free(st.mark_bwt); free(st.mark_orig); free(st.rank_queue); free(sprank);
   /* writeIdxHeader, eis-blockcomp.c:1984-2094 */
   {
-    uint8_t *h = calloc((size_t) header_len + 64, 1);
+    uint8_t *h = calloc((size_t) header_len + 128, 1);
     uint64_t off = 8, v64;
     uint32_t v32;
     unsigned i;
@@ -486,6 +533,15 @@ int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
          eis-bwtseq-extinfo.c:39-76 */
       PUT32(0x45480000u | 1111u); PUT32(16);
       PUT64(longest); PUT32(locint); PUT32((uint32_t) toggles);
+      if (bits_per_orig_rank) {
+        /* writeRankSortHeader, eis-bwtseq-extinfo.c:106-122: bits per rank, then the
+           sort mode of the two ranges as int16: SORTMODE_VALUE 0, SORTMODE_RANK 2 */
+        uint16_t m;
+        PUT32(0x45480000u | 1112u); PUT32(8);
+        PUT32(bits_per_orig_rank);
+        m = 0; memcpy(h + off, &m, 2); off += 2;
+        m = 2; memcpy(h + off, &m, 2); off += 2;
+      }
     }
     out_pwrite(&st.o, 0, h, (size_t) off);
     free(h);

@@ -14,6 +14,7 @@ extern "C" {
 /* enum BWTFeatures, src/match/eis-bwtseq-param.h:78-94 */
 #define ORA_PCK_LOCATE_BITMAP 1
 #define ORA_PCK_LOCATE_COUNT  2
+#define ORA_PCK_REVERSIBLY_SORTED 4   /* -sprank */
 
 typedef struct {
   unsigned block_size;       /* -bsize, default 8 */

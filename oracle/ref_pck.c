@@ -23,7 +23,7 @@
   must exist (written by gt_ref_sfx).
 
   usage: gt_ref_pck [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap yes|no]
-                    [-mkindex] INDEX
+                    [-sprank] [-mkindex] INDEX
 */
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,7 +55,7 @@ int main(int argc, char **argv)
 {
   struct bwtParam params;
   unsigned bsize = 8, blbuck = 8, locfreq = 16;
-  int locbitmap = -1, i, mkindex = 0;
+  int locbitmap = -1, i, mkindex = 0, sprank = 0;
   const char *index = NULL;
   GtError *err;
   GtLogger *logger;
@@ -68,6 +68,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-locfreq") && i + 1 < argc) locfreq = (unsigned) atoi(argv[++i]);
     else if (!strcmp(argv[i], "-locbitmap") && i + 1 < argc) locbitmap = !strcmp(argv[++i], "yes");
     else if (!strcmp(argv[i], "-mkindex")) mkindex = 1;
+    else if (!strcmp(argv[i], "-sprank")) sprank = 1;
     else if (argv[i][0] != '-') index = argv[i];
     else { fprintf(stderr, "gt_ref_pck: unknown option %s\n", argv[i]); return 2; }
   }
@@ -104,6 +105,8 @@ int main(int argc, char **argv)
     else
       params.featureToggles |= BWTLocateBitmap;
   }
+  /* -sprank: gt_computePackedIndexDefaults, eis-bwtseq-param.c:98-100 */
+  if (sprank) params.featureToggles |= BWTReversiblySorted;
   logger = gt_logger_new(false, GT_LOGGER_DEFLT_PREFIX, stdout);
   if (!mkindex)
     bwtSeq = gt_trSuftab2BWTSeq(&params, logger, err);

@@ -53,14 +53,14 @@ def md5(path):
         return hashlib.md5(f.read()).hexdigest()
 
 
-def key(name, opts, mkindex=False):
+def key(name, opts, mkindex=False, sprank=False):
     b, k, f, bm = opts
     return "%s|bsize=%d|blbuck=%d|locfreq=%d|locbitmap=%s" % (
         name, b, k, f, {None: "auto", True: "yes", False: "no"}[bm]) + \
-        ("|mode=mkindex" if mkindex else "")
+        ("|mode=mkindex" if mkindex else "") + ("|sprank=yes" if sprank else "")
 
 
-def run_case(tmp, name, protein, opts, mkindex=False):
+def run_case(tmp, name, protein, opts, mkindex=False, sprank=False):
     src = os.path.join(OUT, "fixtures", name) if not name.startswith("extra/") \
         else os.path.join(OUT, name)
     idx = os.path.join(tmp, "idx")
@@ -72,6 +72,8 @@ def run_case(tmp, name, protein, opts, mkindex=False):
     cmd = [PCK, "-bsize", str(b), "-blbuck", str(k), "-locfreq", str(f)]
     if bm is not None:
         cmd += ["-locbitmap", "yes" if bm else "no"]
+    if sprank:
+        cmd.append("-sprank")
     if mkindex:
         # the construction of `gt packedindex mkindex`: BWT from the suffixerator
         # interface, with sequence statistics (src/match/sfx-run.c:369-425)
@@ -107,6 +109,20 @@ def main():
         for name, sets in PROTEIN:
             for opts in sets:
                 golden[key(name, opts, True)] = run_case(tmp, name, True, opts, True)
+        # -sprank (testsuite/gt_packedindex_include.rb:87-118; the option set of the
+        # index searches, testsuite/gt_idxsearch_include.rb:67-68: -bsize 10 -locfreq 32)
+        sp_sets = [(8, 8, 16, None), (8, 8, 16, True), (10, 8, 32, None), (3, 5, 7, False),
+                   (4, 4, 1, True), (8, 8, 0, None)]
+        for name in ["RandomN.fna", "Random.fna", "Atinsert.fna", "TTT-small.fna",
+                     "trna_glutamine.fna", "Random-Small.fna", "Duplicate.fna", "TTTN.fna",
+                     "Verysmall.fna", "Atinsert_seqrange_3-7.fna",
+                     "extra/starts_ends_special.fna", "extra/long_runs.fna"]:
+            for opts in sp_sets:
+                for mk in (False, True):
+                    golden[key(name, opts, mk, True)] = run_case(tmp, name, False, opts, mk, True)
+        for opts in [(1, 8, 16, None), (2, 3, 5, True)]:
+            for mk in (False, True):
+                golden[key("sw100K2.fsa", opts, mk, True)] = run_case(tmp, "sw100K2.fsa", True, opts, mk, True)
     with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("%d packed-index goldens" % len(golden))

@@ -213,14 +213,15 @@ def fixture_path(name):
     return os.path.join(GOLDEN_DIR, "fixtures", name)
 
 
-def pck_default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None):
+def pck_default_toggles(bsize=8, blbuck=8, locfreq=16, locbitmap=None, sprank=False):
     """feature toggles `gt packedindex` derives from its options"""
     return lib().ora_pck_default_toggles(bsize, blbuck, locfreq,
-                                         -1 if locbitmap is None else int(locbitmap))
+                                         -1 if locbitmap is None else int(locbitmap)) | \
+        (4 if sprank else 0)
 
 
 def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=None,
-            mkindex=False):
+            mkindex=False, sprank=False):
     """bytes of INDEX.bdx by the oracle's restatement: as `gt packedindex
     trsuftab` writes it, or (mkindex) as `gt packedindex mkindex` does"""
     L = lib()
@@ -228,8 +229,8 @@ def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=
     suf = np.ascontiguousarray(suf, dtype=np.uint64)
     bwt = np.ascontiguousarray(bwt, dtype=np.uint8)
     longest = int(np.flatnonzero(suf == 0)[0])
-    pp = PckParams(bsize, blbuck, locfreq, pck_default_toggles(bsize, blbuck, locfreq, locbitmap),
-                   int(mkindex))
+    pp = PckParams(bsize, blbuck, locfreq,
+                   pck_default_toggles(bsize, blbuck, locfreq, locbitmap, sprank), int(mkindex))
     out, n = ctypes.c_void_p(), ctypes.c_size_t()
     rc = L.ora_pck_bdx(_p(bwt), _p(suf), _p(enc), enc.size + 1, numofchars, longest,
                        ctypes.byref(pp), ctypes.byref(out), ctypes.byref(n))
@@ -253,4 +254,6 @@ def parse_pck_key(key):
                locbitmap={"auto": None, "yes": True, "no": False}[kw["locbitmap"]])
     if kw.get("mode") == "mkindex":
         out["mkindex"] = True
+    if kw.get("sprank") == "yes":
+        out["sprank"] = True
     return parts[0], out

@@ -402,6 +402,8 @@ def test_packedindex_trsuftab_writes_the_reference_file(cli, name, tmp_path):
         args = ["-bsize", str(kw["bsize"]), "-blbuck", str(kw["blbuck"]), "-locfreq", str(kw["locfreq"])]
         if kw["locbitmap"] is not None:
             args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]
+        if kw.get("sprank"):
+            args += ["-sprank"]
         if os.path.exists(idx + ".bdx"):
             os.remove(idx + ".bdx")
         out = subprocess.run([cli, "packedindex", "trsuftab", "-v"] + args + [idx], check=True,
@@ -433,6 +435,8 @@ def test_packedindex_mkindex_writes_the_reference_files(cli, name, tmp_path):
         args = ["-bsize", str(kw["bsize"]), "-blbuck", str(kw["blbuck"]), "-locfreq", str(kw["locfreq"])]
         if kw["locbitmap"] is not None:
             args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]
+        if kw.get("sprank"):
+            args += ["-sprank"]
         subprocess.run([cli, "packedindex", "mkindex", kind, "-indexname", idx, "-db",
                         ou.fixture_path(name)] + args, check=True)
         with open(idx + ".bdx", "rb") as f:

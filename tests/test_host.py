@@ -653,8 +653,10 @@ def test_packedindex_trsuftab_option_errors(host, tmp_path):
     assert rc == -1 and "missing argument" in msg
     rc, msg = run("-bsize", "0", "x")
     assert rc == -1 and '"-bsize" must be an integer >= 1' in msg
-    rc, msg = run("-sprank", "x")
+    rc, msg = run("-ctxilog", "2", "x")
     assert rc == -1 and "not supported" in msg
+    rc, msg = run("-sprank", str(tmp_path / "nothere"))
+    assert rc == -1 and "nothere.prj" in msg
     rc, msg = run(str(tmp_path / "nothere"))
     assert rc == -1 and "nothere.prj" in msg
     rc, msg = run("a", "b")

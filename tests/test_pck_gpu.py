@@ -37,8 +37,8 @@ def test_device_bdx_equals_reference_files(name, builder):
             builder.build_from_esa(eng, **kw)
             raw = builder.image().tobytes()
             e = GOLDEN[key]
-            assert pck.default_toggles(kw["bsize"], kw["blbuck"], kw["locfreq"],
-                                       kw["locbitmap"]) == e["featureToggles"], key
+            assert pck.default_toggles(kw["bsize"], kw["blbuck"], kw["locfreq"], kw["locbitmap"],
+                                       kw.get("sprank", False)) == e["featureToggles"], key
             assert len(raw) == e["size"], key
             assert hashlib.md5(raw).hexdigest() == e["md5"], key
 
@@ -66,9 +66,11 @@ def _against_oracle(enc, sigma, builder, **kw):
 def test_device_bdx_equals_oracle_on_synthetic(model, sigma, n, builder):
     enc = synth.generate(model, 7, n)
     sets = [dict(), dict(locbitmap=True), dict(locfreq=0), dict(mkindex=True),
-            dict(mkindex=True, locbitmap=True, locfreq=5)] if sigma == 4 else \
+            dict(mkindex=True, locbitmap=True, locfreq=5), dict(sprank=True),
+            dict(sprank=True, mkindex=True, bsize=10, locfreq=32),
+            dict(sprank=True, locbitmap=True, locfreq=3)] if sigma == 4 else \
         [dict(bsize=1), dict(bsize=2, blbuck=5, locbitmap=True), dict(bsize=3, blbuck=3, locfreq=0),
-         dict(bsize=3, mkindex=True)]
+         dict(bsize=3, mkindex=True), dict(bsize=2, sprank=True)]
     for kw in sets:
         _against_oracle(enc, sigma, builder, **kw)
 
@@ -88,6 +90,7 @@ def test_geometries_and_bucket_borders(builder):
                    dict(bsize=5, blbuck=2, locfreq=1, locbitmap=False),
                    dict(bsize=1, blbuck=1, locfreq=3), dict(bsize=12, blbuck=100, locfreq=32),
                    dict(mkindex=True), dict(bsize=4, blbuck=3, locfreq=6, mkindex=True),
+                   dict(sprank=True), dict(sprank=True, bsize=3, blbuck=5, locfreq=7, locbitmap=False),
                    dict(bsize=16, blbuck=2, locfreq=0), dict(bsize=2, blbuck=4096, locfreq=16,
                                                             locbitmap=True)):
             _against_oracle(enc, 4, builder, **kw)

@@ -5,6 +5,8 @@ tandem repeats, special runs, separators; DNA and protein) through
   * DNA: the same build through the MSD first sort (forced, random depth),
   * a part build with 2..5 parts (thread transport on one device),
   * the device FASTA reader (random line widths, CRLF, blank lines),
+  * the packed-index builder (INDEX.bdx image: random block size, blocks per
+    bucket, locate interval and mode, -sprank, both flavours),
 each compared with the CPU oracle / host reader.  Dev tool; stops at the first
 difference and prints the seed.
 
@@ -23,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_util as ou  # noqa: E402
 import thread_comm  # noqa: E402
-from genometools_amd import encode, esa  # noqa: E402
+from genometools_amd import encode, esa, pck  # noqa: E402
 
 
 def random_sequence(rng, sigma):
@@ -86,6 +88,30 @@ def check_engine(rng, enc, sigma):
         assert res.stats["largelcpvalues"] == ora["stats"]["largelcpvalues"]
         assert res.stats["maxbranchdepth"] == ora["stats"]["maxbranchdepth"]
     return ora
+
+
+_pck = None
+
+
+def check_pck(rng, enc, sigma, ora):
+    """INDEX.bdx from the tables of a fresh build against the oracle's restatement
+    (skipped for a one-symbol sequence... no: total length 2 is fine)"""
+    global _pck
+    if _pck is None:
+        _pck = pck.PackedIndex()
+    bmax = 10 if sigma == 4 else 3
+    kw = dict(bsize=int(rng.integers(1, bmax + 1)),
+              blbuck=int(rng.choice([1, 2, 3, 5, 8, 8, 8, 13, 64, 300])),
+              locfreq=int(rng.choice([0, 1, 2, 3, 7, 16, 16, 32, 1000])),
+              locbitmap=[None, True, False][int(rng.integers(0, 3))],
+              mkindex=bool(rng.integers(0, 2)), sprank=bool(rng.integers(0, 2)))
+    with esa.EsaEngine(enc.size, sigma) as eng:
+        eng.set_sequence(enc)
+        eng.run(esa.WANT_SUF | esa.WANT_BWT)
+        _pck.build_from_esa(eng, **kw)
+        got = _pck.image().tobytes()
+    want = ou.pck_bdx(enc, sigma, ora["suf"], ora["bwt"], **kw)
+    assert got == want, "packed index %r" % (kw,)
 
 
 def check_msd(rng, enc, ora):
@@ -203,6 +229,8 @@ def main():
                     check_parts(rng, enc, sigma, ora)
                 if enc.size <= 20000 and case % 2 == 0:
                     check_encoder(rng, enc, sigma, tmp)
+                if case % 7 != 3:
+                    check_pck(rng, enc, sigma, ora)
             except Exception:
                 print("FAILED: seed %d case %d sigma %d n %d" % (seed, case, sigma, enc.size),
                       flush=True)

@@ -53,6 +53,7 @@ struct PckGeom {
   u64 first_special_row; // rows from here on hold suffixes that start with a special
   u64 cw_base_bit, var_base_bit;  // bit positions in the image
   u64 lut_entries;       // sigma^B, 0: indices are computed, not looked up
+  u64 inv_L;             // ceil(2^32 / L)
   u32 sigma, B, K, L, LP;
   u32 T, ntiles;
   u32 locint, locmask, loc_pow2, loc_bitmap, loc_count;
@@ -62,7 +63,6 @@ struct PckGeom {
   u32 lds_cw_off, lds_cw_words, lds_var_off, lds_var_words;   // EMIT: LDS copies of the tile's bit strings (0 words: none)
   u32 reversible, bits_orig_rank;   // -sprank: specials sorted reversibly, bits per rank
   u64 total_specials;
-  u32 dbg_skip;          // timing experiments only (GTAMD_PCK_SKIP): parts of the emission left out
 };
 
 // ---- block -> (composition index, permutation index, bits) -------------------
@@ -229,6 +229,28 @@ __device__ __forceinline__ u64 special_rank(const u64 *__restrict__ bits, const 
   return (u64) pre[w] + (o ? (u64) __popcll(bits[w] & ((1ull << o) - 1)) : 0);
 }
 
+// the table entries of the blocks b8 .. b8 + 7 of a bucket (its symbols at
+// `mine` in LDS): the eight look-ups are issued together
+__device__ __forceinline__ void block_entries8(const PckGeom &g, const u8 *mine,
+                                               const u64 *__restrict__ lut, u32 b8, u32 nblk,
+                                               u64 e[8]) {
+  u32 code[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u32 c = 0;
+    if (b8 + k < nblk) {
+      const u8 *bp = mine + (size_t) (b8 + k) * g.B;
+      for (u32 i = 0; i < g.B; i++) {
+        const u32 x = bp[i] & 63u;
+        c = c * g.sigma + (x >= LDS_SPECIAL ? 0u : x);    // region symbols fall back to letter 0
+      }
+    }
+    code[k] = c;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) e[k] = b8 + k < nblk ? lut[code[k]] : 0;
+}
+
 // ---- the tile kernel -----------------------------------------------------------
 // tile_tot: (sigma + 3) columns of ntiles u64: COUNT writes the tile's totals,
 // the scan turns each column into exclusive prefixes, EMIT reads them.
@@ -251,26 +273,51 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   // stage the symbols (and the locate marks) of the tile, bucket-major with an
   // odd word stride; positions behind the end read as letter 0 (the fill of the
   // last block, eis-blockcomp.c:587-589)
-  for (u32 i = tid; i < nbk * g.L; i += PCK_THREADS) {
-    u32 code = 0;
-    if (i < npos) {
-      const u64 p = p0 + i;
-      const u32 c = bwt[p];
-      code = c >= 254 ? LDS_SPECIAL + (c - 254) : c;
-      if (g.locint) {
-        // addLocateInfo, eis-bwtseq-extinfo.c:420-441: every locint-th text
-        // position, and the positions where letters and specials meet
-        // (isSortModeTransition :343-382): the symbol before the suffix is the
-        // BWT symbol, the suffix starts with a special iff its row lies in the
-        // tail of the table
-        const u64 v = suf[p];
-        const bool hit = g.loc_pow2 ? (v & g.locmask) == 0 : (v % g.locint) == 0;
-        // (-sprank: the specials are sorted reversibly, no marks where they meet letters)
-        const bool tr = !g.reversible && (c >= 254) != (p >= g.first_special_row);
-        if (hit || tr) code |= LDS_MARK;
+  // (eight positions per thread and step: all loads of a step are issued before
+  // the first is used -- one position per step left the tile waiting for memory
+  // 64 times in a row)
+  constexpr int SU = 8;
+  for (u32 base = 0; base < nbk * g.L; base += PCK_THREADS * SU) {
+    u32 cc[SU];
+    u64 vv[SU];
+#pragma unroll
+    for (int k = 0; k < SU; k++) {
+      const u32 i = base + (u32) k * PCK_THREADS + tid;
+      cc[k] = i < npos ? (u32) bwt[p0 + i] : 0u;
+    }
+    if (g.locint) {
+#pragma unroll
+      for (int k = 0; k < SU; k++) {
+        const u32 i = base + (u32) k * PCK_THREADS + tid;
+        vv[k] = i < npos ? suf[p0 + i] : 1u;
       }
     }
-    s_sym[(i / g.L) * g.LP + i % g.L] = (u8) code;
+#pragma unroll
+    for (int k = 0; k < SU; k++) {
+      const u32 i = base + (u32) k * PCK_THREADS + tid;
+      if (i >= nbk * g.L) break;
+      u32 code = 0;
+      if (i < npos) {
+        const u64 p = p0 + i;
+        const u32 c = cc[k];
+        code = c >= 254 ? LDS_SPECIAL + (c - 254) : c;
+        if (g.locint) {
+          // addLocateInfo, eis-bwtseq-extinfo.c:420-441: every locint-th text
+          // position, and the positions where letters and specials meet
+          // (isSortModeTransition :343-382): the symbol before the suffix is the
+          // BWT symbol, the suffix starts with a special iff its row lies in the
+          // tail of the table
+          const u64 v = vv[k];
+          const bool hit = g.loc_pow2 ? (v & g.locmask) == 0 : (v % g.locint) == 0;
+          // (-sprank: the specials are sorted reversibly, no marks where they meet letters)
+          const bool tr = !g.reversible && (c >= 254) != (p >= g.first_special_row);
+          if (hit || tr) code |= LDS_MARK;
+        }
+      }
+      // i / L by multiplication (exact for i, L <= 16384: i * (L - 1) < 2^32)
+      const u32 q = (u32) (((u64) i * g.inv_L) >> 32);
+      s_sym[q * g.LP + (i - q * g.L)] = (u8) code;
+    }
   }
   for (u32 i = tid; i < g.sigma * g.T; i += PCK_THREADS) s_cnt[i] = 0;
   __syncthreads();
@@ -291,31 +338,33 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     if (len && bpos + len < g.N)
       next = (tid + 1 < nbk) ? (mine[g.LP] & 63u)
                              : (bwt[bpos + len] >= 254 ? LDS_SPECIAL + (bwt[bpos + len] - 254) : 0u);
-    u32 cnt_scratch[PCK_MAX_SIGMA + 2];
-    for (u32 b = 0; b < nblk; b++) {
-      u64 code = 0;
-      u8 bs[16];
-      for (u32 i = 0; i < g.B; i++) {
-        const u32 off = b * g.B + i;
-        const u32 raw = mine[off];
-        const u32 c = raw & 63u;
-        const u32 letter = c >= LDS_SPECIAL ? 0u : c;     // region symbols fall back to letter 0
-        bs[i] = (u8) letter;
-        code = code * g.sigma + letter;
-        if (off < len) {
-          if (c < LDS_SPECIAL) s_cnt[c * g.T + tid]++;
-          else {
-            const u32 before = off ? (mine[off - 1] & 63u) : prev;
-            const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
-            nstart += before != c;
-            nend += after != c;
-            nranks++;
-          }
-          nmarks += (raw & LDS_MARK) != 0;
-        }
+    for (u32 off = 0; off < len; off++) {
+      const u32 raw = mine[off];
+      const u32 c = raw & 63u;
+      if (c < LDS_SPECIAL) s_cnt[c * g.T + tid]++;
+      else {
+        const u32 before = off ? (mine[off - 1] & 63u) : prev;
+        const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
+        nstart += before != c;
+        nend += after != c;
+        nranks++;
       }
-      const u64 e = g.lut_entries ? lut[code] : block_indices(bs, g.sigma, g.B, cnt_scratch);
-      pbits_sum += (u32) (e >> 58);
+      nmarks += (raw & LDS_MARK) != 0;
+    }
+    if (g.lut_entries) {
+      for (u32 b8 = 0; b8 < nblk; b8 += 8) {
+        u64 e[8];
+        block_entries8(g, mine, lut, b8, nblk, e);
+#pragma unroll
+        for (int k = 0; k < 8; k++) pbits_sum += (u32) (e[k] >> 58);
+      }
+    } else {
+      u32 cnt_scratch[PCK_MAX_SIGMA + 2];
+      for (u32 b = 0; b < nblk; b++) {
+        u8 bs[16];
+        for (u32 i = 0; i < g.B; i++) { const u32 c = mine[b * g.B + i] & 63u; bs[i] = (u8) (c >= LDS_SPECIAL ? 0u : c); }
+        pbits_sum += (u32) (block_indices(bs, g.sigma, g.B, cnt_scratch) >> 58);
+      }
     }
   }
   // bits of the bucket's var part
@@ -361,7 +410,7 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   for (u32 s = 0; s < g.sigma; s++) {
     const u32 ex = block_scan_excl_sum(live ? (u32) s_cnt[s * g.T + tid] : 0, &tot, s4);
     if (!EMIT) { if (tid == 0) tile_tot[(u64) s * g.ntiles + tile] = tot; }
-    else if (live && !(g.dbg_skip & 4))   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
+    else if (live)   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
       sink_put(cw_sink, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
   }
   if (!EMIT) return;
@@ -380,56 +429,80 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     if (len && bpos + len < g.N)
       next = (tid + 1 < nbk) ? (mine[g.LP] & 63u)
                              : (bwt[bpos + len] >= 254 ? LDS_SPECIAL + (bwt[bpos + len] - 254) : 0u);
-    u32 cnt_scratch[PCK_MAX_SIGMA + 2];
-    if (!(g.dbg_skip & 2))
-    for (u32 b = 0; b < nblk; b++) {
-      u64 code = 0;
-      u8 bs[16];
-      for (u32 i = 0; i < g.B; i++) {
-        const u32 off = b * g.B + i;
-        const u32 c = mine[off] & 63u;
-        const u32 letter = c >= LDS_SPECIAL ? 0u : c;
-        bs[i] = (u8) letter;
-        code = code * g.sigma + letter;
-        if (off < len && c >= LDS_SPECIAL) {
-          // region list of the specials, gt_SRLAddPosition eis-seqranges.c:183-213
-          const u32 before = off ? (mine[off - 1] & 63u) : prev;
-          const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
-          if (before != c) rstart[ridx_s++] = (bpos + off) | ((u64) (c - LDS_SPECIAL) << 63);
-          if (after != c) rend[ridx_e++] = bpos + off + 1;
+    {
+      if (nranks)
+        // region list of the specials, gt_SRLAddPosition eis-seqranges.c:183-213
+        for (u32 off = 0; off < len; off++) {
+          const u32 c = mine[off] & 63u;
+          if (c >= LDS_SPECIAL) {
+            const u32 before = off ? (mine[off - 1] & 63u) : prev;
+            const u32 after = off + 1 < len ? (mine[off + 1] & 63u) : next;
+            if (before != c) rstart[ridx_s++] = (bpos + off) | ((u64) (c - LDS_SPECIAL) << 63);
+            if (after != c) rend[ridx_e++] = bpos + off + 1;
+          }
+        }
+      // append2IdxOutput, eis-blockcomp.c:1762-1775
+      if (g.lut_entries) {
+        for (u32 b8 = 0; b8 < nblk; b8 += 8) {
+          u64 e[8];
+          block_entries8(g, mine, lut, b8, nblk, e);
+#pragma unroll
+          for (int k = 0; k < 8; k++)
+            if (b8 + k < nblk) {
+              sink_put(cw_sink, cwbit + g.pre_comp_idx + (b8 + k) * g.comp_idx_bits, g.comp_idx_bits,
+                       (e[k] >> 40) & 0x3ffffu);
+              const u32 pb = (u32) (e[k] >> 58);
+              sink_put(var_sink, vbit, pb, e[k] & 0xffffffffffull);
+              vbit += pb;
+            }
+        }
+      } else {
+        u32 cnt_scratch[PCK_MAX_SIGMA + 2];
+        for (u32 b = 0; b < nblk; b++) {
+          u8 bs[16];
+          for (u32 i = 0; i < g.B; i++) { const u32 c = mine[b * g.B + i] & 63u; bs[i] = (u8) (c >= LDS_SPECIAL ? 0u : c); }
+          const u64 e = block_indices(bs, g.sigma, g.B, cnt_scratch);
+          sink_put(cw_sink, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits, (e >> 40) & 0x3ffffu);
+          const u32 pb = (u32) (e >> 58);
+          sink_put(var_sink, vbit, pb, e & 0xffffffffffull);
+          vbit += pb;
         }
       }
-      const u64 e = g.lut_entries ? lut[code] : block_indices(bs, g.sigma, g.B, cnt_scratch);
-      // append2IdxOutput, eis-blockcomp.c:1762-1775
-      sink_put(cw_sink, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits,
-               (e >> 40) & 0x3ffffu);
-      const u32 pb = (u32) (e >> 58);
-      sink_put(var_sink, vbit, pb, e & 0xffffffffffull);
-      vbit += pb;
     }
   }
   if (g.locint) {
     // addLocateInfo, eis-bwtseq-extinfo.c:384-541
-    if (g.loc_bitmap) {
-      for (u32 o = 0; o < len; o += 64) {
-        const u32 m = min(64u, len - o);
-        u64 bitsv = 0;
-        for (u32 i = 0; i < m; i++) bitsv = (bitsv << 1) | ((mine[o + i] & LDS_MARK) ? 1u : 0u);
-        sink_put(cw_sink, cwbit + g.pre_cw_ext + o, m, bitsv);
-      }
-    }
     const u32 bits_bwt_pos = reqbits((u64) len - 1);
     if (g.loc_count) { const u32 bc = reqbits(len); sink_put(var_sink, vbit, bc, nmarks); vbit += bc; }
-    if (!(g.dbg_skip & 1))
-    for (u32 o = 0; o < len; o++)
-      if (mine[o] & LDS_MARK) {
-        if (g.loc_count) { sink_put(var_sink, vbit, bits_bwt_pos, o); vbit += bits_bwt_pos; }
-        u64 v = (g.dbg_skip & 8) ? o : suf[bpos + o];
-        if (g.reversible) v = g.loc_pow2 ? v >> __popc(g.locmask) : v / g.locint;
-        sink_put(var_sink, vbit, g.bits_orig_pos, v);
-        vbit += g.bits_orig_pos;
+    for (u32 o0 = 0; o0 < len; o0 += 64) {
+      const u32 m = min(64u, len - o0);
+      u64 marks = 0;
+      for (u32 i = 0; i < m; i++) marks |= (u64) ((mine[o0 + i] & LDS_MARK) ? 1u : 0u) << i;
+      if (g.loc_bitmap) sink_put(cw_sink, cwbit + g.pre_cw_ext + o0, m, __brevll(marks) >> (64 - m));
+      // the text positions of the marked rows, eight loads at a time
+      while (marks) {
+        u32 off[8];
+        u64 v[8];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          off[k] = 0;
+          if (marks) { off[k] = o0 + (u32) __builtin_ctzll(marks); marks &= marks - 1; cnt = k + 1; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = k < cnt ? suf[bpos + off[k]] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k < cnt) {
+            if (g.loc_count) { sink_put(var_sink, vbit, bits_bwt_pos, off[k]); vbit += bits_bwt_pos; }
+            u64 x = v[k];
+            if (g.reversible) x = g.loc_pow2 ? x >> __popc(g.locmask) : x / g.locint;
+            sink_put(var_sink, vbit, g.bits_orig_pos, x);
+            vbit += g.bits_orig_pos;
+          }
       }
-    if (g.bits_orig_rank)
+    }
+    if (g.bits_orig_rank && nranks)
       // the symbols sorted by rank (specials, the undefined symbol before suffix 0):
       // their rank among the specials of the text, eis-bwtseq-extinfo.c:452-471, 528-541
       for (u32 o = 0; o < len; o++)
@@ -627,6 +700,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   memset(&g, 0, sizeof g);
   g.N = total_len; g.sigma = sigma; g.B = B; g.K = K; g.L = B * K;
   g.LP = 4 * (2 * ((g.L + 7) / 8) + 1);
+  g.inv_L = ((1ull << 32) + g.L - 1) / g.L;
   g.nb = (total_len + 1) / g.L + (((total_len + 1) % g.L) ? 1 : 0);     // numBuckets, eis-blockcomp.c:1633-1638
   g.T = std::max<u32>(1, std::min<u32>(PCK_THREADS, PCK_TILE_POS / g.L));
   g.ntiles = (u32) div_up(g.nb, g.T);
@@ -796,7 +870,6 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
       g.lds_var_off = (u32) lds_emit; g.lds_var_words = (u32) var_words; lds_emit += var_words * 8;
     }
   }
-  if (getenv("GTAMD_PCK_SKIP") != nullptr) g.dbg_skip = (u32) atoi(getenv("GTAMD_PCK_SKIP"));
   k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds_emit, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
                                                          p->rlist, p->rlist + std::max<u64>(1, nregions),
                                                          p->d_tail, g.nb - tail_n, p->spbits, p->sppre);

@@ -856,16 +856,15 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   p->rlist_cap = rl_cap;
   HIP_TRY(hipMemsetAsync(p->img, 0, ((file_bytes + 7) & ~7ull) + 64, p->st));
   const u64 tail_n = std::min<u64>(g.nb, PCK_TAIL_RECORDS);
-  // LDS copies of a tile's parts of the bit strings: the whole cw part when it
-  // fits 16 KB, the var part up to 24 KB (a tile with more writes straight
-  // into the image)
+  // LDS copies of a tile's parts of the bit strings: the whole cw part, and as
+  // much of the 64 KB as is left (at most 24 KB) for the var part -- a tile with
+  // more var bits writes them straight into the image, and so does every tile
+  // when the cw part alone does not fit
   size_t lds_emit = (lds + 15) & ~(size_t) 15;
   {
     const u64 cw_words = ((u64) g.T * g.cw_bits + 63) / 64 + 2;
-    const char *vw = getenv("GTAMD_PCK_VARWORDS");
-    const u64 var_words = vw != nullptr && atoll(vw) > 0 ? (u64) atoll(vw) : 3072;
-    if (cw_words * 8 <= 16384 && lds_emit + cw_words * 8 + var_words * 8 <= 65536 &&
-        getenv("GTAMD_PCK_DIRECT") == nullptr) {
+    if (lds_emit + cw_words * 8 + 1024 * 8 <= 65536 && getenv("GTAMD_PCK_DIRECT") == nullptr) {
+      const u64 var_words = std::min<u64>(3072, (65536 - lds_emit - cw_words * 8) / 8);
       g.lds_cw_off = (u32) lds_emit; g.lds_cw_words = (u32) cw_words; lds_emit += cw_words * 8;
       g.lds_var_off = (u32) lds_emit; g.lds_var_words = (u32) var_words; lds_emit += var_words * 8;
     }

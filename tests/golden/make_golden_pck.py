@@ -53,21 +53,23 @@ def md5(path):
         return hashlib.md5(f.read()).hexdigest()
 
 
-def key(name, opts, mkindex=False, sprank=False):
+def key(name, opts, mkindex=False, sprank=False, direction=None):
     b, k, f, bm = opts
     return "%s|bsize=%d|blbuck=%d|locfreq=%d|locbitmap=%s" % (
         name, b, k, f, {None: "auto", True: "yes", False: "no"}[bm]) + \
-        ("|mode=mkindex" if mkindex else "") + ("|sprank=yes" if sprank else "")
+        ("|mode=mkindex" if mkindex else "") + ("|sprank=yes" if sprank else "") + \
+        ("|dir=" + direction if direction else "")
 
 
-def run_case(tmp, name, protein, opts, mkindex=False, sprank=False):
+def run_case(tmp, name, protein, opts, mkindex=False, sprank=False, direction=None):
     src = os.path.join(OUT, "fixtures", name) if not name.startswith("extra/") \
         else os.path.join(OUT, name)
     idx = os.path.join(tmp, "idx")
     for f in os.listdir(tmp):
         os.unlink(os.path.join(tmp, f))
     subprocess.run([SFX, "-protein" if protein else "-dna", "-suf", "-bwt", "-db", src,
-                    "-indexname", idx], check=True, stdout=subprocess.DEVNULL)
+                    "-indexname", idx] + (["-dir", direction] if direction else []),
+                   check=True, stdout=subprocess.DEVNULL)
     b, k, f, bm = opts
     cmd = [PCK, "-bsize", str(b), "-blbuck", str(k), "-locfreq", str(f)]
     if bm is not None:
@@ -123,6 +125,15 @@ def main():
         for opts in [(1, 8, 16, None), (2, 3, 5, True)]:
             for mk in (False, True):
                 golden[key("sw100K2.fsa", opts, mk, True)] = run_case(tmp, "sw100K2.fsa", True, opts, mk, True)
+        # projects read in another direction (testsuite/gt_packedindex_include.rb:97-108
+        # "revcom sequence with sprank": -dir rev; the index searches build theirs with
+        # -dir rev too): trsuftab on a project the suffixerator wrote with -dir
+        for name in ["Atinsert.fna", "Duplicate.fna", "TTTN.fna"]:
+            for direction in ("rev", "cpl", "rcl"):
+                for opts, sp in (((8, 8, 16, None), False), ((8, 8, 16, None), True),
+                                 ((10, 8, 32, None), True), ((3, 5, 7, True), False)):
+                    golden[key(name, opts, False, sp, direction)] = \
+                        run_case(tmp, name, False, opts, False, sp, direction)
     with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("%d packed-index goldens" % len(golden))

@@ -256,4 +256,17 @@ def parse_pck_key(key):
         out["mkindex"] = True
     if kw.get("sprank") == "yes":
         out["sprank"] = True
+    if "dir" in kw:
+        out["direction"] = kw["dir"]
     return parts[0], out
+
+
+def apply_readmode(enc, direction):
+    """the sequence as the reference reads it with -dir fwd|rev|cpl|rcl
+    (src/core/readmode_api.h:24-27; complement for DNA letters only)"""
+    enc = np.ascontiguousarray(enc, dtype=np.uint8).copy()
+    mode = {"fwd": 0, "rev": 1, "cpl": 2, "rcl": 3}[direction]
+    L = lib()
+    L.ora_apply_readmode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int]
+    L.ora_apply_readmode(_p(enc), enc.size, mode)
+    return enc

@@ -395,10 +395,15 @@ def test_packedindex_trsuftab_writes_the_reference_file(cli, name, tmp_path):
     golden = ou.golden_pck()
     protein = name.endswith(".fsa")
     idx = str(tmp_path / "pidx")
-    subprocess.run([cli, "-protein" if protein else "-dna", "-suf", "-bwt", "-indexname", idx,
-                    "-db", ou.fixture_path(name)], check=True)
-    for key in sorted(k for k in golden if k.split("|")[0] == name and "mode=" not in k):
+    keys = sorted(k for k in golden if k.split("|")[0] == name and "mode=" not in k)
+    last_dir = None
+    for key in sorted(keys, key=lambda k: ou.parse_pck_key(k)[1].get("direction", "fwd")):
         _, kw = ou.parse_pck_key(key)
+        direction = kw.get("direction", "fwd")
+        if direction != last_dir:
+            subprocess.run([cli, "-protein" if protein else "-dna", "-suf", "-bwt", "-indexname", idx,
+                            "-dir", direction, "-db", ou.fixture_path(name)], check=True)
+            last_dir = direction
         args = ["-bsize", str(kw["bsize"]), "-blbuck", str(kw["blbuck"]), "-locfreq", str(kw["locfreq"])]
         if kw["locbitmap"] is not None:
             args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]

@@ -29,11 +29,17 @@ def test_device_bdx_equals_reference_files(name, builder):
     protein = name.endswith((".fsa", ".faa"))
     sigma = 20 if protein else 4
     enc = ou.encode_fasta(ou.fixture_path(name), protein)
-    with esa.EsaEngine(enc.size, sigma) as eng:
+    keys = sorted(k for k in GOLDEN if k.split("|")[0] == name)
+    for direction in sorted({ou.parse_pck_key(k)[1].get("direction", "fwd") for k in keys}):
+      with esa.EsaEngine(enc.size, sigma) as eng:
+        # the project as `gt suffixerator -dir DIRECTION` builds it
+        eng.set_readmode({"fwd": 0, "rev": 1, "cpl": 2, "rcl": 3}[direction])
         eng.set_sequence(enc)
         eng.run(esa.WANT_SUF | esa.WANT_BWT)
-        for key in sorted(k for k in GOLDEN if k.split("|")[0] == name):
+        for key in keys:
             _, kw = ou.parse_pck_key(key)
+            if kw.pop("direction", "fwd") != direction:
+                continue
             builder.build_from_esa(eng, **kw)
             raw = builder.image().tobytes()
             e = GOLDEN[key]

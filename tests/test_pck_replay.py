@@ -44,13 +44,15 @@ def shim():
 _tables = {}
 
 
-def _project(name):
-    if name not in _tables:
+def _project(name, direction=None):
+    if (name, direction) not in _tables:
         protein = name.endswith((".fsa", ".faa"))
         enc = ou.encode_fasta(ou.fixture_path(name), protein)
+        if direction:
+            enc = ou.apply_readmode(enc, direction)
         r = ou.esa(enc, 20 if protein else 4)
-        _tables[name] = (enc, 20 if protein else 4, r["suf"], r["bwt"])
-    return _tables[name]
+        _tables[(name, direction)] = (enc, 20 if protein else 4, r["suf"], r["bwt"])
+    return _tables[(name, direction)]
 
 
 def _reqbits(v):
@@ -83,7 +85,7 @@ def _geometry(raw, sigma, locfreq):
 @pytest.mark.parametrize("key", sorted(GOLDEN))
 def test_replay_restores_the_reference_file(key, shim):
     name, kw = ou.parse_pck_key(key)
-    enc, sigma, suf, bwt = _project(name)
+    enc, sigma, suf, bwt = _project(name, kw.pop("direction", None))
     raw = ou.pck_bdx(enc, sigma, suf, bwt, **kw)
     var_bits = ou.lib().ora_pck_last_var_bits()
     g, pre_var_idx, vdob = _geometry(raw, sigma, kw["locfreq"])

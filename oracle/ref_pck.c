@@ -23,7 +23,7 @@
   must exist (written by gt_ref_sfx).
 
   usage: gt_ref_pck [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap yes|no]
-                    [-sprank] [-mkindex] INDEX
+                    [-sprank] [-mkindex [-dir fwd|rev|cpl|rcl]] INDEX
 */
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,12 +50,14 @@
 #include "core/defined-types.h"
 #include "core/alphabet_api.h"
 #include "core/encseq_api.h"
+#include "core/readmode_api.h"
 
 int main(int argc, char **argv)
 {
   struct bwtParam params;
   unsigned bsize = 8, blbuck = 8, locfreq = 16;
   int locbitmap = -1, i, mkindex = 0, sprank = 0;
+  GtReadmode readmode = GT_READMODE_FORWARD;
   const char *index = NULL;
   GtError *err;
   GtLogger *logger;
@@ -69,6 +71,14 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-locbitmap") && i + 1 < argc) locbitmap = !strcmp(argv[++i], "yes");
     else if (!strcmp(argv[i], "-mkindex")) mkindex = 1;
     else if (!strcmp(argv[i], "-sprank")) sprank = 1;
+    else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
+      /* -dir of the index options, with -mkindex only (trsuftab takes the read
+         mode from INDEX.prj) */
+      i++;
+      readmode = !strcmp(argv[i], "rev") ? GT_READMODE_REVERSE
+               : !strcmp(argv[i], "cpl") ? GT_READMODE_COMPL
+               : !strcmp(argv[i], "rcl") ? GT_READMODE_REVCOMPL : GT_READMODE_FORWARD;
+    }
     else if (argv[i][0] != '-') index = argv[i];
     else { fprintf(stderr, "gt_ref_pck: unknown option %s\n", argv[i]); return 2; }
   }
@@ -133,7 +143,7 @@ int main(int argc, char **argv)
     prefixlength = gt_recommendedprefixlength(numofchars, gt_encseq_total_length(encseq),
                                               GT_RECOMMENDED_MULTIPLIER_DEFAULT, true);
     defaultsfxstrategy(&strategy, gt_encseq_bitwise_cmp_ok(encseq) ? false : true);
-    si = gt_newSfxInterface(GT_READMODE_FORWARD, prefixlength, 1U, 0UL, &strategy, encseq,
+    si = gt_newSfxInterface(readmode, prefixlength, 1U, 0UL, &strategy, encseq,
                             NULL, false, gt_encseq_total_length(encseq) + 1, logger, err);
     bwtSeq = si != NULL ? gt_createBWTSeqFromSfxI(&params, si, err) : NULL;
     if (bwtSeq != NULL) {
@@ -143,7 +153,7 @@ int main(int argc, char **argv)
       Definedunsignedlong longest;
       longest.defined = false;
       longest.valueunsignedlong = 0;
-      if (gt_outprjfile(index, GT_READMODE_FORWARD, encseq, 0, prefixlength, 0, 0.0, 0,
+      if (gt_outprjfile(index, readmode, encseq, 0, prefixlength, 0, 0.0, 0,
                         &longest, err) != 0) {
         fprintf(stderr, "gt_ref_pck: error: %s\n", gt_error_get(err));
         return 1;

@@ -67,8 +67,9 @@ def run_case(tmp, name, protein, opts, mkindex=False, sprank=False, direction=No
     idx = os.path.join(tmp, "idx")
     for f in os.listdir(tmp):
         os.unlink(os.path.join(tmp, f))
+    # (a mkindex run takes the direction itself: the encoded sequence is stored forward)
     subprocess.run([SFX, "-protein" if protein else "-dna", "-suf", "-bwt", "-db", src,
-                    "-indexname", idx] + (["-dir", direction] if direction else []),
+                    "-indexname", idx] + (["-dir", direction] if direction and not mkindex else []),
                    check=True, stdout=subprocess.DEVNULL)
     b, k, f, bm = opts
     cmd = [PCK, "-bsize", str(b), "-blbuck", str(k), "-locfreq", str(f)]
@@ -76,6 +77,8 @@ def run_case(tmp, name, protein, opts, mkindex=False, sprank=False, direction=No
         cmd += ["-locbitmap", "yes" if bm else "no"]
     if sprank:
         cmd.append("-sprank")
+    if mkindex and direction:
+        cmd += ["-dir", direction]
     if mkindex:
         # the construction of `gt packedindex mkindex`: BWT from the suffixerator
         # interface, with sequence statistics (src/match/sfx-run.c:369-425)
@@ -134,6 +137,16 @@ def main():
                                  ((10, 8, 32, None), True), ((3, 5, 7, True), False)):
                     golden[key(name, opts, False, sp, direction)] = \
                         run_case(tmp, name, False, opts, False, sp, direction)
+        # ... and mkindex with -dir, among them the command line of the index searches
+        # (testsuite/gt_idxsearch_include.rb:67-68: -sprank -bsize 10 -locfreq 32 -dir rev)
+        # (rev only: with cpl / rcl the reference takes its statistics from the stored
+        # sequence, not the complemented one it indexes, and stops on its own assertion,
+        # src/match/eis-bwtseq.c:97)
+        for name in ["Atinsert.fna", "Duplicate.fna"]:
+            for direction in ("rev",):
+                for opts, sp in (((10, 8, 32, None), True), ((8, 8, 16, None), False)):
+                    golden[key(name, opts, True, sp, direction)] = \
+                        run_case(tmp, name, False, opts, True, sp, direction)
     with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("%d packed-index goldens" % len(golden))

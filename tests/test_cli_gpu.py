@@ -442,6 +442,8 @@ def test_packedindex_mkindex_writes_the_reference_files(cli, name, tmp_path):
             args += ["-locbitmap", "yes" if kw["locbitmap"] else "no"]
         if kw.get("sprank"):
             args += ["-sprank"]
+        if kw.get("direction"):
+            args += ["-dir", kw["direction"]]
         subprocess.run([cli, "packedindex", "mkindex", kind, "-indexname", idx, "-db",
                         ou.fixture_path(name)] + args, check=True)
         with open(idx + ".bdx", "rb") as f:

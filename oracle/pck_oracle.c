@@ -15,9 +15,9 @@
 
   Covered: block encoding with any block size / blocks per bucket the
   reference accepts, locate information as bitmap or as counts, no locate
-  information; alphabets of the suffixerator (DNA, protein).  Not covered:
-  -sprank (reversibly sorted specials), -ctxilog (context map): both are
-  separate files / extra sections the default tool run does not write.
+  information, -sprank (reversibly sorted specials), both flavours (trsuftab:
+  no sequence statistics; mkindex: with them); alphabets of the suffixerator
+  (DNA, protein).  Not covered: -ctxilog (context map, a second file).
 */
 #include <stdint.h>
 #include <stdlib.h>

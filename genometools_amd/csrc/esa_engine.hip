@@ -1644,31 +1644,16 @@ __global__ __launch_bounds__(256) void k_pair_emit(
   const u32 base = off[blockIdx.x];
   const bool staged = tot <= (u32) PE_STAGE;
   while (ph) {
-    // four pair heads per step, their table entries loaded together
-    u64 idx[4];
-    P a4[4], b4[4];
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      idx[k] = 0;
-      if (ph) { idx[k] = w * 64 + (u64) (__ffsll((unsigned long long) ph) - 1); ph &= ph - 1; cnt = k + 1; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      a4[k] = k < cnt ? sa[idx[k]] : (P) 0;     // the stable sort left equal keys in position order
-      b4[k] = (k < cnt && sizeof(P) == 4) ? sa[idx[k] + 1] : (P) 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (k < cnt) {
-        const u64 i = idx[k];
-        const u64 j = (u64) base + local;
-        // 32-bit positions: the partner travels with the pair (no look-up later)
-        const u64 v = (sizeof(P) == 4 ? (u64) b4[k] : i) | (j << 32);
-        if (staged) { s_pk[local] = a4[k]; s_pv[local] = v; s_pi[local] = (u32) i; }
-        else { pkey[j] = a4[k]; pval[j] = v; pidx[j] = (u32) i; }
-        local++;
-      }
+    const int b = __ffsll((unsigned long long) ph) - 1;
+    ph &= ph - 1;
+    const u64 i = w * 64 + b;
+    const u64 j = (u64) base + local;
+    const P a = sa[i];    // the stable sort left equal keys in position order
+    // 32-bit positions: the partner travels with the pair (no look-up later)
+    const u64 v = (sizeof(P) == 4 ? (u64) sa[i + 1] : i) | (j << 32);
+    if (staged) { s_pk[local] = a; s_pv[local] = v; s_pi[local] = (u32) i; }
+    else { pkey[j] = a; pval[j] = v; pidx[j] = (u32) i; }
+    local++;
   }
   if (!staged) return;   // (whole workgroup)
   __syncthreads();
@@ -2452,30 +2437,13 @@ __global__ __launch_bounds__(256) void k_llv_emit(
   u32 mask = i0 < N ? llv_mask(lcp, i0, N) : 0u;
   u32 tot;
   u64 o = boff[blockIdx.x] + block_scan_excl_sum((u32) __popc(mask), &tot, s_scan);
-  if (mask == 0) return;
-  // the 16 full-width values of the thread are one 64-byte line: fetched whole
-  // (a single value costs the line anyway) and all at once -- one load per large
-  // entry, each waiting for the bit scan before it, was a chain of up to 16
-  // memory latencies in repeats
-  u32 full[LLV_PER];
-  if (i0 + LLV_PER <= N) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(lcpfull + i0);
-    const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-    full[0] = q0.x; full[1] = q0.y; full[2] = q0.z; full[3] = q0.w;
-    full[4] = q1.x; full[5] = q1.y; full[6] = q1.z; full[7] = q1.w;
-    full[8] = q2.x; full[9] = q2.y; full[10] = q2.z; full[11] = q2.w;
-    full[12] = q3.x; full[13] = q3.y; full[14] = q3.z; full[15] = q3.w;
-  } else {
-#pragma unroll
-    for (int k = 0; k < LLV_PER; k++) full[k] = i0 + k < N ? lcpfull[i0 + k] : 0u;
+  while (mask) {
+    const int k = __ffs(mask) - 1;
+    mask &= mask - 1;
+    llv[2 * o] = index_offset + i0 + k;
+    llv[2 * o + 1] = lcpfull[i0 + k];
+    o++;
   }
-#pragma unroll
-  for (int k = 0; k < LLV_PER; k++)
-    if ((mask >> k) & 1u) {
-      llv[2 * o] = index_offset + i0 + k;
-      llv[2 * o + 1] = full[k];
-      o++;
-    }
 }
 
 // grid of a kernel whose workgroups stride over `tiles` tiles: enough

@@ -250,17 +250,17 @@ int gtamd_suffixerator(int argc, const char **argv, char *err, size_t errlen);
 int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen);
 
 /* `gt packedindex trsuftab [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap
-   [yes|no]] [-v] INDEX` (tool function src/tools/gt_packedindex_trsuftab.c:44-79,
+   [yes|no]] [-sprank [yes|no]] [-sprankilog I] [-v] INDEX` (tool function src/tools/gt_packedindex_trsuftab.c:44-79,
    construction src/match/eis-bwtseq-construct.c:64-92): INDEX.bdx, the
    block-compressed BWT of the packed index, from the project's INDEX.prj / .esq /
    .bwt / .suf -- byte for byte the reference's file; built on
-   the device through include/gtamd_pck.h.  -sprank / -ctxilog are refused. */
+   the device through include/gtamd_pck.h.  -ctxilog (context map) is refused. */
 int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen);
 
 /* `gt packedindex mkindex` (src/tools/gt_packedindex.c:33-36:
    gt_parseargsandcallsuffixerator(false, ...)): the command line of
    gtamd_suffixerator without the table switches, plus -bsize -blbuck -locfreq
-   -locbitmap; writes the sequence-side files, INDEX.bdx as the reference's
+   -locbitmap -sprank -sprankilog; writes the sequence-side files, INDEX.bdx as the reference's
    run_packedindexconstruction does (src/match/sfx-run.c:369-425: with sequence
    statistics, block size 3 for alphabets of more than 10 letters) and INDEX.prj
    (no suffixes written, no `longest`). */

@@ -164,6 +164,11 @@ ABI = {
     "gtamd_pck_get_info": (_INT, [_P, ctypes.POINTER(PckInfo)]),
     "gtamd_pck_image_device": (_P, [_P]),
     "gtamd_pck_image_copy": (_INT, [_P, _P, _U64, _U64]),
+    "gtamd_pck_ctxmap_build": (_INT, [_P, _P, _U64, _INT, ctypes.POINTER(_INT)]),
+    "gtamd_pck_ctxmap_build_from_esa": (_INT, [_P, _P, _INT, ctypes.POINTER(_INT)]),
+    "gtamd_pck_ctxmap_build_host": (_INT, [_P, _P, _U64, _INT, ctypes.POINTER(_INT)]),
+    "gtamd_pck_ctxmap_bytes": (_U64, [_P]),
+    "gtamd_pck_ctxmap_copy": (_INT, [_P, _P, _U64, _U64]),
 }
 
 _lib = None

@@ -565,6 +565,18 @@ __global__ void k_pck_regions(const u64 *rstart, const u64 *rend, u64 nregions, 
   }
 }
 
+// context map, gt_BWTSCRFMapAdvance src/match/eis-bwtseq-context.c:158-177: the row
+// of the suffix behind every 2^ilog-th text position, uniform entries behind a
+// 32-bit header
+__global__ void k_pck_ctxmap(const u64 *__restrict__ suf, u64 N, u32 ilog, u32 bits, u64 *img) {
+  const u64 mask = (1ull << ilog) - 1;
+  for (u64 r = (u64) blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (u64) gridDim.x * blockDim.x) {
+    const u64 v = suf[r];
+    const u64 op = v ? v - 1 : N - 1;
+    if ((op & mask) == 0) put_bits(img, 32 + (op >> ilog) * bits, bits, r);
+  }
+}
+
 }  // namespace
 
 struct gtamd_pck {
@@ -580,6 +592,7 @@ struct gtamd_pck {
   u64 *spbits; u64 spbits_cap;     // -sprank: bitmap of the text's specials, word prefix counts,
   u32 *sppre; u64 sppre_cap;       // scan workspace
   u32 *spws; u64 spws_cap;
+  u8 *cxm; u64 cxm_cap, cxm_bytes;   // image of INDEX.<ilog>cxm
   gtamd_pck_info info;
   bool built;
 };
@@ -628,6 +641,7 @@ extern "C" void gtamd_pck_destroy(gtamd_pck *p) {
   if (p->spbits) (void) hipFree(p->spbits);
   if (p->sppre) (void) hipFree(p->sppre);
   if (p->spws) (void) hipFree(p->spws);
+  if (p->cxm) (void) hipFree(p->cxm);
   (void) hipEventDestroy(p->ev0);
   (void) hipEventDestroy(p->ev1);
   (void) hipStreamDestroy(p->st);
@@ -998,5 +1012,84 @@ extern "C" int gtamd_pck_image_copy(gtamd_pck *p, void *dst, uint64_t offset, ui
   }
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipMemcpy(dst, p->img + offset, count, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- the context map (-ctxilog, `gt packedindex mkctxmap`) ------------------------
+extern "C" int gtamd_pck_ctxmap_build(gtamd_pck *p, const uint64_t *suf, uint64_t total_len,
+                                      int ilog, int *ilog_used) {
+  if (p == nullptr || suf == nullptr || total_len < 2) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build"); return -1; }
+  // CTX_MAP_ILOG_AUTOSIZE, initBWTSeqContextRetrieverFactory eis-bwtseq-context.c:65-68
+  if (ilog < 0) ilog = (int) reqbits(reqbits(total_len));
+  // ctxMapILogIsValid, eis-bwtseq-context-param.h:36-45
+  if ((u32) ilog >= reqbits(total_len) || ilog > 62) {
+    gtamd_set_error("context map: interval 2^%d is not smaller than the sequence", ilog);
+    return -1;
+  }
+  HIP_TRY(hipSetDevice(p->device));
+  const u32 bits = reqbits(total_len - 1);
+  const u64 nentries = (total_len + (1ull << ilog) - 1) >> ilog;
+  const u64 size = 4 + (bits * nentries + 7) / 8;
+  u64 cap = p->cxm_cap;
+  TRY(grow(&p->cxm, &cap, ((size + 7) & ~7ull) + 16));
+  p->cxm_cap = cap;
+  p->cxm_bytes = 0;
+  HIP_TRY(hipMemsetAsync(p->cxm, 0, ((size + 7) & ~7ull) + 16, p->st));
+  k_pck_ctxmap<<<4096, 256, 0, p->st>>>(suf, total_len, (u32) ilog, bits, (u64 *) p->cxm);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(p->st));
+  // header: interval log and entry width, 16 bits each, most significant bit
+  // first (BWTSeqCRMapOpen :291-296); the file is created by writing the first
+  // character of its own suffix ".<ilog>cxm" to its last byte (:297-300): the
+  // unused bits of the last byte are those of '.'
+  const u8 hdr[4] = { (u8) (ilog >> 8), (u8) ilog, (u8) (bits >> 8), (u8) bits };
+  HIP_TRY(hipMemcpy(p->cxm, hdr, 4, hipMemcpyHostToDevice));
+  const u32 used = (u32) ((bits * nentries) % 8);
+  if (used) {
+    u8 last = 0;
+    HIP_TRY(hipMemcpy(&last, p->cxm + size - 1, 1, hipMemcpyDeviceToHost));
+    last |= (u8) ('.' & ((1u << (8 - used)) - 1));
+    HIP_TRY(hipMemcpy(p->cxm + size - 1, &last, 1, hipMemcpyHostToDevice));
+  }
+  p->cxm_bytes = size;
+  if (ilog_used != nullptr) *ilog_used = ilog;
+  return 0;
+}
+
+extern "C" int gtamd_pck_ctxmap_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa, int ilog,
+                                               int *ilog_used) {
+  if (p == nullptr || esa == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build_from_esa"); return -1; }
+  int device = 0; u32 sigma = 0, numparts = 0;
+  TRY(gtamd_esa_internal_info(esa, &device, &sigma, &numparts));
+  if (numparts != 1 || device != p->device) { gtamd_set_error("context map: needs the suffix array of a whole-table build on the builder's device"); return -1; }
+  const u64 *suf = (const u64 *) gtamd_esa_table_device(esa, GTAMD_TAB_SUF);
+  if (suf == nullptr) { gtamd_set_error("context map: the last run did not produce the .suf table"); return -1; }
+  return gtamd_pck_ctxmap_build(p, suf, gtamd_esa_table_entries(esa, GTAMD_TAB_SUF), ilog, ilog_used);
+}
+
+extern "C" int gtamd_pck_ctxmap_build_host(gtamd_pck *p, const uint64_t *suf, uint64_t total_len,
+                                           int ilog, int *ilog_used) {
+  if (p == nullptr || suf == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build_host"); return -1; }
+  HIP_TRY(hipSetDevice(p->device));
+  u64 *d_suf = nullptr;
+  int rc = -1;
+  if (hipMalloc(&d_suf, total_len * sizeof(u64)) != hipSuccess)
+    gtamd_set_error("context map: cannot allocate device memory for %llu suffix-array entries", (unsigned long long) total_len);
+  else if (hipMemcpy(d_suf, suf, total_len * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess)
+    gtamd_set_error("context map: cannot copy the suffix array to the device");
+  else
+    rc = gtamd_pck_ctxmap_build(p, d_suf, total_len, ilog, ilog_used);
+  if (d_suf) (void) hipFree(d_suf);
+  return rc;
+}
+
+extern "C" uint64_t gtamd_pck_ctxmap_bytes(const gtamd_pck *p) { return p != nullptr ? p->cxm_bytes : 0; }
+
+extern "C" int gtamd_pck_ctxmap_copy(gtamd_pck *p, void *dst, uint64_t offset, uint64_t count) {
+  if (p == nullptr || p->cxm_bytes == 0) { gtamd_set_error("no context map built"); return -1; }
+  if (count == 0) return 0;
+  if (dst == nullptr || offset + count > p->cxm_bytes) { gtamd_set_error("context map: range outside the image"); return -1; }
+  HIP_TRY(hipSetDevice(p->device));
+  HIP_TRY(hipMemcpy(dst, p->cxm + offset, count, hipMemcpyDeviceToHost));
   return 0;
 }

@@ -46,6 +46,26 @@ static void *read_whole(const char *path, uint64_t expect_bytes)
   return buf;
 }
 
+/* INDEX.<ilog>cxm from the builder's context map image */
+static int write_ctxmap(gtamd_pck *pck, const char *index, int ilog_used, char *err, size_t errlen)
+{
+  char path[4096];
+  const uint64_t n = gtamd_pck_ctxmap_bytes(pck);
+  uint8_t *buf = malloc(n ? n : 1);
+  FILE *fp;
+  int rc = -1;
+  snprintf(path, sizeof path, "%s.%dcxm", index, ilog_used);
+  if (buf == NULL) return pfail(err, errlen, "out of memory (%s)", "context map");
+  if (gtamd_pck_ctxmap_copy(pck, buf, 0, n) != 0) snprintf(err, errlen, "%s", gtamd_esa_last_error());
+  else if ((fp = fopen(path, "wb")) == NULL) pfail(err, errlen, "cannot open file '%s' for writing", path);
+  else {
+    rc = fwrite(buf, 1, n, fp) == n ? 0 : pfail(err, errlen, "cannot write file '%s'", path);
+    if (fclose(fp) != 0 && rc == 0) rc = pfail(err, errlen, "cannot close file '%s'", path);
+  }
+  free(buf);
+  return rc;
+}
+
 static int uint_option(int argc, const char **argv, int *i, uint32_t *out, char *err, size_t errlen)
 {
   char *end;
@@ -62,7 +82,7 @@ static int uint_option(int argc, const char **argv, int *i, uint32_t *out, char 
 int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen)
 {
   gtamd_pck_params pp = { 8, 8, 16, 0, 0 };
-  int locbitmap = -1, verbose = 0, rc = -1, protein = 0, sprank = 0;
+  int locbitmap = -1, verbose = 0, rc = -1, protein = 0, sprank = 0, ctxilog = -2;
   const char *index = NULL;
   char path[4096];
   unsigned long long totallength, longest, integersize = 64;
@@ -92,8 +112,13 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
          the file, but a value >= 0 switches the rank sort on (eis-bwtseq-param.c:98-100) */
       if (i + 1 >= argc) return pfail(err, errlen, "missing argument to option \"%s\"", a);
       if (atoi(argv[++i]) >= 0) sprank = 1;
-    } else if (!strcmp(a, "-ctxilog"))
-      return pfail(err, errlen, "option \"%s\" is not supported by the MI355X packed-index builder", a);
+    } else if (!strcmp(a, "-ctxilog")) {
+      /* gt_registerCtxMapOptions, src/match/eis-bwtseq-context-param.c:20-32: -1 the
+         automatic interval, -2 no map */
+      if (i + 1 >= argc) return pfail(err, errlen, "missing argument to option \"%s\"", a);
+      ctxilog = atoi(argv[++i]);
+      if (ctxilog < -2 || ctxilog > 63) return pfail(err, errlen, "argument to option \"%s\" must be an integer between -2 and 63", a);
+    }
     else if (a[0] == '-') return pfail(err, errlen, "unknown option: %s (try -help)", a);
     else if (index != NULL) return pfail(err, errlen, "superfluous argument \"%s\"", a);
     else index = a;
@@ -135,6 +160,16 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
   }
+  /* the context map is made beside the locate marks (addLocateInfo,
+     src/match/eis-bwtseq-extinfo.c:473-476): none without locate information */
+  if (ctxilog >= -1 && pp.locate_interval) {
+    int used = 0;
+    if (gtamd_pck_ctxmap_build_host(pck, suf, totallength + 1, ctxilog, &used) != 0) {
+      snprintf(err, errlen, "%s", gtamd_esa_last_error());
+      goto done;
+    }
+    if (write_ctxmap(pck, index, used, err, errlen) != 0) goto done;
+  }
   snprintf(path, sizeof path, "%s.bdx", index);
   if ((fp = fopen(path, "wb")) == NULL) { pfail(err, errlen, "cannot open file '%s' for writing", path); goto done; }
   {
@@ -157,5 +192,43 @@ done:
   if (fp != NULL && fclose(fp) != 0 && rc == 0) rc = pfail(err, errlen, "cannot close file '%s'", path);
   gtamd_pck_destroy(pck);
   free(bwt); free(suf);
+  return rc;
+}
+
+/* `gt packedindex mkctxmap [-ctxilog I] [-v] INDEX` (src/tools/gt_packedindex_mkctxmap.c:40-139):
+   the context map of an existing project from its INDEX.suf */
+int gtamd_packedindex_mkctxmap(int argc, const char **argv, char *err, size_t errlen)
+{
+  int ctxilog = -1, rc = -1, used = 0;
+  const char *index = NULL;
+  char path[4096];
+  unsigned long long totallength;
+  uint64_t *suf = NULL;
+  gtamd_pck *pck = NULL;
+  for (int i = 1; i < argc; i++) {
+    const char *a = argv[i];
+    if (!strcmp(a, "-ctxilog")) {
+      if (i + 1 >= argc) return pfail(err, errlen, "missing argument to option \"%s\"", a);
+      ctxilog = atoi(argv[++i]);
+    } else if (!strcmp(a, "-v")) continue;
+    else if (a[0] == '-') return pfail(err, errlen, "unknown option: %s (try -help)", a);
+    else if (index != NULL) return pfail(err, errlen, "superfluous argument \"%s\"", a);
+    else index = a;
+  }
+  if (index == NULL) return pfail(err, errlen, "missing argument%s", "");
+  if (ctxilog < -1) return pfail(err, errlen, "argument to option \"%s\" must be an integer >= -1", "-ctxilog");
+  snprintf(path, sizeof path, "%s.prj", index);
+  if (prj_value(path, "totallength", &totallength) != 0)
+    return pfail(err, errlen, "cannot read totallength from file '%s'", path);
+  snprintf(path, sizeof path, "%s.suf", index);
+  if ((suf = read_whole(path, 8 * (totallength + 1))) == NULL)
+    return pfail(err, errlen, "The project %s does not contain sufficient information to regenerate the suffix array.", index);
+  if ((pck = gtamd_pck_create(0)) == NULL ||
+      gtamd_pck_ctxmap_build_host(pck, suf, totallength + 1, ctxilog, &used) != 0)
+    snprintf(err, errlen, "%s", gtamd_esa_last_error());
+  else
+    rc = write_ctxmap(pck, index, used, err, errlen);
+  gtamd_pck_destroy(pck);
+  free(suf);
   return rc;
 }

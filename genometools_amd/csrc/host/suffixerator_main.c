@@ -24,8 +24,15 @@ int main(int argc, char **argv)
       }
       return 0;
     }
+    if (argc > 2 && !strcmp(argv[2], "mkctxmap")) {
+      if (gtamd_packedindex_mkctxmap(argc - 2, (const char **) argv + 2, err, sizeof err) != 0) {
+        fprintf(stderr, "gt packedindex mkctxmap: error: %s\n", err);
+        return 1;
+      }
+      return 0;
+    }
     if (argc < 3 || strcmp(argv[2], "trsuftab")) {
-      fprintf(stderr, "gt packedindex: error: tool mkindex or trsuftab expected\n");
+      fprintf(stderr, "gt packedindex: error: tool mkindex, trsuftab or mkctxmap expected\n");
       return 1;
     }
     if (gtamd_packedindex_trsuftab(argc - 2, (const char **) argv + 2, err, sizeof err) != 0) {

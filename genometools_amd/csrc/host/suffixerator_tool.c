@@ -176,6 +176,7 @@ typedef struct {
   gtamd_pck_params params;
   int locbitmap;                 /* -1: option not given */
   int sprank;
+  int ctxilog;                   /* -2: no context map, -1: automatic interval */
 } pck_request;
 
 static int write_bdx(gtamd_esa_ctx *ctx, const pck_request *pr, uint32_t numofchars,
@@ -199,6 +200,28 @@ static int write_bdx(gtamd_esa_ctx *ctx, const pck_request *pr, uint32_t numofch
       gtamd_pck_get_info(pck, &info) != 0) {
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
+  }
+  if (pr->ctxilog >= -1 && pp.locate_interval) {
+    /* INDEX.<ilog>cxm, made beside the locate marks (eis-bwtseq-extinfo.c:473-476) */
+    int used = 0;
+    uint64_t n;
+    uint8_t *m;
+    FILE *mf;
+    if (gtamd_pck_ctxmap_build_from_esa(pck, ctx, pr->ctxilog, &used) != 0) {
+      snprintf(err, errlen, "%s", gtamd_esa_last_error());
+      goto done;
+    }
+    n = gtamd_pck_ctxmap_bytes(pck);
+    snprintf(path, sizeof path, "%s.%dcxm", indexname, used);
+    if ((m = malloc(n ? n : 1)) == NULL || gtamd_pck_ctxmap_copy(pck, m, 0, n) != 0 ||
+        (mf = fopen(path, "wb")) == NULL) {
+      free(m);
+      fail(err, errlen, "cannot write file '%s'", path);
+      goto done;
+    }
+    if (fwrite(m, 1, n, mf) != n) { fclose(mf); free(m); fail(err, errlen, "cannot write file '%s'", path); goto done; }
+    fclose(mf);
+    free(m);
   }
   snprintf(path, sizeof path, "%s.bdx", indexname);
   if ((fp = fopen(path, "wb")) == NULL || (buf = malloc(chunk)) == NULL) {
@@ -245,7 +268,7 @@ static int uint_arg(int argc, const char **argv, int *i, uint32_t *out, char *er
 
 int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t errlen)
 {
-  pck_request pr = { { 8, 8, 16, 0, 1 }, -1, 0 };
+  pck_request pr = { { 8, 8, 16, 0, 1 }, -1, 0, -2 };
   const char **rest = malloc(sizeof *rest * (size_t) (argc + 1));
   int nrest = 0, rc;
   if (rest == NULL) return fail(err, errlen, "out of memory (%s)", "packedindex mkindex");
@@ -261,8 +284,14 @@ int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t err
     else if (!strcmp(a, "-sprankilog")) {
       if (i + 1 >= argc) rc = fail(err, errlen, "missing argument to option \"%s\"", a);
       else if (atoi(argv[++i]) >= 0) pr.sprank = 1;
-    } else if (!strcmp(a, "-ctxilog"))
-      rc = fail(err, errlen, "option \"%s\" is not supported by the MI355X packed-index builder", a);
+    } else if (!strcmp(a, "-ctxilog")) {
+      if (i + 1 >= argc) rc = fail(err, errlen, "missing argument to option \"%s\"", a);
+      else {
+        pr.ctxilog = atoi(argv[++i]);
+        if (pr.ctxilog < -2 || pr.ctxilog > 63)
+          rc = fail(err, errlen, "argument to option \"%s\" must be an integer between -2 and 63", a);
+      }
+    }
     else if (!strcmp(a, "-suf") || !strcmp(a, "-lcp") || !strcmp(a, "-bwt") || !strcmp(a, "-bck") ||
              !strcmp(a, "-suftabuint"))
       /* the index options of the packed-index variant have no table switches

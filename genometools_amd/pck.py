@@ -74,6 +74,17 @@ class PackedIndex:
         check(self._lib.gtamd_pck_build(self._p, bwt_ptr, suf_ptr, total_len, numofchars,
                                         longest, ctypes.byref(pp)))
 
+    def context_map_from_esa(self, engine, ilog=-1):
+        """INDEX.<ilog>cxm (-ctxilog; -1: the automatic interval) from the engine's
+        suffix array: (interval log used, bytes of the file)"""
+        used = ctypes.c_int()
+        check(self._lib.gtamd_pck_ctxmap_build_from_esa(self._p, engine._ctx, ilog,
+                                                        ctypes.byref(used)))
+        n = self._lib.gtamd_pck_ctxmap_bytes(self._p)
+        out = np.empty(n, dtype=np.uint8)
+        check(self._lib.gtamd_pck_ctxmap_copy(self._p, out.ctypes.data_as(ctypes.c_void_p), 0, n))
+        return used.value, out
+
     def info(self):
         inf = PckInfo()
         check(self._lib.gtamd_pck_get_info(self._p, ctypes.byref(inf)))

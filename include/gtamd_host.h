@@ -254,7 +254,7 @@ int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen);
    construction src/match/eis-bwtseq-construct.c:64-92): INDEX.bdx, the
    block-compressed BWT of the packed index, from the project's INDEX.prj / .esq /
    .bwt / .suf -- byte for byte the reference's file; built on
-   the device through include/gtamd_pck.h.  -ctxilog (context map) is refused. */
+   the device through include/gtamd_pck.h; with -ctxilog I also INDEX.<I>cxm. */
 int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t errlen);
 
 /* `gt packedindex mkindex` (src/tools/gt_packedindex.c:33-36:
@@ -265,6 +265,9 @@ int gtamd_packedindex_trsuftab(int argc, const char **argv, char *err, size_t er
    statistics, block size 3 for alphabets of more than 10 letters) and INDEX.prj
    (no suffixes written, no `longest`). */
 int gtamd_packedindex_mkindex(int argc, const char **argv, char *err, size_t errlen);
+/* `gt packedindex mkctxmap [-ctxilog I] INDEX` (src/tools/gt_packedindex_mkctxmap.c:40-139):
+   INDEX.<I>cxm from INDEX.prj / INDEX.suf; mkindex and trsuftab take -ctxilog too */
+int gtamd_packedindex_mkctxmap(int argc, const char **argv, char *err, size_t errlen);
 int gtamd_write_prj_packedindex(const char *path, const gtamd_seqstats *ss,
                                 uint32_t prefixlength, int readmode, int mirrored);
 

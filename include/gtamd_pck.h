@@ -28,7 +28,8 @@
   Covered: block encoding, locate information as counts or as bitmap
   (-locfreq, -locbitmap), none (-locfreq 0), reversibly sorted specials
   (-sprank: the ranks of the text's specials in the var parts and the sort-mode
-  extension header).  Not covered: -ctxilog (context map, a second file).
+  extension header), and the context map of -ctxilog / `gt packedindex mkctxmap`
+  (INDEX.<I>cxm, gtamd_pck_ctxmap_*).
 
   Conventions as in gtamd_esa.h: 0 / -1, message from gtamd_esa_last_error().
   Plain C; no CPU fallback.
@@ -120,6 +121,21 @@ int gtamd_pck_get_info(const gtamd_pck *pck, gtamd_pck_info *info);
 const void *gtamd_pck_image_device(const gtamd_pck *pck);
 /* copy bytes [offset, offset + count) of the image to host memory */
 int gtamd_pck_image_copy(gtamd_pck *pck, void *dst, uint64_t offset, uint64_t count);
+
+/* ---- the context map (-ctxilog I of mkindex / trsuftab, `gt packedindex
+   mkctxmap`; src/match/eis-bwtseq-context.c:36-300): INDEX.<I>cxm, for every
+   2^I-th text position the row of the suffix that follows it -- what lets the
+   reference regenerate any stretch of the text from the index.  ilog < 0: the
+   automatic interval (log of the log of the length); *ilog_used (may be NULL)
+   gets the interval of the file name.  Needs only the suffix array. */
+int gtamd_pck_ctxmap_build(gtamd_pck *pck, const uint64_t *suf_device, uint64_t total_len,
+                           int ilog, int *ilog_used);
+int gtamd_pck_ctxmap_build_from_esa(gtamd_pck *pck, const gtamd_esa_ctx *esa, int ilog,
+                                    int *ilog_used);
+int gtamd_pck_ctxmap_build_host(gtamd_pck *pck, const uint64_t *suf_host, uint64_t total_len,
+                                int ilog, int *ilog_used);
+uint64_t gtamd_pck_ctxmap_bytes(const gtamd_pck *pck);
+int gtamd_pck_ctxmap_copy(gtamd_pck *pck, void *dst, uint64_t offset, uint64_t count);
 
 #ifdef __cplusplus
 }

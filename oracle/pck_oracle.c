@@ -568,3 +568,37 @@ int ora_pck_default_toggles(unsigned block_size, unsigned bucket_blocks,
     return ORA_PCK_LOCATE_BITMAP;
   }
 }
+
+/* The context map `gt packedindex mkindex|trsuftab -ctxilog I` / `gt packedindex
+   mkctxmap` write beside the index (INDEX.<I>cxm, src/match/eis-bwtseq-context.c):
+   16 bits interval log, 16 bits entry width, then for every 2^I-th text position
+   q the row of the suffix that FOLLOWS it -- gt_BWTSCRFMapAdvance :158-177 maps
+   origPos = (suf[row] + seqLen - 1) % seqLen -- as uniform entries of bits(seqLen - 1)
+   bits, most significant bit first (readBS2Map :239-260).  The file is created
+   by writing the first character of its own suffix ".<I>cxm" at its last byte
+   (BWTSeqCRMapOpen :291-300 writes `buf`, not a zero), so the unused bits of the
+   last byte are those of '.'.  ilog < 0: gt_requiredUIntBits(requiredUlongBits(seqLen)),
+   :65-68.  Returns the interval log used, or -1. */
+int ora_pck_ctxmap(const uint64_t *suf, uint64_t total_len, int ilog, uint8_t **out,
+                   size_t *out_len)
+{
+  unsigned bits = reqbits(total_len - 1);
+  uint64_t nentries, r, size;
+  uint8_t *d;
+  if (ilog < 0) ilog = (int) reqbits(reqbits(total_len));
+  if ((unsigned) ilog >= reqbits(total_len) || ilog > 62) return -1;   /* ctxMapILogIsValid */
+  nentries = (total_len + ((uint64_t) 1 << ilog) - 1) >> ilog;
+  size = 4 + (bits * nentries + 7) / 8;
+  d = calloc((size_t) size + 8, 1);
+  d[size - 1] = '.';
+  bs_store(d, 0, 16, (uint64_t) ilog);
+  bs_store(d, 16, 16, bits);
+  for (r = 0; r < total_len; r++) {
+    uint64_t op = (suf[r] + total_len - 1) % total_len;
+    if ((op & (((uint64_t) 1 << ilog) - 1)) == 0)
+      bs_store(d + 4, (op >> ilog) * bits, bits, r);
+  }
+  *out = d;
+  *out_len = (size_t) size;
+  return ilog;
+}

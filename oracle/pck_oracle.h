@@ -37,6 +37,10 @@ int ora_pck_default_toggles(unsigned block_size, unsigned bucket_blocks,
 int ora_pck_bdx(const uint8_t *bwt, const uint64_t *suf, const uint8_t *seq,
                 uint64_t total_len, unsigned sigma, uint64_t longest,
                 const ora_pck_params *pp, uint8_t **out, size_t *out_len);
+/* the bytes of INDEX.<ilog>cxm (-ctxilog; ilog < 0: the automatic interval);
+   returns the interval log used, -1 for an invalid one */
+int ora_pck_ctxmap(const uint64_t *suf, uint64_t total_len, int ilog, uint8_t **out,
+                   size_t *out_len);
 void ora_pck_free(uint8_t *p);
 uint64_t ora_pck_last_var_bits(void);
 

@@ -23,7 +23,7 @@
   must exist (written by gt_ref_sfx).
 
   usage: gt_ref_pck [-bsize B] [-blbuck K] [-locfreq F] [-locbitmap yes|no]
-                    [-sprank] [-mkindex [-dir fwd|rev|cpl|rcl]] INDEX
+                    [-sprank] [-ctxilog I] [-mkindex [-dir fwd|rev|cpl|rcl]] INDEX
 */
 #include <stdio.h>
 #include <stdlib.h>
@@ -56,7 +56,7 @@ int main(int argc, char **argv)
 {
   struct bwtParam params;
   unsigned bsize = 8, blbuck = 8, locfreq = 16;
-  int locbitmap = -1, i, mkindex = 0, sprank = 0;
+  int locbitmap = -1, i, mkindex = 0, sprank = 0, ctxilog = CTX_MAP_ILOG_NOMAP;
   GtReadmode readmode = GT_READMODE_FORWARD;
   const char *index = NULL;
   GtError *err;
@@ -71,6 +71,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-locbitmap") && i + 1 < argc) locbitmap = !strcmp(argv[++i], "yes");
     else if (!strcmp(argv[i], "-mkindex")) mkindex = 1;
     else if (!strcmp(argv[i], "-sprank")) sprank = 1;
+    else if (!strcmp(argv[i], "-ctxilog") && i + 1 < argc) ctxilog = atoi(argv[++i]);
     else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
       /* -dir of the index options, with -mkindex only (trsuftab takes the read
          mode from INDEX.prj) */
@@ -102,7 +103,7 @@ int main(int argc, char **argv)
   params.seqParams.EISFeatureSet = gt_convertBWTOptFlags2EISFeatures(BWTDEFOPT_MULTI_QUERY);
   params.locateInterval = locfreq;
   params.sourceRankInterval = -1;
-  params.ctxMapILog = CTX_MAP_ILOG_NOMAP;
+  params.ctxMapILog = ctxilog;   /* -ctxilog: INDEX.<ilog>cxm beside INDEX.bdx */
   params.projectName = project;
   params.featureToggles = BWTBaseFeatures;
   if (locbitmap >= 0)

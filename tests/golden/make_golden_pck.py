@@ -147,6 +147,36 @@ def main():
                 for opts, sp in (((10, 8, 32, None), True), ((8, 8, 16, None), False)):
                     golden[key(name, opts, True, sp, direction)] = \
                         run_case(tmp, name, False, opts, True, sp, direction)
+        # context maps (-ctxilog I; testsuite/gt_packedindex_include.rb:50-57, 110-118):
+        # md5 + size of INDEX.<I>cxm; keys "name|ctxilog=I[|dir=..]", "used" = the I
+        # of the file name (-1: the automatic interval)
+        ctx = {}
+        for name, protein in [("Atinsert.fna", False), ("Duplicate.fna", False),
+                              ("TTTN.fna", False), ("Verysmall.fna", False),
+                              ("TTT-small.fna", False), ("Random.fna", False),
+                              ("sw100K2.fsa", True)]:
+            for direction in (None, "rev") if name == "Atinsert.fna" else (None,):
+                for ilog in (-1, 0, 1, 3, 5):
+                    src = os.path.join(OUT, "fixtures", name)
+                    idx = os.path.join(tmp, "idx")
+                    for f in os.listdir(tmp):
+                        os.unlink(os.path.join(tmp, f))
+                    subprocess.run([SFX, "-protein" if protein else "-dna", "-suf", "-bwt", "-db",
+                                    src, "-indexname", idx] +
+                                   (["-dir", direction] if direction else []),
+                                   check=True, stdout=subprocess.DEVNULL)
+                    r = subprocess.run([PCK, "-ctxilog", str(ilog)] + (["-bsize", "2"] if protein else []) + [idx],
+                                       capture_output=True, text=True)
+                    maps = [f for f in os.listdir(tmp) if f.endswith("cxm")]
+                    if r.returncode != 0 or len(maps) != 1:
+                        continue      # an interval the reference refuses for this length
+                    used = int(maps[0].split(".")[-1][:-3])
+                    k = "%s|ctxilog=%d" % (name, ilog) + ("|dir=" + direction if direction else "")
+                    ctx[k] = {"md5": md5(os.path.join(tmp, maps[0])),
+                              "size": os.path.getsize(os.path.join(tmp, maps[0])), "used": used}
+        with open(os.path.join(OUT, "golden_ctxmap.json"), "w") as f:
+            json.dump(ctx, f, indent=1, sort_keys=True)
+        print("%d context-map goldens" % len(ctx))
     with open(os.path.join(OUT, "golden_pck.json"), "w") as f:
         json.dump(golden, f, indent=1, sort_keys=True)
     print("%d packed-index goldens" % len(golden))

@@ -81,6 +81,8 @@ def lib():
                                   ctypes.POINTER(P), ctypes.POINTER(ctypes.c_size_t)]
         L.ora_pck_free.argtypes = [P]
         L.ora_pck_last_var_bits.restype = U64
+        L.ora_pck_ctxmap.argtypes = [P, U64, ctypes.c_int, ctypes.POINTER(P),
+                                     ctypes.POINTER(ctypes.c_size_t)]
         _lib = L
     return _lib
 
@@ -239,6 +241,24 @@ def pck_bdx(enc, numofchars, suf, bwt, bsize=8, blbuck=8, locfreq=16, locbitmap=
     raw = ctypes.string_at(out, n.value)
     L.ora_pck_free(out)
     return raw
+
+
+def pck_ctxmap(suf, ilog):
+    """(interval log used, bytes of INDEX.<ilog>cxm) by the oracle's restatement"""
+    L = lib()
+    suf = np.ascontiguousarray(suf, dtype=np.uint64)
+    out, n = ctypes.c_void_p(), ctypes.c_size_t()
+    used = L.ora_pck_ctxmap(_p(suf), suf.size, ilog, ctypes.byref(out), ctypes.byref(n))
+    if used < 0:
+        raise ValueError("invalid context map interval %d" % ilog)
+    raw = ctypes.string_at(out, n.value)
+    L.ora_pck_free(out)
+    return used, raw
+
+
+def golden_ctxmap():
+    with open(os.path.join(GOLDEN_DIR, "golden_ctxmap.json")) as f:
+        return json.load(f)
 
 
 def golden_pck():

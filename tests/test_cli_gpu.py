@@ -467,3 +467,37 @@ def test_packedindex_mkindex_writes_the_reference_files(cli, name, tmp_path):
     r = subprocess.run([cli, "packedindex", "mkindex", kind, "-suf", "-db", ou.fixture_path(name)],
                        capture_output=True, text=True)
     assert r.returncode == 1 and "gt packedindex mkindex: error: unknown option: -suf" in r.stderr
+
+
+def test_packedindex_context_maps_through_the_tools(cli, tmp_path):
+    """-ctxilog of trsuftab / mkindex and `gt packedindex mkctxmap`: INDEX.<I>cxm equals
+    the reference's file (tests/golden/golden_ctxmap.json)"""
+    ctx = ou.golden_ctxmap()
+    name = "Atinsert.fna"
+    idx = str(tmp_path / "cidx")
+    subprocess.run([cli, "-dna", "-suf", "-bwt", "-indexname", idx, "-db", ou.fixture_path(name)],
+                   check=True)
+
+    def check(path, key):
+        with open(path, "rb") as f:
+            raw = f.read()
+        assert len(raw) == ctx[key]["size"] and hashlib.md5(raw).hexdigest() == ctx[key]["md5"], key
+
+    for ilog in (-1, 0, 3):
+        key = "%s|ctxilog=%d" % (name, ilog)
+        used = ctx[key]["used"]
+        subprocess.run([cli, "packedindex", "mkctxmap", "-ctxilog", str(ilog), idx], check=True)
+        check("%s.%dcxm" % (idx, used), key)
+        os.remove("%s.%dcxm" % (idx, used))
+        subprocess.run([cli, "packedindex", "trsuftab", "-ctxilog", str(ilog), idx], check=True)
+        check("%s.%dcxm" % (idx, used), key)
+        os.remove("%s.%dcxm" % (idx, used))
+        mk = str(tmp_path / ("mk%d" % (ilog + 1)))
+        subprocess.run([cli, "packedindex", "mkindex", "-dna", "-ctxilog", str(ilog), "-indexname", mk,
+                        "-db", ou.fixture_path(name)], check=True)
+        check("%s.%dcxm" % (mk, used), key)
+    # no locate information, no map (the reference builds it beside the locate marks)
+    subprocess.run([cli, "packedindex", "trsuftab", "-locfreq", "0", "-ctxilog", "3", idx], check=True)
+    assert not os.path.exists(idx + ".3cxm")
+    r = subprocess.run([cli, "packedindex", "mkctxmap", "-ctxilog", "40", idx], capture_output=True, text=True)
+    assert r.returncode == 1 and "gt packedindex mkctxmap: error:" in r.stderr

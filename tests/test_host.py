@@ -653,8 +653,8 @@ def test_packedindex_trsuftab_option_errors(host, tmp_path):
     assert rc == -1 and "missing argument" in msg
     rc, msg = run("-bsize", "0", "x")
     assert rc == -1 and '"-bsize" must be an integer >= 1' in msg
-    rc, msg = run("-ctxilog", "2", "x")
-    assert rc == -1 and "not supported" in msg
+    rc, msg = run("-ctxilog", "99", "x")
+    assert rc == -1 and "between -2 and 63" in msg
     rc, msg = run("-sprank", str(tmp_path / "nothere"))
     assert rc == -1 and "nothere.prj" in msg
     rc, msg = run(str(tmp_path / "nothere"))
@@ -681,7 +681,25 @@ def test_packedindex_mkindex_option_errors(host, tmp_path):
     assert rc == -1 and '"-blbuck" must be an integer >= 1' in msg
     rc, msg = run("-locfreq", "-db", "x")
     assert rc == -1 and "non-negative integer" in msg
-    rc, msg = run("-ctxilog", "3", "-db", "x")
-    assert rc == -1 and "not supported" in msg
+    rc, msg = run("-ctxilog", "-3", "-db", "x")
+    assert rc == -1 and "between -2 and 63" in msg
     rc, msg = run("-dna", "-db", str(tmp_path / "nothere.fna"))
     assert rc == -1 and ("nothere.fna" in msg or "no HIP device" in msg)
+
+
+def test_packedindex_mkctxmap_option_errors(host, tmp_path):
+    host.gtamd_packedindex_mkctxmap.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                                ctypes.c_char_p, ctypes.c_size_t]
+
+    def run(*args):
+        argv = (ctypes.c_char_p * (len(args) + 1))(b"mkctxmap", *[a.encode() for a in args])
+        err = ctypes.create_string_buffer(2048)
+        return host.gtamd_packedindex_mkctxmap(len(args) + 1, argv, err, 2048), err.value.decode()
+
+    assert run()[0] == -1
+    rc, msg = run("-ctxilog")
+    assert rc == -1 and "missing argument" in msg
+    rc, msg = run("-ctxilog", "-2", "x")
+    assert rc == -1 and ">= -1" in msg
+    rc, msg = run(str(tmp_path / "nothere"))
+    assert rc == -1 and "nothere.prj" in msg

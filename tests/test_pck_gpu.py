@@ -126,3 +126,47 @@ def test_raw_pointer_entry_point_and_errors(builder):
         eng.run(esa.WANT_SUF)
         with pytest.raises(esa.EsaError):
             builder.build_from_esa(eng)
+
+
+CTX = ou.golden_ctxmap()
+
+
+def test_device_context_maps_equal_reference_files(builder):
+    """INDEX.<I>cxm (-ctxilog I, `gt packedindex mkctxmap`) from the engine's suffix array"""
+    done = 0
+    for name in sorted({k.split("|")[0] for k in CTX}):
+        protein = name.endswith((".fsa", ".faa"))
+        enc = ou.encode_fasta(ou.fixture_path(name), protein)
+        keys = [k for k in sorted(CTX) if k.split("|")[0] == name]
+        for direction in sorted({dict(p.split("=") for p in k.split("|")[1:]).get("dir", "fwd")
+                                 for k in keys}):
+            with esa.EsaEngine(enc.size, 20 if protein else 4) as eng:
+                eng.set_readmode({"fwd": 0, "rev": 1}[direction])
+                eng.set_sequence(enc)
+                eng.run(esa.WANT_SUF)
+                for key in keys:
+                    kw = dict(p.split("=") for p in key.split("|")[1:])
+                    if kw.get("dir", "fwd") != direction:
+                        continue
+                    used, raw = builder.context_map_from_esa(eng, int(kw["ctxilog"]))
+                    e = CTX[key]
+                    assert used == e["used"], key
+                    assert raw.size == e["size"], key
+                    assert hashlib.md5(raw.tobytes()).hexdigest() == e["md5"], key
+                    done += 1
+    assert done == len(CTX)
+
+
+def test_context_map_on_synthetic_and_invalid_interval(builder):
+    for n in (100, 4096, 300000):
+        enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 5, n)
+        with esa.EsaEngine(enc.size, 4) as eng:
+            eng.set_sequence(enc)
+            eng.run(esa.WANT_SUF)
+            suf = eng.table(esa.TAB_SUF)
+            for ilog in (-1, 0, 2, 6):
+                used, raw = builder.context_map_from_esa(eng, ilog)
+                want_used, want = ou.pck_ctxmap(suf, ilog)
+                assert used == want_used and raw.tobytes() == want, (n, ilog)
+            with pytest.raises(esa.EsaError):
+                builder.context_map_from_esa(eng, 40)     # interval longer than the sequence

@@ -186,6 +186,63 @@ __device__ __forceinline__ void sink_flush(const BitSink &k, u32 nwords) {
   }
 }
 
+// A thread writes the fields of its record in increasing bit order: they are put
+// together in a 64-bit accumulator and leave word by word -- the first and the
+// last word of a record by atomic OR (the neighbouring records share them), the
+// words between by a plain store (nobody else has bits there, the memory is
+// zeroed).  Five LDS operations per record instead of one or two per field.
+struct BitWriter {
+  BitSink k;
+  u64 acc, word;
+  u32 used;
+  bool first;
+  __device__ __forceinline__ void begin(const BitSink &sink, u64 bit) {
+    k = sink; word = bit >> 6; used = (u32) (bit & 63); acc = 0; first = true;
+  }
+  __device__ __forceinline__ void flush_word() {
+    if (acc) {
+      if (k.lds != nullptr) {
+        u64 *d = &k.lds[word - k.w0];
+        if (first) atomicOr((unsigned long long *) d, (unsigned long long) acc); else *d = acc;
+      } else {
+        const u64 x = __builtin_bswap64(acc);
+        if (first) atomicOr((unsigned long long *) &k.img[word], (unsigned long long) x); else k.img[word] = x;
+      }
+    }
+    word++; acc = 0; used = 0; first = false;
+  }
+  // zeros up to bit position `bit` (not before the current position)
+  __device__ __forceinline__ void skip_to(u64 bit) {
+    const u64 tw = bit >> 6;
+    while (word < tw) flush_word();
+    used = (u32) (bit & 63);
+  }
+  __device__ __forceinline__ void put(u32 nbits, u64 v) {
+    if (nbits == 0) return;
+    // (the reference's gt_bsStore* keep the low nbits bits of a value that does not fit)
+    if (nbits < 64) v &= (1ull << nbits) - 1;
+    if (used + nbits <= 64) {
+      acc |= v << (64 - used - nbits);
+      used += nbits;
+      if (used == 64) flush_word();
+    } else {
+      const u32 r = used + nbits - 64;
+      acc |= v >> r;
+      flush_word();
+      acc = v << (64 - r);
+      used = r;
+    }
+  }
+  __device__ __forceinline__ void put_at(u64 bit, u32 nbits, u64 v) { skip_to(bit); put(nbits, v); }
+  __device__ __forceinline__ void finish() {
+    if (acc) {
+      if (k.lds != nullptr) atomicOr((unsigned long long *) &k.lds[word - k.w0], (unsigned long long) acc);
+      else atomicOr((unsigned long long *) &k.img[word], (unsigned long long) __builtin_bswap64(acc));
+    }
+    acc = 0;
+  }
+};
+
 __global__ void k_pck_count_specials(const u8 *bwt, u64 N, unsigned long long *out) {
   __shared__ u32 s4[4];
   u32 c = 0;
@@ -407,19 +464,23 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
     for (u32 i = tid; i < var_nw; i += PCK_THREADS) var_sink.lds[i] = 0;
     __syncthreads();
   }
+  BitWriter cw_w, var_w;
+  cw_w.begin(cw_sink, cwbit);
+  var_w.begin(var_sink, 0);
   for (u32 s = 0; s < g.sigma; s++) {
     const u32 ex = block_scan_excl_sum(live ? (u32) s_cnt[s * g.T + tid] : 0, &tot, s4);
     if (!EMIT) { if (tid == 0) tile_tot[(u64) s * g.ntiles + tile] = tot; }
     else if (live)   // occurrences before the bucket, updateIdxOutput eis-blockcomp.c:1847-1855
-      sink_put(cw_sink, cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
+      cw_w.put_at(cwbit + g.sym_off[s], g.sym_bits[s], tile_tot[(u64) s * g.ntiles + tile] + ex);
   }
   if (!EMIT) return;
   if (live) {
   const u64 var_off = tile_tot[(u64) g.sigma * g.ntiles + tile] + var_ex;
-  sink_put(cw_sink, cwbit + g.pre_var_idx, g.var_off_bits, var_off);
+  cw_w.put_at(cwbit + g.pre_var_idx, g.var_off_bits, var_off);
   if (bucket >= tail_first) tail_off[bucket - tail_first] = var_off;   // for the replay of the last records
-  if (g.locint) sink_put(cw_sink, cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
+  if (g.locint) cw_w.put_at(cwbit + g.pre_cb_off, g.cb_off_bits, pbits_sum);
   u64 vbit = g.var_base_bit + var_off;
+  var_w.begin(var_sink, vbit);
   u64 ridx_s = tile_tot[(u64) (g.sigma + 1) * g.ntiles + tile] + st_ex;
   u64 ridx_e = tile_tot[(u64) (g.sigma + 2) * g.ntiles + tile] + en_ex;
   {
@@ -449,10 +510,10 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
 #pragma unroll
           for (int k = 0; k < 8; k++)
             if (b8 + k < nblk) {
-              sink_put(cw_sink, cwbit + g.pre_comp_idx + (b8 + k) * g.comp_idx_bits, g.comp_idx_bits,
-                       (e[k] >> 40) & 0x3ffffu);
+              cw_w.put_at(cwbit + g.pre_comp_idx + (b8 + k) * g.comp_idx_bits, g.comp_idx_bits,
+                          (e[k] >> 40) & 0x3ffffu);
               const u32 pb = (u32) (e[k] >> 58);
-              sink_put(var_sink, vbit, pb, e[k] & 0xffffffffffull);
+              var_w.put(pb, e[k] & 0xffffffffffull);
               vbit += pb;
             }
         }
@@ -462,9 +523,9 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
           u8 bs[16];
           for (u32 i = 0; i < g.B; i++) { const u32 c = mine[b * g.B + i] & 63u; bs[i] = (u8) (c >= LDS_SPECIAL ? 0u : c); }
           const u64 e = block_indices(bs, g.sigma, g.B, cnt_scratch);
-          sink_put(cw_sink, cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits, (e >> 40) & 0x3ffffu);
+          cw_w.put_at(cwbit + g.pre_comp_idx + b * g.comp_idx_bits, g.comp_idx_bits, (e >> 40) & 0x3ffffu);
           const u32 pb = (u32) (e >> 58);
-          sink_put(var_sink, vbit, pb, e & 0xffffffffffull);
+          var_w.put(pb, e & 0xffffffffffull);
           vbit += pb;
         }
       }
@@ -473,12 +534,12 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
   if (g.locint) {
     // addLocateInfo, eis-bwtseq-extinfo.c:384-541
     const u32 bits_bwt_pos = reqbits((u64) len - 1);
-    if (g.loc_count) { const u32 bc = reqbits(len); sink_put(var_sink, vbit, bc, nmarks); vbit += bc; }
+    if (g.loc_count) { const u32 bc = reqbits(len); var_w.put(bc, nmarks); vbit += bc; }
     for (u32 o0 = 0; o0 < len; o0 += 64) {
       const u32 m = min(64u, len - o0);
       u64 marks = 0;
       for (u32 i = 0; i < m; i++) marks |= (u64) ((mine[o0 + i] & LDS_MARK) ? 1u : 0u) << i;
-      if (g.loc_bitmap) sink_put(cw_sink, cwbit + g.pre_cw_ext + o0, m, __brevll(marks) >> (64 - m));
+      if (g.loc_bitmap) cw_w.put_at(cwbit + g.pre_cw_ext + o0, m, __brevll(marks) >> (64 - m));
       // the text positions of the marked rows, eight loads at a time
       while (marks) {
         u32 off[8];
@@ -494,10 +555,10 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
 #pragma unroll
         for (int k = 0; k < 8; k++)
           if (k < cnt) {
-            if (g.loc_count) { sink_put(var_sink, vbit, bits_bwt_pos, off[k]); vbit += bits_bwt_pos; }
+            if (g.loc_count) { var_w.put(bits_bwt_pos, off[k]); vbit += bits_bwt_pos; }
             u64 x = v[k];
             if (g.reversible) x = g.loc_pow2 ? x >> __popc(g.locmask) : x / g.locint;
-            sink_put(var_sink, vbit, g.bits_orig_pos, x);
+            var_w.put(g.bits_orig_pos, x);
             vbit += g.bits_orig_pos;
           }
       }
@@ -508,10 +569,12 @@ __global__ __launch_bounds__(PCK_THREADS) void k_pck_tile(
       for (u32 o = 0; o < len; o++)
         if ((mine[o] & 63u) >= LDS_SPECIAL) {
           const u64 v = suf[bpos + o];
-          sink_put(var_sink, vbit, g.bits_orig_rank, v ? special_rank(spbits, sppre, v - 1) : g.total_specials);
+          var_w.put(g.bits_orig_rank, v ? special_rank(spbits, sppre, v - 1) : g.total_specials);
           vbit += g.bits_orig_rank;
         }
   }
+  cw_w.finish();
+  var_w.finish();
   }  // live
   __syncthreads();
   sink_flush(cw_sink, cw_nw);

@@ -256,3 +256,141 @@ def test_positions_beyond_2p32_in_two_parts(gpu):
     finally:
         for eng in engines:
             eng.close()
+
+
+# ---- the packed index at a size the oracle cannot reach --------------------------
+def _bits(raw, pos, n):
+    """n bits at bit position pos of a byte string, most significant first"""
+    v = 0
+    for b in range(pos, pos + n):
+        v = (v << 1) | ((raw[b >> 3] >> (7 - (b & 7))) & 1)
+    return v
+
+
+def _unrank_block(comp, perm, sigma, B):
+    """the block with composition index `comp` and permutation index `perm`
+    (inverse of gt_block2IndexPair, src/match/eis-seqblocktranslate.c:436-540)"""
+    from math import comb, factorial
+    cnt, left = [], B
+    for i in range(sigma - 1):
+        k = sigma - i - 1
+        v = 0
+        while True:
+            ways = comb(left - v + k - 1, k - 1)
+            if comp < ways:
+                break
+            comp -= ways
+            v += 1
+        cnt.append(v)
+        left -= v
+    cnt.append(left)
+
+    def arrangements(c):
+        r = factorial(sum(c))
+        for x in c:
+            r //= factorial(x)
+        return r
+    out = []
+    for _ in range(B):
+        for s in range(sigma):
+            if cnt[s] == 0:
+                continue
+            cnt[s] -= 1
+            ways = arrangements(cnt)
+            if perm < ways:
+                out.append(s)
+                break
+            perm -= ways
+            cnt[s] += 1
+    return out, arrangements
+
+
+def test_packed_index_of_a_1gbp_sequence_decodes_to_the_bwt(gpu):
+    """INDEX.bdx of 10^9 bases (human-like model: wildcard runs, separators), built
+    from the resident tables: sampled buckets decode -- occurrence counters,
+    composition and permutation index of every block, locate marks -- to the .bwt
+    and .suf tables the image was made from; the region list is the list of the
+    runs of specials in the BWT; sizes add up"""
+    import struct
+    from math import comb
+    from genometools_amd import pck
+    n = 1000 * 1000 * 1000
+    buf = _device_sequence(synth.MODEL_HUMANLIKE_DNA, 43, n)
+    with esa.EsaEngine(n, 4) as eng, pck.PackedIndex() as builder:
+        eng.set_sequence_device(buf.data_ptr(), n)
+        del buf
+        eng.run(esa.WANT_SUF | esa.WANT_BWT)
+        builder.build_from_esa(eng)
+        inf = builder.info()
+        bwt = eng.table(esa.TAB_BWT)
+        N, B, K, L, sigma, locfreq = n + 1, 8, 8, 64, 4, 16
+        assert inf["num_buckets"] == (N + 1 + L - 1) // L
+        header = builder.image(0, 8192).tobytes()
+        assert header[:4] == b"BDX\0"
+        voff, roff, seqlen = (struct.unpack_from("<Q", header, o)[0] for o in (28, 40, 52))
+        assert (voff, roff, seqlen) == (inf["var_data_pos"], inf["range_enc_pos"], N)
+        bits_ulong, vdob = struct.unpack_from("<I", header, 64)[0], struct.unpack_from("<I", header, 72)[0]
+        assert bits_ulong == (N - 1).bit_length()
+        cib = (comb(B + sigma - 1, sigma - 1) - 1).bit_length()
+        cbb = struct.unpack_from("<I", header, 84 + 4 * sigma + 32 + 4)[0]
+        cw_bits = sigma * bits_ulong + vdob + cbb + K * cib
+        assert cw_bits == inf["cw_bits"]
+        assert inf["file_bytes"] == roff + 8 + 16 * inf["num_regions"]
+        assert roff == voff + (inf["var_bits"] + 7) // 8
+        # region list == runs of specials in the BWT
+        special = bwt >= 254
+        change = np.flatnonzero(np.diff(bwt.astype(np.int16)) != 0) + 1
+        starts = np.concatenate(([0], change))
+        starts = starts[special[starts]]
+        regions = builder.image(roff, 8 + 16 * inf["num_regions"]).tobytes()
+        assert struct.unpack_from("<Q", regions, 0)[0] == inf["num_regions"] == starts.size + 1
+        rec = np.frombuffer(regions, dtype=np.uint64, offset=8).reshape(-1, 2)
+        assert np.array_equal(rec[:-1, 0], starts.astype(np.uint64))
+        assert int(rec[-1, 0]) == N + B
+        # sampled buckets
+        prefix_at = {}
+        rng = np.random.default_rng(9)
+        sample = sorted(set(int(x) for x in rng.integers(0, inf["num_buckets"] - 1, 300)) |
+                        {0, 1, 100, 5000, 200000, inf["num_buckets"] - 2})
+        for j in sample:
+            rb = (j * cw_bits) // 8
+            cw = builder.image(inf["cw_data_pos"] + rb, cw_bits // 8 + 2).tobytes()
+            at = j * cw_bits - rb * 8
+            sums = [_bits(cw, at + s * bits_ulong, bits_ulong) for s in range(sigma)]
+            var_off = _bits(cw, at + sigma * bits_ulong, vdob)
+            pbits = _bits(cw, at + sigma * bits_ulong + vdob, cbb)
+            before = bwt[:j * L]
+            if j not in prefix_at:
+                prefix_at[j] = [int(np.count_nonzero(before == s)) for s in range(sigma)] \
+                    if j * L <= 5 * 10 ** 7 else None
+            if prefix_at[j] is not None:
+                assert sums == prefix_at[j], j
+            want = bwt[j * L:(j + 1) * L]
+            vb = (var_off // 8)
+            var = builder.image(voff + vb, 1024).tobytes()
+            vat = var_off - vb * 8
+            used = 0
+            for b in range(K):
+                comp = _bits(cw, at + sigma * bits_ulong + vdob + cbb + b * cib, cib)
+                block, arrangements = _unrank_block(comp, 0, sigma, B)
+                cnt = [block.count(s) for s in range(sigma)]
+                ways = arrangements(cnt)
+                pb = (ways - 1).bit_length() if ways > 1 else 0
+                perm = _bits(var, vat + used, pb)
+                used += pb
+                block, _ = _unrank_block(comp, perm, sigma, B)
+                w = want[b * B:(b + 1) * B]
+                assert block == [int(x) if x < 254 else 0 for x in w], (j, b)
+            assert used == pbits, j
+            # locate marks (count mode): number, then (row in bucket, text position)
+            suf = eng.table(esa.TAB_SUF, j * L, L)
+            nm = _bits(var, vat + used, 7)
+            used += 7
+            special_row = (np.arange(j * L, (j + 1) * L) >= N - int(np.count_nonzero(special)))
+            marked = [i for i in range(L) if int(suf[i]) % locfreq == 0 or
+                      bool(want[i] >= 254) != bool(special_row[i])]
+            assert nm == len(marked), j
+            for i in marked:
+                assert _bits(var, vat + used, 6) == i
+                assert _bits(var, vat + used + 6, bits_ulong) == int(suf[i]), (j, i)
+                used += 6 + bits_ulong

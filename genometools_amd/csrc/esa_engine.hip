@@ -2964,8 +2964,18 @@ static int msd_cbits(u64 N) {
     const int v = atoi(e);
     if (v >= 0 && v <= 8) return v;
   }
-  const int c = bits_for(N > 1 ? N - 1 : 1) - 24;    // ranges of ~256 entries after level C
-  return c < 0 ? 0 : (c > 8 ? 8 : c);
+  // Ranges of 128-256 entries after level C, but never more than 64 children per
+  // parent: a 256-way level C writes runs of 16 entries where a 64-way one
+  // writes runs of 64, and level D takes ranges of several hundred entries as
+  // readily as ranges of two hundred (3 Gbp, cbits 8 / 7 / 6: 145.5 / 139.3 /
+  // 137.4 ms; 1 Gbp, 6 / 5 / 4: 48.6 / 49.3 / 49.0).  The ranges must stay below
+  // ~770 entries on average, though: level D cuts its runs at the first range
+  // start behind 3328 entries, and a run above 4096 entries leaves the LDS
+  // kernels (3 Gbp with cbits 5, 1430 per range: 180 ms).
+  int c = bits_for(N > 1 ? N - 1 : 1) - 24;
+  if (c > 6) c = 6;
+  while (c < 8 && (N >> (16 + c)) > 770) c++;
+  return c < 0 ? 0 : c;
 }
 static u32 msd_big_max() {
   if (const char *e = getenv("GTAMD_MSD_BIG_MAX")) {   // tests: the giant path at small N

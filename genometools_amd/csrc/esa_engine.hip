@@ -2967,8 +2967,9 @@ static int msd_cbits(u64 N) {
   // Ranges of 128-256 entries after level C, but never more than 64 children per
   // parent: a 256-way level C writes runs of 16 entries where a 64-way one
   // writes runs of 64, and level D takes ranges of several hundred entries as
-  // readily as ranges of two hundred (3 Gbp, cbits 8 / 7 / 6: 145.5 / 139.3 /
-  // 137.4 ms; 1 Gbp, 6 / 5 / 4: 48.6 / 49.3 / 49.0).  The ranges must stay below
+  // readily as ranges of two hundred (3 Gbp, cbits 8 / 7 / 6 alternating in one
+  // process: 140.6 / 140.1 / 138.9 ms; 1 Gbp, 6 / 5 / 4: 48.6 / 49.3 / 49.0).  The
+  // ranges must stay below
   // ~770 entries on average, though: level D cuts its runs at the first range
   // start behind 3328 entries, and a run above 4096 entries leaves the LDS
   // kernels (3 Gbp with cbits 5, 1430 per range: 180 ms).

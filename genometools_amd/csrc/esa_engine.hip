@@ -1672,7 +1672,8 @@ __global__ __launch_bounds__(256) void k_pair_emit(
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
     Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 nrec, u64 np,
-    const u32 *__restrict__ pidx, P *__restrict__ sa, u32 *__restrict__ res, Stats *stats) {
+    const u32 *__restrict__ pidx, P *__restrict__ sa, u32 *__restrict__ res, Stats *stats,
+    int chunk) {
   // records with ordinal < np are pairs (their LCP is a table entry: counted in
   // the statistics); the others are pairs of members of small groups
   __shared__ unsigned long long s_sum[4], s_large[4];
@@ -1680,7 +1681,7 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   unsigned long long sum = 0, nlarge = 0;
   u32 mx = 0;
-  const u64 nchunks = (nrec + LCP_CHUNK - 1) / LCP_CHUNK;
+  const u64 nchunks = (nrec + chunk - 1) / chunk;
   for (u64 c = (u64) blockIdx.x * 256 + threadIdx.x; c < nchunks;
        c += (u64) gridDim.x * 256) {
     // the last records of this chunk: the pairs of a small group's members share
@@ -1690,8 +1691,8 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
     u64 ra[RING] = {0, 0, 0, 0}, rb[RING] = {0, 0, 0, 0}, rl[RING] = {0, 0, 0, 0};
     bool rf[RING] = {true, true, true, true};
     int filled = 0;
-    for (int e = 0; e < LCP_CHUNK; e++) {
-      const u64 s = c * LCP_CHUNK + e;
+    for (int e = 0; e < chunk; e++) {
+      const u64 s = c * chunk + e;
       if (s >= nrec) break;
       const u64 a = pkey[s];
       const u64 iv = pval[s];
@@ -3662,8 +3663,13 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       const P *pk_sorted = (pn & 1) ? pk_b : pk_a;
       const u64 *pv_sorted = (pn & 1) ? pv_b : pv_a;
       TRY(launch_emission());   // bandwidth-bound, beside the comparisons
-      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, LCP_CHUNK), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats);
+      // pairs per thread: a chunk's first pair pays its whole comparison, the
+      // others ride on the diagonal (3 Gbp, alternating in one process, 16 / 32 /
+      // 64 / 128 pairs: 145.0 / 144.4 / 144.0 / 143.6 ms)
+      int pair_chunk = 128;
+      if (const char *e = getenv("GTAMD_PAIR_CHUNK")) { const int v = atoi(e); if (v >= 4 && v <= 1024) pair_chunk = v; }
+      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256)), 256, 0, st>>>(
+          c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk);
       HIP_TRY(hipGetLastError());
       if (nsmall > 0) {
         k_small_combine<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(

@@ -89,7 +89,9 @@ typedef struct gtamd_pck gtamd_pck;
 int gtamd_pck_default_toggles(uint32_t block_size, uint32_t bucket_blocks,
                               uint32_t locate_interval, int locbitmap);
 
-/* a builder on HIP device `device`; NULL on failure */
+/* a builder on HIP device `device`; NULL on failure.  A builder keeps its device
+   buffers between builds (image, block table, scratch); one thread at a time
+   per builder. */
 gtamd_pck *gtamd_pck_create(int device);
 void gtamd_pck_destroy(gtamd_pck *pck);
 

@@ -2960,24 +2960,46 @@ static int ensure_workspace(gtamd_esa_ctx *c, u64 cap, u32 want, bool dist) {
 // the first sort of a DNA whole-table build, most significant digit first
 // (esa_msd.h): keygen, sort, tie bitmap and table emission in one go
 // ---------------------------------------------------------------------------
-static int msd_cbits(u64 N) {
-  if (const char *e = getenv("GTAMD_MSD_CBITS")) {   // tests: every depth at small N
+// Bits of level C.  The deepest it goes: ranges of 128-256 entries.  Fewer bits
+// are better when the ranges stay small enough for level D: a 256-way level C
+// writes runs of 16 entries where a 64-way one writes runs of 64 (3 Gbp
+// human-like, k_msd_scatter_lvl<2> 11.8 -> 8.9 ms and 30.2 -> 24.8 GB written;
+// the build with 8 / 7 / 6 bits alternating in one process: 140.6 / 140.1 /
+// 138.9 ms) -- but a level-D run ends at the first range start behind 3328
+// entries, and a run above 4096 leaves the LDS kernels: with ranges of 1430
+// entries (5 bits) the same build takes 180 ms, and a text with 70 % A + T,
+// whose 8-mer ranges differ in size by a factor of 15, takes 138.6 / 145.1 /
+// 165.9 ms with 8 / 7 / 6 bits.  So the depth is chosen per build, from the sizes
+// of the 65536 ranges level B leaves (k_msd_skew, msd_choose_cbits).
+static int msd_cbits_max(u64 N) {
+  const int c = bits_for(N > 1 ? N - 1 : 1) - 24;
+  return c < 0 ? 0 : (c > 8 ? 8 : c);
+}
+// forced depth (tests: every depth at small N), or -1
+static int msd_cbits_forced() {
+  if (const char *e = getenv("GTAMD_MSD_CBITS")) {
     const int v = atoi(e);
     if (v >= 0 && v <= 8) return v;
   }
-  // Ranges of 128-256 entries after level C, but never more than 64 children per
-  // parent: a 256-way level C writes runs of 16 entries where a 64-way one
-  // writes runs of 64, and level D takes ranges of several hundred entries as
-  // readily as ranges of two hundred (3 Gbp, cbits 8 / 7 / 6 alternating in one
-  // process: 140.6 / 140.1 / 138.9 ms; 1 Gbp, 6 / 5 / 4: 48.6 / 49.3 / 49.0).  The
-  // ranges must stay below
-  // ~770 entries on average, though: level D cuts its runs at the first range
-  // start behind 3328 entries, and a run above 4096 entries leaves the LDS
-  // kernels (3 Gbp with cbits 5, 1430 per range: 180 ms).
-  int c = bits_for(N > 1 ? N - 1 : 1) - 24;
-  if (c > 6) c = 6;
-  while (c < 8 && (N >> (16 + c)) > 770) c++;
-  return c < 0 ? 0 : c;
+  return -1;
+}
+// expected[k]: entries in runs above the LDS tile with cmax - 2 + k bits.  Per 10^9
+// entries, one bit less than the deepest is worth ~0.17 ms, two ~0.57 ms (3 Gbp,
+// alternating in one process); a per cent of the entries in oversize runs costs
+// ~0.6 ms (3 Gbp: 40 ms with 5 bits, ~11 % of the entries; 70 % A + T: 27 ms with
+// 6 instead of 8 bits).  Below 64 children per parent nothing more is gained
+// (1 Gbp, 6 / 5 / 4 bits: 48.6 / 49.3 / 49.0 ms).
+static int msd_choose_cbits(u64 N, int cmax, const float *expected) {
+  int best = cmax;
+  float best_cost = 0.0f;
+  for (int k = 1; k >= 0; k--) {
+    const int c = cmax - 2 + k;
+    if (c < 6) continue;
+    const float gain = k == 1 ? 0.17f : 0.57f;
+    const float cost = 60.0f * (expected[k] - expected[2]) / (float) N - gain;
+    if (cost < best_cost) { best = c; best_cost = cost; }
+  }
+  return best;
 }
 static u32 msd_big_max() {
   if (const char *e = getenv("GTAMD_MSD_BIG_MAX")) {   // tests: the giant path at small N
@@ -3054,11 +3076,12 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
                          u64 **fkey, u32 **fval, u64 *local_entries) {
   const u64 N = c->N;
   hipStream_t st = c->st;
-  const int cb = msd_cbits(N);
+  const int cmax = msd_cbits_max(N);
+  int cb = msd_cbits_forced() >= 0 ? msd_cbits_forced() : cmax;
   MsdWs w;
-  const u64 bytes = msd_carve(N, cb, nullptr, &w);
+  const u64 bytes = msd_carve(N, cb > cmax ? cb : cmax, nullptr, &w);    // room for the deepest level C
   TRY(ensure_buf(c, c->msd, bytes, "the tables of the first sort"));
-  (void) msd_carve(N, cb, c->msd.as<u8>(), &w);
+  (void) msd_carve(N, cb > cmax ? cb : cmax, c->msd.as<u8>(), &w);
   const u32 ntA = (u32) div_up(N, MS_TILE);
   const u32 last_valid = (u32) (N - (u64) (ntA - 1) * MS_TILE);
   const u64 pad = N + 8;
@@ -3082,6 +3105,19 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   k_msd_scatter_lvl<1><<<((w.tilesB_ub + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
       ka, xa, pa, w.desc, w.tilesB_ub, w.hist, w.tfirst, w.startB, 8, 24, kb, pb);
   HIP_TRY(hipGetLastError());
+  if (msd_cbits_forced() < 0 && cmax >= 1) {
+    // how deep level C has to cut, from the ranges level B leaves (the host
+    // waits here while the device moves the entries of level B)
+    float *d_exp = reinterpret_cast<float *>(w.counters);
+    float *h_exp = reinterpret_cast<float *>(c->h_counts);
+    HIP_TRY(hipMemsetAsync(d_exp, 0, 16, st));
+    k_msd_skew<<<MSD_PARENTS / 256, 256, 0, st>>>(w.startB, cmax, d_exp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_exp, d_exp, 12, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    cb = msd_choose_cbits(N, cmax, h_exp);
+  }
+  w.nf = (u64) MSD_PARENTS << cb;
   // ---- level C: (kb, pb) -> (ka, pa); its scatter waits for the look at the tiles
   u32 *kf = kb, *pf = pb, *ko = ka, *po = pa;   // (kf, pf): where the finest level ends up
   const u32 *F = w.startB;

@@ -522,6 +522,44 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_lvl(
   }
 }
 
+// How deep level C has to cut: the share of the entries that would land in
+// level-D runs above the LDS tile, for cmax - 2 .. cmax bits.  A run ends at the
+// first range start behind MSD_STRIDE entries: with ranges of r entries it is
+// longer than MS_TILE = MSD_STRIDE + 768 with probability (r - 768)^2 / (2 r^2)
+// (both overshoots uniform in [0, r)).  pstart: the 65536 parents after level B.
+// out[k]: expected entries in such runs for cmax - 2 + k bits.
+__global__ __launch_bounds__(256) void k_msd_skew(const u32 *__restrict__ pstart, int cmax,
+                                                  float *__restrict__ out) {
+  __shared__ float s_sum[3][4];
+  const u32 s = blockIdx.x * 256u + threadIdx.x;
+  const float size = s < MSD_PARENTS ? (float) (pstart[s + 1] - pstart[s]) : 0.0f;
+  float e[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int c = cmax - 2 + k;
+    float p = 0.0f;
+    if (c >= 0) {
+      const float r = size / (float) (1u << c);
+      const float slack = (float) (MS_TILE - MSD_STRIDE);
+      if (r > slack) { const float d = (r - slack) / r; p = 0.5f * d * d; }
+      if (r >= (float) MS_TILE) p = 1.0f;
+    }
+    e[k] = size * p;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float v = e[k];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float t = s_sum[threadIdx.x][0] + s_sum[threadIdx.x][1] + s_sum[threadIdx.x][2] +
+                    s_sum[threadIdx.x][3];
+    if (t > 0.0f) atomicAdd(&out[threadIdx.x], t);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // level D: tiles of whole finest-level ranges
 // ---------------------------------------------------------------------------

@@ -2965,12 +2965,10 @@ static int ensure_workspace(gtamd_esa_ctx *c, u64 cap, u32 want, bool dist) {
 // writes runs of 16 entries where a 64-way one writes runs of 64 (3 Gbp
 // human-like, k_msd_scatter_lvl<2> 11.8 -> 8.9 ms and 30.2 -> 24.8 GB written;
 // the build with 8 / 7 / 6 bits alternating in one process: 140.6 / 140.1 /
-// 138.9 ms) -- but a level-D run ends at the first range start behind 3328
-// entries, and a run above 4096 leaves the LDS kernels: with ranges of 1430
-// entries (5 bits) the same build takes 180 ms, and a text with 70 % A + T,
-// whose 8-mer ranges differ in size by a factor of 15, takes 138.6 / 145.1 /
-// 165.9 ms with 8 / 7 / 6 bits.  So the depth is chosen per build, from the sizes
-// of the 65536 ranges level B leaves (k_msd_skew, msd_choose_cbits).
+// 138.9 ms) -- but level D packs whole ranges into tiles of 4096 entries: a text
+// with 70 % A + T, whose 8-mer ranges differ in size by a factor of 15, takes
+// 136.1 / 136.3 / 149.4 ms with 8 / 7 / 6 bits.  So the depth is chosen per build,
+// from the sizes of the 65536 ranges level B leaves (k_msd_skew).
 static int msd_cbits_max(u64 N) {
   const int c = bits_for(N > 1 ? N - 1 : 1) - 24;
   return c < 0 ? 0 : (c > 8 ? 8 : c);
@@ -2983,20 +2981,19 @@ static int msd_cbits_forced() {
   }
   return -1;
 }
-// expected[k]: entries in runs above the LDS tile with cmax - 2 + k bits.  Per 10^9
-// entries, one bit less than the deepest is worth ~0.17 ms, two ~0.57 ms (3 Gbp,
-// alternating in one process); a per cent of the entries in oversize runs costs
-// ~0.6 ms (3 Gbp: 40 ms with 5 bits, ~11 % of the entries; 70 % A + T: 27 ms with
-// 6 instead of 8 bits).  Below 64 children per parent nothing more is gained
-// (1 Gbp, 6 / 5 / 4 bits: 48.6 / 49.3 / 49.0 ms).
-static int msd_choose_cbits(u64 N, int cmax, const float *expected) {
+// penalty[k]: what level D pays with cmax - 2 + k bits, summed over the entries
+// (k_msd_skew, ms per 10^9 entries).  Per 10^9 entries one bit less than the
+// deepest is worth ~0.17 ms, two ~0.57 ms (3 Gbp, alternating in one process).
+// Below 64 children per parent nothing more is gained (1 Gbp, 6 / 5 / 4 bits:
+// 48.6 / 49.3 / 49.0 ms).
+static int msd_choose_cbits(u64 N, int cmax, const float *penalty) {
   int best = cmax;
   float best_cost = 0.0f;
   for (int k = 1; k >= 0; k--) {
     const int c = cmax - 2 + k;
     if (c < 6) continue;
     const float gain = k == 1 ? 0.17f : 0.57f;
-    const float cost = 60.0f * (expected[k] - expected[2]) / (float) N - gain;
+    const float cost = (penalty[k] - penalty[2]) / (float) N - gain;
     if (cost < best_cost) { best = c; best_cost = cost; }
   }
   return best;
@@ -3021,7 +3018,8 @@ static u64 msd_carve(u64 N, int cb, u8 *base, MsdWs *w) {
   const u32 ntA = (u32) div_up(N, MS_TILE);
   w->tilesB_ub = ntA + 256;
   w->tilesC_ub = ntA + MSD_PARENTS;
-  w->tilesD_ub = (u32) div_up(N, MSD_STRIDE) + MSD_PARENTS;
+  // (packed tiles: two consecutive ones hold more than MS_TILE entries together)
+  w->tilesD_ub = (u32) (2 * div_up(N, MS_TILE)) + MSD_PARENTS + 8;
   w->rows = w->tilesC_ub + 2;
   w->nf = (u64) MSD_PARENTS << cb;
   Bump b;
@@ -3128,6 +3126,22 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   }
   // ---- level D tiles, and a look at them
   HIP_TRY(hipMemsetAsync(w.counters, 0, 64, st));
+  // tiles of whole ranges: packed (default), or cut by the stride rule
+  // (GTAMD_MSD_PACK=0, kept for comparison)
+  const char *pk = getenv("GTAMD_MSD_PACK");
+  const bool packed = pk == nullptr || atoi(pk) != 0;
+  u32 pack_cap = MD_CAP;
+  if (const char *e = getenv("GTAMD_MSD_PACK_CAP")) { const long v = atol(e); if (v >= 1024 && v <= (long) MD_CAP) pack_cap = (u32) v; }
+  if (packed) {
+    k_msd_pack<false><<<(MSD_PARENTS + 1 + 255) / 256, 256, 0, st>>>(F, cb, nullptr, pack_cap, w.dtcnt, nullptr,
+                                                                nullptr, nullptr, nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    TRY(scan_u32(SCAN_SUM, w.dtcnt, w.dtfirst, (u64) MSD_PARENTS + 1, false, w.scan2, st));
+    k_msd_pack<true><<<(MSD_PARENTS + 1 + 255) / 256, 256, 0, st>>>(F, cb, w.dtfirst, pack_cap, nullptr, w.dtiles,
+                                                               w.biglist, w.giantlist, w.counters,
+                                                               msd_big_max());
+    HIP_TRY(hipGetLastError());
+  } else {
   k_msd_tilecount<<<(MSD_PARENTS + 1 + 255) / 256, 256, 0, st>>>(F, cb, MSD_PARENTS, MSD_STRIDE,
                                                                w.dtcnt);
   HIP_TRY(hipGetLastError());
@@ -3136,6 +3150,7 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
                                                         w.biglist, w.giantlist, w.crowdlist,
                                                         w.counters, msd_big_max());
   HIP_TRY(hipGetLastError());
+  }
   u32 *hc = c->h_counts;
   HIP_TRY(hipMemcpyAsync(hc, w.counters, 16, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(hc + 4, w.dtfirst + MSD_PARENTS, 4, hipMemcpyDeviceToHost, st));

@@ -522,12 +522,14 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_lvl(
   }
 }
 
-// How deep level C has to cut: the share of the entries that would land in
-// level-D runs above the LDS tile, for cmax - 2 .. cmax bits.  A run ends at the
-// first range start behind MSD_STRIDE entries: with ranges of r entries it is
-// longer than MS_TILE = MSD_STRIDE + 768 with probability (r - 768)^2 / (2 r^2)
-// (both overshoots uniform in [0, r)).  pstart: the 65536 parents after level B.
-// out[k]: expected entries in such runs for cmax - 2 + k bits.
+// How deep level C has to cut: what level D pays for ranges that are larger than
+// they need be, for cmax - 2 .. cmax bits.  Level D packs whole ranges into tiles
+// of MD_CAP entries (k_msd_pack): a range above the tile is a big run (k_msd_big:
+// a fifth of k_msd_local's rate), and ranges of r entries fill a tile to
+// floor(MD_CAP / r) * r / MD_CAP only -- a half-empty tile costs k_msd_local
+// what a full one costs.  pstart: the 65536 parents after level B, whose ranges
+// are taken to be of equal size.  out[k]: sum over the entries of the penalty in
+// ms per 10^9 entries, for cmax - 2 + k bits.
 __global__ __launch_bounds__(256) void k_msd_skew(const u32 *__restrict__ pstart, int cmax,
                                                   float *__restrict__ out) {
   __shared__ float s_sum[3][4];
@@ -537,14 +539,17 @@ __global__ __launch_bounds__(256) void k_msd_skew(const u32 *__restrict__ pstart
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int c = cmax - 2 + k;
-    float p = 0.0f;
-    if (c >= 0) {
-      const float r = size / (float) (1u << c);
-      const float slack = (float) (MS_TILE - MSD_STRIDE);
-      if (r > slack) { const float d = (r - slack) / r; p = 0.5f * d * d; }
-      if (r >= (float) MS_TILE) p = 1.0f;
+    float pen = 0.0f;
+    if (c >= 0 && size > 0.0f) {
+      const float r = size / (float) (1u << c), cap = (float) MD_CAP;
+      if (r > 0.95f * cap) pen = 60.0f;                    // 0.6 ms per cent of the entries in big runs
+      else if (r >= 1.0f) {
+        const float fill = floorf(cap / r) * r / cap;
+        pen = 6.0f * (0.85f / fill - 1.0f);                // k_msd_local: 6 ms per 10^9 entries at 85 %
+        if (pen < 0.0f) pen = 0.0f;
+      }
     }
-    e[k] = size * p;
+    e[k] = size * pen;
   }
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -623,6 +628,68 @@ __global__ __launch_bounds__(256) void k_msd_dtiles(const u32 *__restrict__ F, i
     }
   }
   tiles[t] = d;
+}
+
+// The same tiles by packing: a parent's ranges in order, a tile takes whole
+// ranges while they fit `cap` entries (at least one).  Only a single range above
+// the LDS tile makes a big run; with the stride rule above two ranges of 2500
+// entries make one of 5000 (a text with 70 % A + T at 3 Gbp: 76 119 big runs, 13 %
+// of the entries, 11 ms in k_msd_big).  One thread per parent; COUNT: tiles per
+// parent (cnt[MSD_PARENTS] = 0), EMIT: the descriptors from tfirst[parent] on.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_msd_pack(const u32 *__restrict__ F, int cb,
+                                                  const u32 *__restrict__ tfirst, u32 cap,
+                                                  u32 *__restrict__ cnt, MdTile *__restrict__ tiles,
+                                                  u32 *__restrict__ biglist,
+                                                  u32 *__restrict__ giantlist,
+                                                  u32 *__restrict__ counters, u32 big_max) {
+  const u32 s = blockIdx.x * 256u + threadIdx.x;
+  if (s > MSD_PARENTS) return;
+  if (s == MSD_PARENTS) { if (!EMIT) cnt[s] = 0; return; }
+  const u64 lo = (u64) s << cb;
+  const u32 nr = 1u << cb;
+  const u32 out0 = EMIT ? tfirst[s] : 0u;
+  u32 t = 0, jstart = 0;
+  u32 begin = F[lo], prev = begin;
+  auto close = [&](u32 end, u32 jend) {
+    if (EMIT) {
+      MdTile d;
+      d.begin = begin; d.end = end; d.s16 = s;
+      d.pad = jstart | ((jend - jstart) << 16);
+      const u32 idx = out0 + t, n = end - begin;
+      if (n > big_max) {
+        giantlist[atomicAdd(&counters[3], 1u)] = idx;
+        atomicAdd(&counters[2], n);
+        atomicMax(&counters[1], n);
+      } else if (n > (u32) MS_TILE) {
+        biglist[atomicAdd(&counters[0], 1u)] = idx;
+        atomicAdd(&counters[2], n);
+        atomicMax(&counters[1], n);
+      }
+      tiles[idx] = d;
+    }
+    t++;
+  };
+  for (u32 j0 = 0; j0 < nr; j0 += 8) {
+    u32 nx[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) nx[k] = j0 + k < nr ? F[lo + j0 + k + 1] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const u32 j = j0 + (u32) k;
+      if (j < nr) {
+        const u32 next = nx[k];
+        if (prev > begin && next - begin > cap) {    // range j does not fit behind what the tile holds
+          close(prev, j);
+          begin = prev;
+          jstart = j;
+        }
+        prev = next;
+      }
+    }
+  }
+  if (prev > begin) close(prev, nr);
+  if (!EMIT) cnt[s] = t;
 }
 
 // Table entries of the sorted run [gbeg, gbeg + cnt) that lies in LDS

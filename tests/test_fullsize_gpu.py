@@ -305,6 +305,68 @@ def _unrank_block(comp, perm, sigma, B):
     return out, arrangements
 
 
+def _check_packed_index(builder, N, get_bwt, get_suf, nspecial, sample, count_prefix_below=0):
+    """header, sizes and sampled buckets of the image in `builder` (default options:
+    block size 8, 8 blocks per bucket, locate interval 16, marks as counts) against
+    the tables it was made from; get_bwt / get_suf(first, count) -> numpy"""
+    import struct
+    from math import comb
+    inf = builder.info()
+    B, K, L, sigma, locfreq = 8, 8, 64, 4, 16
+    assert inf["num_buckets"] == (N + 1 + L - 1) // L
+    header = builder.image(0, 8192).tobytes()
+    assert header[:4] == b"BDX\0"
+    voff, roff, seqlen = (struct.unpack_from("<Q", header, o)[0] for o in (28, 40, 52))
+    assert (voff, roff, seqlen) == (inf["var_data_pos"], inf["range_enc_pos"], N)
+    bits_ulong, vdob = struct.unpack_from("<I", header, 64)[0], struct.unpack_from("<I", header, 72)[0]
+    assert bits_ulong == (N - 1).bit_length()
+    cib = (comb(B + sigma - 1, sigma - 1) - 1).bit_length()
+    cbb = struct.unpack_from("<I", header, 84 + 4 * sigma + 32 + 4)[0]
+    cw_bits = sigma * bits_ulong + vdob + cbb + K * cib
+    assert cw_bits == inf["cw_bits"]
+    assert inf["file_bytes"] == roff + 8 + 16 * inf["num_regions"]
+    assert roff == voff + (inf["var_bits"] + 7) // 8
+    for j in sample:
+        rb = (j * cw_bits) // 8
+        cw = builder.image(inf["cw_data_pos"] + rb, cw_bits // 8 + 2).tobytes()
+        at = j * cw_bits - rb * 8
+        sums = [_bits(cw, at + s * bits_ulong, bits_ulong) for s in range(sigma)]
+        var_off = _bits(cw, at + sigma * bits_ulong, vdob)
+        pbits = _bits(cw, at + sigma * bits_ulong + vdob, cbb)
+        if j * L <= count_prefix_below:
+            before = get_bwt(0, j * L)
+            assert sums == [int(np.count_nonzero(before == s)) for s in range(sigma)], j
+        want = get_bwt(j * L, L)
+        vb = var_off // 8
+        var = builder.image(voff + vb, 1200).tobytes()
+        vat = var_off - vb * 8
+        used = 0
+        for b in range(K):
+            comp = _bits(cw, at + sigma * bits_ulong + vdob + cbb + b * cib, cib)
+            block, arrangements = _unrank_block(comp, 0, sigma, B)
+            ways = arrangements([block.count(s) for s in range(sigma)])
+            pb = (ways - 1).bit_length() if ways > 1 else 0
+            perm = _bits(var, vat + used, pb)
+            used += pb
+            block, _ = _unrank_block(comp, perm, sigma, B)
+            w = want[b * B:(b + 1) * B]
+            assert block == [int(x) if x < 254 else 0 for x in w], (j, b)
+        assert used == pbits, j
+        # locate marks (count mode): number, then (row in bucket, text position)
+        suf = get_suf(j * L, L)
+        nm = _bits(var, vat + used, 7)
+        used += 7
+        rows = np.arange(j * L, (j + 1) * L)
+        marked = [i for i in range(L) if int(suf[i]) % locfreq == 0 or
+                  bool(want[i] >= 254) != bool(rows[i] >= N - nspecial)]
+        assert nm == len(marked), j
+        for i in marked:
+            assert _bits(var, vat + used, 6) == i
+            assert _bits(var, vat + used + 6, bits_ulong) == int(suf[i]), (j, i)
+            used += 6 + bits_ulong
+    return inf, roff
+
+
 def test_packed_index_of_a_1gbp_sequence_decodes_to_the_bwt(gpu):
     """INDEX.bdx of 10^9 bases (human-like model: wildcard runs, separators), built
     from the resident tables: sampled buckets decode -- occurrence counters,
@@ -312,7 +374,6 @@ def test_packed_index_of_a_1gbp_sequence_decodes_to_the_bwt(gpu):
     and .suf tables the image was made from; the region list is the list of the
     runs of specials in the BWT; sizes add up"""
     import struct
-    from math import comb
     from genometools_amd import pck
     n = 1000 * 1000 * 1000
     buf = _device_sequence(synth.MODEL_HUMANLIKE_DNA, 43, n)
@@ -321,24 +382,18 @@ def test_packed_index_of_a_1gbp_sequence_decodes_to_the_bwt(gpu):
         del buf
         eng.run(esa.WANT_SUF | esa.WANT_BWT)
         builder.build_from_esa(eng)
-        inf = builder.info()
         bwt = eng.table(esa.TAB_BWT)
-        N, B, K, L, sigma, locfreq = n + 1, 8, 8, 64, 4, 16
-        assert inf["num_buckets"] == (N + 1 + L - 1) // L
-        header = builder.image(0, 8192).tobytes()
-        assert header[:4] == b"BDX\0"
-        voff, roff, seqlen = (struct.unpack_from("<Q", header, o)[0] for o in (28, 40, 52))
-        assert (voff, roff, seqlen) == (inf["var_data_pos"], inf["range_enc_pos"], N)
-        bits_ulong, vdob = struct.unpack_from("<I", header, 64)[0], struct.unpack_from("<I", header, 72)[0]
-        assert bits_ulong == (N - 1).bit_length()
-        cib = (comb(B + sigma - 1, sigma - 1) - 1).bit_length()
-        cbb = struct.unpack_from("<I", header, 84 + 4 * sigma + 32 + 4)[0]
-        cw_bits = sigma * bits_ulong + vdob + cbb + K * cib
-        assert cw_bits == inf["cw_bits"]
-        assert inf["file_bytes"] == roff + 8 + 16 * inf["num_regions"]
-        assert roff == voff + (inf["var_bits"] + 7) // 8
-        # region list == runs of specials in the BWT
+        N = n + 1
         special = bwt >= 254
+        rng = np.random.default_rng(9)
+        nb = (N + 1 + 63) // 64
+        sample = sorted(set(int(x) for x in rng.integers(0, nb - 1, 300)) |
+                        {0, 1, 100, 5000, 200000, nb - 2})
+        inf, roff = _check_packed_index(
+            builder, N, lambda first, count: bwt[first:first + count],
+            lambda first, count: eng.table(esa.TAB_SUF, first, count),
+            int(np.count_nonzero(special)), sample, count_prefix_below=5 * 10 ** 7)
+        # region list == runs of specials in the BWT
         change = np.flatnonzero(np.diff(bwt.astype(np.int16)) != 0) + 1
         starts = np.concatenate(([0], change))
         starts = starts[special[starts]]
@@ -346,51 +401,41 @@ def test_packed_index_of_a_1gbp_sequence_decodes_to_the_bwt(gpu):
         assert struct.unpack_from("<Q", regions, 0)[0] == inf["num_regions"] == starts.size + 1
         rec = np.frombuffer(regions, dtype=np.uint64, offset=8).reshape(-1, 2)
         assert np.array_equal(rec[:-1, 0], starts.astype(np.uint64))
-        assert int(rec[-1, 0]) == N + B
-        # sampled buckets
-        prefix_at = {}
-        rng = np.random.default_rng(9)
-        sample = sorted(set(int(x) for x in rng.integers(0, inf["num_buckets"] - 1, 300)) |
-                        {0, 1, 100, 5000, 200000, inf["num_buckets"] - 2})
-        for j in sample:
-            rb = (j * cw_bits) // 8
-            cw = builder.image(inf["cw_data_pos"] + rb, cw_bits // 8 + 2).tobytes()
-            at = j * cw_bits - rb * 8
-            sums = [_bits(cw, at + s * bits_ulong, bits_ulong) for s in range(sigma)]
-            var_off = _bits(cw, at + sigma * bits_ulong, vdob)
-            pbits = _bits(cw, at + sigma * bits_ulong + vdob, cbb)
-            before = bwt[:j * L]
-            if j not in prefix_at:
-                prefix_at[j] = [int(np.count_nonzero(before == s)) for s in range(sigma)] \
-                    if j * L <= 5 * 10 ** 7 else None
-            if prefix_at[j] is not None:
-                assert sums == prefix_at[j], j
-            want = bwt[j * L:(j + 1) * L]
-            vb = (var_off // 8)
-            var = builder.image(voff + vb, 1024).tobytes()
-            vat = var_off - vb * 8
-            used = 0
-            for b in range(K):
-                comp = _bits(cw, at + sigma * bits_ulong + vdob + cbb + b * cib, cib)
-                block, arrangements = _unrank_block(comp, 0, sigma, B)
-                cnt = [block.count(s) for s in range(sigma)]
-                ways = arrangements(cnt)
-                pb = (ways - 1).bit_length() if ways > 1 else 0
-                perm = _bits(var, vat + used, pb)
-                used += pb
-                block, _ = _unrank_block(comp, perm, sigma, B)
-                w = want[b * B:(b + 1) * B]
-                assert block == [int(x) if x < 254 else 0 for x in w], (j, b)
-            assert used == pbits, j
-            # locate marks (count mode): number, then (row in bucket, text position)
-            suf = eng.table(esa.TAB_SUF, j * L, L)
-            nm = _bits(var, vat + used, 7)
-            used += 7
-            special_row = (np.arange(j * L, (j + 1) * L) >= N - int(np.count_nonzero(special)))
-            marked = [i for i in range(L) if int(suf[i]) % locfreq == 0 or
-                      bool(want[i] >= 254) != bool(special_row[i])]
-            assert nm == len(marked), j
-            for i in marked:
-                assert _bits(var, vat + used, 6) == i
-                assert _bits(var, vat + used + 6, bits_ulong) == int(suf[i]), (j, i)
-                used += 6 + bits_ulong
+        assert int(rec[-1, 0]) == N + 8
+
+
+def test_packed_index_beyond_2p32_positions(gpu):
+    """more than 2^32 table entries (33-bit counters and text positions, var offsets
+    beyond 2^32 bits): tables made up on the device -- the builder takes any .bwt /
+    .suf pair -- and sampled buckets of the image decoded against them"""
+    from genometools_amd import pck
+    N = (1 << 32) + (1 << 20) + 7
+    dev = "cuda:0"
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    bwt = torch.empty(N, dtype=torch.uint8, device=dev)
+    suf = torch.empty(N, dtype=torch.int64, device=dev)
+    step = 1 << 28
+    for o in range(0, N, step):
+        m = min(step, N - o)
+        x = torch.randint(0, 4, (m,), dtype=torch.uint8, device=dev, generator=g)
+        u = torch.rand(m, device=dev, generator=g)
+        x[u < 0.01] = 254
+        bwt[o:o + m] = x
+        i = torch.arange(o, o + m, dtype=torch.int64, device=dev)
+        suf[o:o + m] = (i * 11400714819 + 12345) % N          # any values below N do
+        del x, u, i
+    # the tail of the table holds the suffixes that start with a special: as many
+    # rows as the BWT holds specials
+    nspecial = int((bwt >= 254).sum().item())
+    with pck.PackedIndex() as builder:
+        builder.build(bwt.data_ptr(), suf.data_ptr(), N, 4, 5)
+        rng = np.random.default_rng(3)
+        nb = (N + 1 + 63) // 64
+        sample = sorted(set(int(x) for x in rng.integers(0, nb - 1, 200)) |
+                        {0, 1, (1 << 26) - 1, 1 << 26, (1 << 26) + 1, nb - 2})
+        inf, _ = _check_packed_index(
+            builder, N, lambda first, count: bwt[first:first + count].cpu().numpy(),
+            lambda first, count: suf[first:first + count].cpu().numpy().astype(np.uint64),
+            nspecial, sample, count_prefix_below=10 ** 7)
+        assert inf["var_bits"] > 1 << 32

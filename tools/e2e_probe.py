@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--dir", default="/dev/shm/gtamd_e2e")
     ap.add_argument("--encoders", default="device,host")
     ap.add_argument("--tables", default="-suf -lcp -bwt")
+    ap.add_argument("--packedindex", action="store_true",
+                    help="also time `packedindex mkindex` (FASTA -> INDEX.bdx) on the same file")
     ap.add_argument("--generate-only", action="store_true",
                     help="write DIR/genome.fna and stop (input for a profiler run)")
     a = ap.parse_args()
@@ -77,6 +79,18 @@ def main():
             for ext in ("suf", "lcp", "llv", "bwt", "esq"):
                 if os.path.exists(idx + "." + ext):
                     os.unlink(idx + "." + ext)
+        if a.packedindex:
+            idx = os.path.join(a.dir, "pck")
+            t = time.time()
+            r = subprocess.run([cli, "packedindex", "mkindex", "-dna", "-v", "-indexname", idx,
+                                "-db", "genome.fna"], cwd=a.dir, capture_output=True, text=True)
+            wall = time.time() - t
+            if r.returncode != 0:
+                print("packedindex mkindex FAILED", r.stderr)
+                return 1
+            line = [l for l in r.stdout.splitlines() if l.startswith(("# seconds", "# packed index"))]
+            print("packedindex mkindex: wall %.2f s, INDEX.bdx %.1f MB\n  %s" % (
+                wall, os.path.getsize(idx + ".bdx") / 1e6, "\n  ".join(line)), flush=True)
         if len(sums) == 2:
             same = sums["device"] == sums["host"]
             print("device and host reader wrote identical files:", same)

@@ -169,3 +169,29 @@ def test_same_tables_as_the_lsd_sort(gpu, monkeypatch, model, n, seed):
     for k in ("longest", "largelcpvalues", "maxbranchdepth", "lcptabsum", "prefixlength",
               "numberofallsortedsuffixes"):
         assert out["0"][4][k] == out["1"][4][k], k
+
+
+@pytest.mark.parametrize("pack", ["0", "1"])
+@pytest.mark.parametrize("cbits", ["0", "4", "8"])
+def test_level_d_tiles_packed_and_by_stride(gpu, msd, pack, cbits):
+    """the runs of level D as whole ranges packed into tiles (default) and cut by
+    the stride rule (GTAMD_MSD_PACK=0, kept for comparison); a skewed composition
+    makes ranges of very different sizes, among them ranges above the LDS tile"""
+    msd.setenv("GTAMD_MSD_PACK", pack)
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    rng = np.random.default_rng(17)
+    for n, p in ((150000, [0.45, 0.05, 0.05, 0.45]), (400000, [0.7, 0.1, 0.1, 0.1])):
+        enc = rng.choice(4, size=n, p=p).astype(np.uint8)
+        enc[rng.integers(0, n, 40)] = 254
+        res = esa.suffixerator_tables(enc, 4)
+        _assert_same_as_oracle(enc, 4, res)
+
+
+def test_depth_of_level_c_is_chosen_from_the_ranges(gpu, msd):
+    """without GTAMD_MSD_CBITS the depth comes from the sizes of the ranges level B
+    leaves (k_msd_skew); whatever it picks, the tables are the oracle's"""
+    rng = np.random.default_rng(23)
+    for p in ([0.25, 0.25, 0.25, 0.25], [0.4, 0.1, 0.1, 0.4]):
+        enc = rng.choice(4, size=300000, p=p).astype(np.uint8)
+        res = esa.suffixerator_tables(enc, 4)
+        _assert_same_as_oracle(enc, 4, res)

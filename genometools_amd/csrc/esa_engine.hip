@@ -2477,7 +2477,7 @@ struct gtamd_esa_ctx {
   u64 max_n, n, N;         // N = n + 1 entries
   int readmode;            // GtReadmode of the sequence handed in as bytes
   hipStream_t st, st2;     // st2: table emission beside the refinement
-  hipEvent_t ev_sorted, ev_emitted;
+  hipEvent_t ev_sorted, ev_emitted, ev_applied;
   // resident sequence
   DevBuf tb_own, sp_own;
   Text text;
@@ -2496,6 +2496,8 @@ struct gtamd_esa_ctx {
   DevBuf arena_p;          // lists of the pairs and of the small groups
   DevBuf xrecv;            // part builds: receive side of the exchanges
   DevBuf winbuf;           // bitmaps and list of the rank-table windows
+  DevBuf lcpfull_buf;      // LCP values beyond the byte, by table index (when the pairs'
+                           // entries are written beside the refinement)
   u64 *llv;
   u64 llv_pairs, llv_cap;
   u32 *bck;                      // .bck sections, back to back
@@ -2566,7 +2568,8 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   if (c->st2 != nullptr) (void) hipStreamSynchronize(c->st2);
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
-                    &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf, &c->msd};
+                    &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf, &c->msd,
+                    &c->lcpfull_buf};
   for (DevBuf *b : bufs) free_buf(*b);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
@@ -2577,6 +2580,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   for (auto &e : c->ev_scatter) if (e != nullptr) (void) hipEventDestroy(e);
   if (c->ev_sorted != nullptr) (void) hipEventDestroy(c->ev_sorted);
   if (c->ev_emitted != nullptr) (void) hipEventDestroy(c->ev_emitted);
+  if (c->ev_applied != nullptr) (void) hipEventDestroy(c->ev_applied);
   if (c->st2 != nullptr) (void) hipStreamDestroy(c->st2);
   if (c->st != nullptr) (void) hipStreamDestroy(c->st);
   delete c;
@@ -2631,6 +2635,7 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   CTX_TRY(hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_sorted, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_emitted, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_applied, hipEventDisableTiming));
   CTX_TRY(hipMalloc(&c->d_stats, sizeof(Stats)));
   CTX_TRY(hipHostMalloc(&c->h_stats, sizeof(Stats), hipHostMallocDefault));
   CTX_TRY(hipHostMalloc(&c->h_counts, 4 * DEST_MAXPARTS * 4, hipHostMallocDefault));
@@ -3731,6 +3736,50 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         HIP_TRY(hipGetLastError());
       }
     }
+    // ---- table entries of the pairs and of the small groups (random lines,
+    // 11 ms at 3 Gbp): on the second stream, beside the rank table and the
+    // doubling rounds (streaming kernels, then short ones that leave most of
+    // the device idle).  Nothing on this stream touches those entries or the
+    // pair lists until the join behind the rounds; the LCP values beyond the
+    // byte need a buffer of their own for that -- behind the rounds they went
+    // where the rank table had been.  GTAMD_APPLY_EARLY: 0 = behind the rounds
+    // on this stream, 1 = from here on, 2 = from the first round on.
+    int apply_early = 1;
+    if (const char *e = getenv("GTAMD_APPLY_EARLY")) apply_early = atoi(e);
+    if (nrec == 0 || apply_early < 0 || apply_early > 2) apply_early = 0;
+    u32 *lcpfull = nullptr;
+    if (want_lcp && apply_early) {
+      fail = ensure_buf(c, c->lcpfull_buf, (NL + 8) * 4, "the LCP values beyond the byte") != 0;
+      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+      else if (fail) return -1;
+      lcpfull = c->lcpfull_buf.as<u32>();
+    }
+    auto launch_apply = [&](hipStream_t s) -> int {
+      if (npairs > 0) {
+        k_pair_apply<P><<<(u32) div_up(npairs, 256), 256, 0, s>>>(
+            pidx, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
+        HIP_TRY(hipGetLastError());
+      }
+      if (nsmall > 0) {
+        k_small_apply<P><<<(u32) div_up(nsmall, 256), 256, 0, s>>>(
+            sidx, sres, slcp, nsmall, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
+        HIP_TRY(hipGetLastError());
+      }
+      return 0;
+    };
+    auto apply_beside = [&]() -> int {
+      // (ev_sorted is free: the emission, if it is a kernel of its own, has been
+      // launched by the pair path; st2 runs the entries behind it)
+      // (a stream of the lowest priority for them changes nothing: 137.6 ms
+      // against 136.9 -- the rounds lose 5 ms to the memory system, not to the
+      // dispatcher)
+      HIP_TRY(hipEventRecord(c->ev_sorted, st));
+      HIP_TRY(hipStreamWaitEvent(c->st2, c->ev_sorted, 0));
+      TRY(launch_apply(c->st2));
+      HIP_TRY(hipEventRecord(c->ev_applied, c->st2));
+      return 0;
+    };
+    if (apply_early == 1) TRY(apply_beside());
     TRY(tie_words(tiebits2));
     m0 = c->h_stats->count;
     const u64 smalldone = c->h_stats->smalldone;
@@ -4056,6 +4105,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       TRY(send_ranks());
     }
     TRY(launch_emission());   // (if the pair path has not started it)
+    if (apply_early == 2) TRY(apply_beside());
     // ---- doubling rounds
     int gs[8], gw[8];
     const int gn = passes_for(nbl, gs, gw);
@@ -4265,22 +4315,13 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
     // 32-bit LCP values that do not fit the byte, by table index: in a buffer
     // that has done its work (the rank table; the bucketing scratch)
-    u32 *lcpfull = nullptr;
-    if (want_lcp) {
+    if (want_lcp && !apply_early) {
       if (!dist) lcpfull = fval;
       else if (WIDE) lcpfull = fval;
       else lcpfull = c->isa_tmp.as<u32>();
     }
-    if (npairs > 0) {
-      k_pair_apply<P><<<(u32) div_up(npairs, 256), 256, 0, st>>>(
-          pidx, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
-      HIP_TRY(hipGetLastError());
-    }
-    if (nsmall > 0) {
-      k_small_apply<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(
-          sidx, sres, slcp, nsmall, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
-      HIP_TRY(hipGetLastError());
-    }
+    if (apply_early) HIP_TRY(hipStreamWaitEvent(st, c->ev_applied, 0));
+    else TRY(launch_apply(st));
     const u32 g0 = (u32) div_up(m0, 256);
     u32 *bcnt0 = koff, *boff0 = koff + g0 + 16;   // per-workgroup counts and their scan
     if (m0 > 0) {

@@ -1595,23 +1595,24 @@ __global__ __launch_bounds__(256) void k_small_apply(
     const u32 *__restrict__ sidx, const u32 *__restrict__ sres, const u32 *__restrict__ slcp,
     u64 ns, const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
     u8 *__restrict__ bwt, u32 *__restrict__ lcpfull, u64 index_offset, Stats *stats) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= ns) return;
-  const u32 r = sres[j];
-  const u64 i = sidx[j];
-  const int g = (int) (r >> 8) & 7;
-  u8 old[4] = {0, 0, 0, 0};
-  if (bwt != nullptr)
-    for (int k = 0; k < g; k++) old[k] = bwt[i + k];
-  for (int k = 0; k < g; k++) {
-    const u64 p = sa[i + k];
-    if (suf != nullptr) suf[i + k] = p;
-    if (bwt != nullptr) bwt[i + k] = old[(r >> (2 * k)) & 3u];   // (the symbols of the keys, in key order)
-    if (p == 0) stats->longest = index_offset + i + k;
-    if (k > 0 && lcp != nullptr) {
-      const u32 lv = slcp[3 * j + (k - 1)];
-      lcp[i + k] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
-      if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + k] = lv;
+  // (grid-stride: beside the refinement the grid is kept small, see apply_grid)
+  for (u64 j = (u64) blockIdx.x * 256 + threadIdx.x; j < ns; j += (u64) gridDim.x * 256) {
+    const u32 r = sres[j];
+    const u64 i = sidx[j];
+    const int g = (int) (r >> 8) & 7;
+    u8 old[4] = {0, 0, 0, 0};
+    if (bwt != nullptr)
+      for (int k = 0; k < g; k++) old[k] = bwt[i + k];
+    for (int k = 0; k < g; k++) {
+      const u64 p = sa[i + k];
+      if (suf != nullptr) suf[i + k] = p;
+      if (bwt != nullptr) bwt[i + k] = old[(r >> (2 * k)) & 3u];   // (the symbols of the keys, in key order)
+      if (p == 0) stats->longest = index_offset + i + k;
+      if (k > 0 && lcp != nullptr) {
+        const u32 lv = slcp[3 * j + (k - 1)];
+        lcp[i + k] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+        if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + k] = lv;
+      }
     }
   }
 }
@@ -1773,24 +1774,25 @@ __global__ __launch_bounds__(256) void k_pair_apply(
     const u32 *__restrict__ pidx, const u32 *__restrict__ res, u64 np,
     const P *__restrict__ sa, u64 *__restrict__ suf, u8 *__restrict__ lcp,
     u8 *__restrict__ bwt, u32 *__restrict__ lcpfull, u64 index_offset, Stats *stats) {
-  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
-  if (j >= np) return;
-  const u64 i = pidx[j];
-  const u32 r = res[j], lv = r & ~PAIR_SWAP;
-  if (lcp != nullptr) {
-    lcp[i + 1] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
-    if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + 1] = lv;
-  }
-  // (a pair in its old order has its .suf / .bwt entries from the emission;
-  // suffix 0, whose place the statistics want, is always the first of its pair)
-  if (r & PAIR_SWAP) {
-    const u64 x = sa[i], y = sa[i + 1];
-    if (y == 0) stats->longest = index_offset + i + 1;
-    if (suf != nullptr) { suf[i] = x; suf[i + 1] = y; }
-    if (bwt != nullptr) {
-      const u8 b0 = bwt[i], b1 = bwt[i + 1];
-      bwt[i] = b1;
-      bwt[i + 1] = b0;
+  // (grid-stride: beside the refinement the grid is kept small, see apply_grid)
+  for (u64 j = (u64) blockIdx.x * 256 + threadIdx.x; j < np; j += (u64) gridDim.x * 256) {
+    const u64 i = pidx[j];
+    const u32 r = res[j], lv = r & ~PAIR_SWAP;
+    if (lcp != nullptr) {
+      lcp[i + 1] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
+      if (lv >= GTAMD_LCPOVERFLOW) lcpfull[i + 1] = lv;
+    }
+    // (a pair in its old order has its .suf / .bwt entries from the emission;
+    // suffix 0, whose place the statistics want, is always the first of its pair)
+    if (r & PAIR_SWAP) {
+      const u64 x = sa[i], y = sa[i + 1];
+      if (y == 0) stats->longest = index_offset + i + 1;
+      if (suf != nullptr) { suf[i] = x; suf[i + 1] = y; }
+      if (bwt != nullptr) {
+        const u8 b0 = bwt[i], b1 = bwt[i + 1];
+        bwt[i] = b1;
+        bwt[i + 1] = b0;
+      }
     }
   }
 }
@@ -3740,28 +3742,54 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     // 11 ms at 3 Gbp): on the second stream, beside the rank table and the
     // doubling rounds (streaming kernels, then short ones that leave most of
     // the device idle).  Nothing on this stream touches those entries or the
-    // pair lists until the join behind the rounds; the LCP values beyond the
-    // byte need a buffer of their own for that -- behind the rounds they went
-    // where the rank table had been.  GTAMD_APPLY_EARLY: 0 = behind the rounds
-    // on this stream, 1 = from here on, 2 = from the first round on.
-    int apply_early = 1;
+    // pair lists until the join before the walk over the LCP table; the LCP
+    // values beyond the byte need a buffer of their own for that -- behind the
+    // rounds they went where the rank table had been.  GTAMD_APPLY_EARLY: 0 =
+    // behind the rounds on this stream, 1 = from here on, 2 = from the first
+    // round on.  The rank table's kernels are bound by HBM bandwidth, where every
+    // byte of the entries costs its time again (k_win_filter 7.8 -> 13 ms beside
+    // them); the rounds wait for latency and launches, and there the entries
+    // are nearly free (3 Gbp, one process: 142.5 / 137.5 / 133.0 ms).
+    int apply_early = 2;
     if (const char *e = getenv("GTAMD_APPLY_EARLY")) apply_early = atoi(e);
-    if (nrec == 0 || apply_early < 0 || apply_early > 2) apply_early = 0;
+    if (apply_early < 0 || apply_early > 2) apply_early = 0;
     u32 *lcpfull = nullptr;
     if (want_lcp && apply_early) {
-      fail = ensure_buf(c, c->lcpfull_buf, (NL + 8) * 4, "the LCP values beyond the byte") != 0;
+      // (every part takes this step, with or without pairs of its own: the
+      // parts agree on the outcome)
+      fail = nrec > 0 &&
+             ensure_buf(c, c->lcpfull_buf, (NL + 8) * 4, "the LCP values beyond the byte") != 0;
       if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
       else if (fail) return -1;
-      lcpfull = c->lcpfull_buf.as<u32>();
+      if (nrec > 0) lcpfull = c->lcpfull_buf.as<u32>();
     }
+    if (nrec == 0) apply_early = 0;
+    // Beside the refinement the two kernels get a grid of one workgroup per CU:
+    // with a workgroup per 256 pairs the dispatcher kept every wave slot filled
+    // with their waves and the short kernels of this stream -- the copy of the
+    // statistics among them, which the host waits for -- queued behind them
+    // for milliseconds (kernel trace: a 6 ms copy).  64 / 128 / 192 / 256 /
+    // 320 / 384 / 512 / 1024 workgroups: 146.0 / 135.5 / 133.3 / 133.0 / 133.8 /
+    // 134.3 / 136.4 / 138.0 ms -- fewer do not finish before the join.
+    u64 apply_wgs = 256;
+    {
+      int cus = 0;
+      if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0)
+        apply_wgs = (u64) cus;
+    }
+    if (const char *e = getenv("GTAMD_APPLY_WGS")) { const long v = atol(e); if (v >= 64 && v <= (1 << 22)) apply_wgs = (u64) v; }
     auto launch_apply = [&](hipStream_t s) -> int {
+      // (no rounds to hide behind: the full grid)
+      const u64 cap = apply_early && (apply_early == 1 || m0 > 0) ? apply_wgs : ~0ull;
       if (npairs > 0) {
-        k_pair_apply<P><<<(u32) div_up(npairs, 256), 256, 0, s>>>(
+        const u64 g = div_up(npairs, 256);
+        k_pair_apply<P><<<(u32) (g < cap ? g : cap), 256, 0, s>>>(
             pidx, pres, npairs, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
         HIP_TRY(hipGetLastError());
       }
       if (nsmall > 0) {
-        k_small_apply<P><<<(u32) div_up(nsmall, 256), 256, 0, s>>>(
+        const u64 g = div_up(nsmall, 256);
+        k_small_apply<P><<<(u32) (g < cap ? g : cap), 256, 0, s>>>(
             sidx, sres, slcp, nsmall, sa, d_suf, d_lcp, d_bwt, lcpfull, index_offset, c->d_stats);
         HIP_TRY(hipGetLastError());
       }
@@ -4320,8 +4348,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       else if (WIDE) lcpfull = fval;
       else lcpfull = c->isa_tmp.as<u32>();
     }
-    if (apply_early) HIP_TRY(hipStreamWaitEvent(st, c->ev_applied, 0));
-    else TRY(launch_apply(st));
+    if (!apply_early) TRY(launch_apply(st));
     const u32 g0 = (u32) div_up(m0, 256);
     u32 *bcnt0 = koff, *boff0 = koff + g0 + 16;   // per-workgroup counts and their scan
     if (m0 > 0) {
@@ -4353,6 +4380,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           c->text, pk, pv, m1, sa, d_lcp, lcpfull, c->d_stats);
       HIP_TRY(hipGetLastError());
     }
+    // (the pairs' entries written beside all this: the tie fix above touches
+    // other entries; the walk over the whole LCP table below needs them)
+    if (apply_early) HIP_TRY(hipStreamWaitEvent(st, c->ev_applied, 0));
     if (want_lcp) {
       // .llv from the byte table and the side table
       TRY(fetch_stats(c));

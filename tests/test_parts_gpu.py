@@ -125,3 +125,19 @@ def test_deep_groups_reach_new_rank_windows(gpu, monkeypatch, parts):
     assert np.array_equal(tabs["lcp"], t["lcp"])
     assert np.array_equal(tabs["llv"], t["llv"])
     assert np.array_equal(tabs["bwt"], t["bwt"])
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_pairs_in_some_parts_only(gpu, parts):
+    """Two copies of a block over {A, C} in a text over {G, T}: deep pairs (too
+    deep for the direct comparison of a few ties), all in the lowest range, so
+    the other parts have no pair list at all -- and every step the parts agree
+    on must still be taken by all of them (found by the fuzz campaign: a part
+    without pairs skipped one and the build stopped)."""
+    rng = np.random.default_rng(12)        # (this seed: no 20 symbols twice outside the block)
+    a = rng.integers(2, 4, 1500, dtype=np.uint8)
+    blk = rng.integers(0, 2, 300, dtype=np.uint8)
+    enc = np.concatenate([a[:500], blk, [2], a[500:1000], blk, [3], a[1000:]]).astype(np.uint8)
+    per_part = _check(enc, 4, parts)
+    assert sum(1 for s in per_part if s["pair_suffixes"] > 0) == 1
+    assert sum(1 for s in per_part if s["tied_suffixes"] == 0) >= 1

@@ -512,3 +512,25 @@ def test_small_groups_too_deep_fall_back(gpu):
     assert np.array_equal(res.lcp, t["lcp"])
     assert np.array_equal(res.llv, t["llv"])
     assert np.array_equal(res.bwt, t["bwt"])
+
+
+@pytest.mark.parametrize("mode,wgs", [("0", None), ("1", None), ("2", None), ("2", "64"), ("1", "100000")])
+def test_table_entries_of_the_pairs_beside_the_rounds(gpu, monkeypatch, mode, wgs):
+    """the table entries of the pairs and small groups are written on the second
+    stream beside the doubling rounds (GTAMD_APPLY_EARLY=2, the default), from
+    the pair path on (1) or behind the rounds on the main stream (0), by a
+    capped or a full grid: the same tables, `.llv` and statistics every time --
+    pairs with LCP values beyond the byte, small groups, groups that need rounds"""
+    rng = np.random.default_rng(31)
+    a = rng.integers(0, 4, 6000, dtype=np.uint8)
+    b = rng.integers(0, 4, 900, dtype=np.uint8)
+    enc = np.concatenate([a[:3000], [255], b, b, b, b, [254], a[:3000], [255], a[500:2500], [255],
+                          a[3000:], a[5000:5600], np.zeros(300, dtype=np.uint8)]).astype(np.uint8)
+    ora = ou.esa(enc, 4)
+    monkeypatch.setenv("GTAMD_APPLY_EARLY", mode)
+    if wgs is not None:
+        monkeypatch.setenv("GTAMD_APPLY_WGS", wgs)
+    res = esa.suffixerator_tables(enc, 4)
+    assert res.stats["pair_suffixes"] > 0 and res.stats["refine_rounds"] > 0
+    assert res.stats["largelcpvalues"] > 0
+    _assert_same_as_oracle(enc, 4, res, ora)

@@ -3778,9 +3778,26 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         apply_wgs = (u64) cus;
     }
     if (const char *e = getenv("GTAMD_APPLY_WGS")) { const long v = atol(e); if (v >= 64 && v <= (1 << 22)) apply_wgs = (u64) v; }
+    const bool apply_wgs_given = getenv("GTAMD_APPLY_WGS") != nullptr;
     auto launch_apply = [&](hipStream_t s) -> int {
-      // (no rounds to hide behind: the full grid)
-      const u64 cap = apply_early && (apply_early == 1 || m0 > 0) ? apply_wgs : ~0ull;
+      // One workgroup per CU is right while the rounds last as long as the
+      // entries take that way (3 Gbp human-like: 13 + 1.6 ms of entries under
+      // 12 ms of rounds; repeat-heavy: 35 under 195).  Many pairs and few
+      // suffixes left for the rounds -- low-copy repeats only -- would leave the
+      // small grid working alone behind the last round: the grid grows with what
+      // the entries need over what the rounds give (measured rates: 77 ns per
+      // 1000 pairs and 285 ns per 1000 small groups with one workgroup per CU,
+      // 400 ns per 1000 suffixes in the rounds), up to the full one.
+      u64 cap = ~0ull;
+      if (apply_early == 1) cap = apply_wgs;
+      else if (apply_early == 2 && m0 > 0) {
+        cap = apply_wgs;
+        if (!apply_wgs_given) {
+          const double need = 7.7e-8 * (double) npairs + 2.85e-7 * (double) nsmall;   // ms
+          const double have = 1.25 * 4.0e-7 * (double) m0 + 0.5;
+          if (need > have) cap = (u64) ((double) apply_wgs * (need / have));
+        }
+      }
       if (npairs > 0) {
         const u64 g = div_up(npairs, 256);
         k_pair_apply<P><<<(u32) (g < cap ? g : cap), 256, 0, s>>>(

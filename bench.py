@@ -52,12 +52,15 @@ from genometools_amd import dist as gdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 JOB_BYTES_PER_BP = 10.25       # 0.25 text + 8 suf + 1 lcp + 1 bwt
-SCATTER_BYTES_PER_PAIR = 24.0  # k_rs_scatter: 8+4 read, 8+4 written per pair and radix pass
-MSD_LOCAL_BYTES_PER_ENTRY = 22.125  # k_msd_local: K2 + position read; suf 8, position 4,
-                                    # lcp 1, bwt 1, tie bit 1/8 written
-DOMINANT = {0: ("k_rs_scatter (radix scatter pass of the LSD sort)", SCATTER_BYTES_PER_PAIR),
+# algorithmic bytes of the dominant kernel per entry it (reads, writes) in a launch:
+# k_rs_scatter: 8+4 read, 8+4 written per pair and radix pass; k_msd_local: K2 + position
+# read for every entry of the runs that fit its tile, suf 8 + position 4 + lcp 1 + bwt 1 +
+# tie bit 1/8 written for the entries of the runs it sorts itself -- the runs it leaves
+# to k_msd_local_radix (a crowded bin) it only reads (DESIGN.md section 4;
+# gtamd_esa_timing.scatter_read_items / scatter_written_items)
+DOMINANT = {0: ("k_rs_scatter (radix scatter pass of the LSD sort)", 12.0, 12.0),
             1: ("k_msd_local (last level of the MSD sort: LDS sort of a run + table emission)",
-                MSD_LOCAL_BYTES_PER_ENTRY)}
+                8.0, 14.125)}
 
 
 def cpu_baseline(model, seed, sample_n):
@@ -153,7 +156,8 @@ def main():
         sc_ms += tm["scatter_ms"]
         sc_launches += tm["scatter_launches"]
         dominant = tm["dominant_kernel"]
-        items_per_launch = tm["scatter_items"]
+        read_per_launch = tm["scatter_read_items"]
+        written_per_launch = tm["scatter_written_items"]
         total_dev_ms += tm["total_ms"]
     barrier()
     dt = time.perf_counter() - t0
@@ -166,22 +170,23 @@ def main():
     slice_entries = eng.entries(esa.TAB_SUF)
     if world > 1:
         st = gdist.combine_stats(st, "cuda:%d" % dev)
-        t = torch.tensor([sc_ms, float(sc_launches), float(slice_entries),
-                          float(comm.bytes_exchanged)], dtype=torch.float64,
-                         device=cdev)
+        t = torch.tensor([sc_ms, float(sc_launches), float(read_per_launch),
+                          float(written_per_launch), float(comm.bytes_exchanged)],
+                         dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         sc_ms, sc_launches = float(t[0].item()) / world, int(t[1].item()) // world
-        pairs_per_launch = float(t[2].item()) / world
-        exchanged = float(t[3].item())
+        read_per_launch = float(t[2].item()) / world
+        written_per_launch = float(t[3].item()) / world
+        exchanged = float(t[4].item())
     else:
-        pairs_per_launch = float(items_per_launch)
         exchanged = 0.0
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = n / (dt / a.steps) / 1e9
         sc_avg_s = sc_ms / max(sc_launches, 1) / 1e3
-        kernel_name, kernel_bytes = DOMINANT[dominant]
-        achieved = kernel_bytes * pairs_per_launch / sc_avg_s / 1e9
+        kernel_name, bytes_read, bytes_written = DOMINANT[dominant]
+        launch_bytes = bytes_read * float(read_per_launch) + bytes_written * float(written_per_launch)
+        achieved = launch_bytes / sc_avg_s / 1e9
         # PMC traffic of that kernel: only a measurement of THIS kernel source
         # counts (tools/pmc_summary.py stamps the file with the source's hash)
         traffic = None
@@ -222,6 +227,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_ms": sc_avg_s * 1e3,
+                         "algorithmic_bytes_per_launch": launch_bytes,
+                         "entries_read_per_launch": float(read_per_launch),
+                         "entries_written_per_launch": float(written_per_launch),
                          "launches_per_step": sc_launches // max(a.steps, 1),
                          "job_frac": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world),
                          "job": {"achieved": JOB_BYTES_PER_BP * n / (dt / a.steps) / 1e9,

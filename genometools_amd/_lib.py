@@ -50,7 +50,9 @@ class EsaStats(ctypes.Structure):
                 ("refine_rounds", ctypes.c_uint32),
                 ("tied_suffixes", ctypes.c_uint64),
                 ("pair_suffixes", ctypes.c_uint64),
-                ("device_bytes", ctypes.c_uint64)]
+                ("device_bytes", ctypes.c_uint64),
+                ("msd_big_entries", ctypes.c_uint64),
+                ("msd_crowded_entries", ctypes.c_uint64)]
 
 
 class EsaTiming(ctypes.Structure):
@@ -67,7 +69,9 @@ class EsaTiming(ctypes.Structure):
                 ("comm_calls", ctypes.c_uint32),
                 ("comm_bytes", ctypes.c_uint64),
                 ("alloc_ms", ctypes.c_float),
-                ("dominant_kernel", ctypes.c_uint32)]
+                ("dominant_kernel", ctypes.c_uint32),
+                ("scatter_read_items", ctypes.c_uint64),
+                ("scatter_written_items", ctypes.c_uint64)]
 
 
 class EncodeSummary(ctypes.Structure):     # gtamd_encode_summary, include/gtamd_encode.h
@@ -110,6 +114,7 @@ ABI = {
     "gtamd_device_count": (_INT, []),
     "gtamd_esa_last_error": (ctypes.c_char_p, []),
     "gtamd_recommended_prefixlength": (_U32, [_U32, _U64]),
+    "gtamd_abi_selftest": (_INT, [_U64]),
     "gtamd_esa_create": (_P, [_INT, _U64, _U32]),
     "gtamd_esa_destroy": (None, [_P]),
     "gtamd_esa_set_part": (_INT, [_P, _U32, _U32]),

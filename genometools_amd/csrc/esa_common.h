@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <exception>
+#include <new>
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -32,6 +34,28 @@ void gtamd_set_error(const char *fmt, ...);
   } while (0)
 
 static inline u64 div_up(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// Exception barrier of the C ABI.  The callers are C (GenomeTools' GtError
+// convention: -1 / NULL + message); a std::bad_alloc or std::length_error from a
+// host container -- e.g. one sized from a number read back from the device --
+// must not cross an extern "C" frame, where it ends in std::terminate() and
+// kills the caller.  Every entry point that can reach `new` or a container runs
+// its body through this: GTAMD_ABI_BEGIN ... GTAMD_ABI_END(value on failure).
+#define GTAMD_ABI_BEGIN try {
+#define GTAMD_ABI_END(failvalue)                                                     \
+  }                                                                                  \
+  catch (const std::bad_alloc &) {                                                   \
+    gtamd_set_error("%s: out of host memory", __func__);                             \
+    return failvalue;                                                                \
+  }                                                                                  \
+  catch (const std::exception &e_) {                                                 \
+    gtamd_set_error("%s: %s", __func__, e_.what());                                  \
+    return failvalue;                                                                \
+  }                                                                                  \
+  catch (...) {                                                                      \
+    gtamd_set_error("%s: unexpected exception", __func__);                           \
+    return failvalue;                                                                \
+  }
 
 // ---- key layout ------------------------------------------------------------
 // One 64-bit sort key per suffix:

@@ -469,15 +469,18 @@ static void enc_free(gtamd_encoder *e) {
 }
 
 extern "C" gtamd_encoder *gtamd_encoder_create(int device, int protein) {
+  GTAMD_ABI_BEGIN
   u8 lut[256];
   build_lut(lut, protein != 0);
   for (int c = 0; c < 256; c++) if (lut[c] == LUT_BLANK) lut[c] = LUT_UNDEF;
   return gtamd_encoder_create_map(device, lut, protein ? 20 : 4, protein ? 5 : 3);
+  GTAMD_ABI_END(nullptr)
 }
 
 extern "C" gtamd_encoder *gtamd_encoder_create_map(int device, const uint8_t *symbolmap,
                                                    uint32_t numofchars,
                                                    unsigned bitspersymbol) {
+  GTAMD_ABI_BEGIN
   int count = 0;
   if (symbolmap == nullptr || numofchars < 1 || numofchars > 32 || bitspersymbol < 1 ||
       bitspersymbol > 8) {
@@ -510,6 +513,7 @@ extern "C" gtamd_encoder *gtamd_encoder_create_map(int device, const uint8_t *sy
   }
   for (auto &ev : e->ev) (void) hipEventCreate(&ev);
   return e;
+  GTAMD_ABI_END(nullptr)
 }
 
 extern "C" void gtamd_encoder_destroy(gtamd_encoder *e) {
@@ -523,6 +527,7 @@ extern "C" void gtamd_encoder_destroy(gtamd_encoder *e) {
 
 extern "C" int gtamd_encoder_add_file(gtamd_encoder *e, const char *name,
                                       const uint8_t *bytes, uint64_t length) {
+  GTAMD_ABI_BEGIN
   if (e == nullptr || name == nullptr || (bytes == nullptr && length > 0)) {
     gtamd_set_error("invalid argument to gtamd_encoder_add_file");
     return -1;
@@ -538,6 +543,7 @@ extern "C" int gtamd_encoder_add_file(gtamd_encoder *e, const char *name,
   e->files.push_back(f);
   e->finished = false;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 // descriptions seen so far do not fit: grow both arrays, keep the contents
@@ -731,6 +737,7 @@ static int summarise(gtamd_encoder *e) {
 }
 
 extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
   if (e == nullptr) { gtamd_set_error("null encoder"); return -1; }
   if (e->files.empty()) { gtamd_set_error("option \"-db\" is mandatory"); return -1; }
   HIP_TRY(hipSetDevice(e->device));
@@ -783,10 +790,12 @@ extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
   if (rc != 0) { enc_free(e); e->n = 0; e->ndesc = 0; return -1; }
   e->finished = true;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_set_symbols(gtamd_encoder *e, const uint8_t *symbols,
                                          uint64_t n) {
+  GTAMD_ABI_BEGIN
   if (e == nullptr || (symbols == nullptr && n > 0)) {
     gtamd_set_error("invalid argument to gtamd_encoder_set_symbols");
     return -1;
@@ -816,6 +825,7 @@ extern "C" int gtamd_encoder_set_symbols(gtamd_encoder *e, const uint8_t *symbol
   (void) hipEventElapsedTime(&e->total_ms, e->ev[0], e->ev[2]);
   e->finished = true;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 static int need_finished(const gtamd_encoder *e) {
@@ -827,15 +837,20 @@ static int need_finished(const gtamd_encoder *e) {
 }
 
 extern "C" uint64_t gtamd_encoder_length(const gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
   return e != nullptr && e->finished ? e->n : 0;
+  GTAMD_ABI_END(0)
 }
 
 extern "C" const uint8_t *gtamd_encoder_device_symbols(const gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
   return e != nullptr && e->finished ? e->d_enc : nullptr;
+  GTAMD_ABI_END(nullptr)
 }
 
 extern "C" int gtamd_encoder_copy_symbols(const gtamd_encoder *e, uint8_t *dst,
                                           uint64_t first, uint64_t count) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   if (first > e->n || count > e->n - first) {
     gtamd_set_error("range [%llu, +%llu) exceeds the %llu encoded symbols",
@@ -846,16 +861,20 @@ extern "C" int gtamd_encoder_copy_symbols(const gtamd_encoder *e, uint8_t *dst,
   HIP_TRY(hipSetDevice(e->device));
   if (count > 0) HIP_TRY(hipMemcpy(dst, e->d_enc + first, count, hipMemcpyDeviceToHost));
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_get_summary(const gtamd_encoder *e, gtamd_encode_summary *s) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   *s = e->sum;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_file_lengths(const gtamd_encoder *e, size_t file,
                                           uint64_t *length, uint64_t *effectivelength) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   if (file >= e->files.size()) { gtamd_set_error("no input file %zu", file); return -1; }
   const InputFile &f = e->files[file];
@@ -867,10 +886,13 @@ extern "C" int gtamd_encoder_file_lengths(const gtamd_encoder *e, size_t file,
   *length = f.length;
   *effectivelength = f.out_len - separators_written + own_separators;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
   return e != nullptr && e->finished ? e->ndesc : 0;
+  GTAMD_ABI_END(0)
 }
 
 // the caller's arrays hold `capacity` entries: more would be written -> error
@@ -884,6 +906,7 @@ static int check_capacity(const char *what, u64 needed, u64 capacity) {
 extern "C" int gtamd_encoder_get_descriptions(const gtamd_encoder *e, uint32_t *file,
                                               uint64_t *start, uint64_t *end,
                                               uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   TRY(check_capacity("descriptions", e->ndesc, capacity));
   HIP_TRY(hipSetDevice(e->device));
@@ -899,17 +922,20 @@ extern "C" int gtamd_encoder_get_descriptions(const gtamd_encoder *e, uint32_t *
     }
   }
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_get_timing(const gtamd_encoder *e, float *total_ms,
                                         float *parse_ms, float *stats_ms,
                                         uint64_t *input_bytes) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   if (total_ms) *total_ms = e->total_ms;
   if (parse_ms) *parse_ms = e->parse_ms;
   if (stats_ms) *stats_ms = e->stats_ms;
   if (input_bytes) *input_bytes = e->input_bytes;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 // ---- INDEX.esq sections ---------------------------------------------------
@@ -923,6 +949,7 @@ static int launch_1d(u64 items, u32 *blocks) {
 extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
                                          unsigned fillcode, uint64_t *words,
                                          uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 units = e->n < 32 ? 2 : 2 + (e->n - 1) / 32;
@@ -942,10 +969,12 @@ extern "C" int gtamd_encoder_pack_twobit(const gtamd_encoder *e, int bitaccess,
   }
   (void) hipFree(d);
   return rc;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *words,
                                               uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 units = 1 + (e->n + 63) / 64;
@@ -965,10 +994,12 @@ extern "C" int gtamd_encoder_pack_specialbits(const gtamd_encoder *e, uint64_t *
   }
   (void) hipFree(d);
   return rc;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *bytes,
                                                uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u32 sigma = e->sigma, bits = e->packbits;
@@ -989,6 +1020,7 @@ extern "C" int gtamd_encoder_pack_bytecompress(const gtamd_encoder *e, uint8_t *
   }
   (void) hipFree(d);
   return rc;
+  GTAMD_ABI_END(-1)
 }
 
 // the `expected` positions of one kind, in increasing order, to host memory
@@ -1036,6 +1068,7 @@ static int positions_to_host(const gtamd_encoder *e, int kind, u64 expected, u64
 
 extern "C" int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *e, uint64_t *start,
                                                uint64_t *length, uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   const u64 runs = e->sum.realwildcardranges;
@@ -1044,12 +1077,15 @@ extern "C" int gtamd_encoder_get_wildcard_runs(const gtamd_encoder *e, uint64_t 
   TRY(positions_to_host(e, POS_WILDCARD_END, runs, length));
   for (u64 r = 0; r < runs; r++) length[r] = length[r] - start[r] + 1;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_encoder_get_separators(const gtamd_encoder *e, uint64_t *pos,
                                             uint64_t capacity) {
+  GTAMD_ABI_BEGIN
   TRY(need_finished(e));
   HIP_TRY(hipSetDevice(e->device));
   TRY(check_capacity("separators", e->sum.numofsequences - 1, capacity));
   return positions_to_host(e, POS_SEPARATOR, e->sum.numofsequences - 1, pos);
+  GTAMD_ABI_END(-1)
 }

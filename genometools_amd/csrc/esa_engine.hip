@@ -49,9 +49,20 @@ void gtamd_set_error(const char *fmt, ...) {
 extern "C" const char *gtamd_esa_last_error(void) { return g_err; }
 
 extern "C" int gtamd_device_count(void) {
+  GTAMD_ABI_BEGIN
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+  GTAMD_ABI_END(0)
+}
+
+// host only: a container sized by the caller inside the barrier (tests/test_abi.py)
+extern "C" int gtamd_abi_selftest(uint64_t host_bytes) {
+  GTAMD_ABI_BEGIN
+  std::vector<u8> probe((size_t) host_bytes);
+  if (!probe.empty()) probe[probe.size() - 1] = 1;
+  return probe.empty() ? 0 : (int) probe[probe.size() - 1] - 1;
+  GTAMD_ABI_END(-1)
 }
 
 // ---------------------------------------------------------------------------
@@ -892,6 +903,8 @@ struct Stats {          // device-side accumulators
   u32 dfallback;                  // direct tie path gave up on some group
   u32 count3;                     // third counter (small groups)
   unsigned long long smalldone;   // entries of the small groups settled directly
+  unsigned long long crowded;     // MSD sort: entries of the runs k_msd_local read and left to
+                                  // k_msd_local_radix (a crowded bin): read, not written by it
 };
 
 constexpr int FIN_THREADS = 256;
@@ -2610,6 +2623,7 @@ constexpr u64 SINGLE_LIMIT = (1ull << 32) - 4096;   // entries of one slice / si
 
 extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
                                            uint32_t numofchars) {
+  GTAMD_ABI_BEGIN
   if (gtamd_device_count() <= device || device < 0) {
     gtamd_set_error("no HIP device %d available (this library has no CPU "
                     "fallback)", device);
@@ -2649,10 +2663,12 @@ extern "C" gtamd_esa_ctx *gtamd_esa_create(int device, uint64_t max_n,
   for (auto &e : c->ev) CTX_TRY(hipEventCreate(&e));
   for (auto &e : c->ev_scatter) CTX_TRY(hipEventCreate(&e));
   return c;
+  GTAMD_ABI_END(nullptr)
 }
 
 extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
                                   uint32_t numparts) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   if (numparts == 0 || numparts > (u32) DEST_MAXPARTS || part >= numparts) {
     gtamd_set_error("invalid part %u of %u (1..%d parts)", part, numparts, DEST_MAXPARTS);
@@ -2662,18 +2678,22 @@ extern "C" int gtamd_esa_set_part(gtamd_esa_ctx *c, uint32_t part,
   c->numparts = numparts;
   c->ran = false;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_esa_set_comm(gtamd_esa_ctx *c, gtamd_allgather_fn ag,
                                   gtamd_alltoallv_fn a2a, void *user) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   c->comm_allgather = ag;
   c->comm_alltoallv = a2a;
   c->comm_user = user;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_esa_set_prefixlength(gtamd_esa_ctx *c, uint32_t k) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   const u32 maxk = c->bits == 2 ? (u32) KeyLayout<2>::KEY_SYMS : (u32) KeyLayout<5>::KEY_SYMS;
   if (k > maxk) {
@@ -2683,9 +2703,11 @@ extern "C" int gtamd_esa_set_prefixlength(gtamd_esa_ctx *c, uint32_t k) {
   }
   c->user_prefixlength = k;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_esa_set_readmode(gtamd_esa_ctx *c, int readmode) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   if (readmode < 0 || readmode > 3) {
     gtamd_set_error("invalid readmode %d (0 forward, 1 reverse, 2 complement, "
@@ -2701,6 +2723,7 @@ extern "C" int gtamd_esa_set_readmode(gtamd_esa_ctx *c, int readmode) {
   c->readmode = readmode;
   c->have_text = false;   // applies to the next gtamd_esa_set_sequence_bytes
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 static int set_n(gtamd_esa_ctx *c, u64 n) {
@@ -2718,6 +2741,7 @@ static int set_n(gtamd_esa_ctx *c, u64 n) {
 extern "C" int gtamd_esa_set_sequence_bytes(gtamd_esa_ctx *c,
                                             const uint8_t *enc, uint64_t n,
                                             int is_device) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   TRY(set_n(c, n));
   HIP_TRY(hipSetDevice(c->device));
@@ -2752,12 +2776,14 @@ extern "C" int gtamd_esa_set_sequence_bytes(gtamd_esa_ctx *c,
   c->text.nw_tb = nw_tb; c->text.nw_sp = nw_sp;
   c->have_text = true;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
                                              const uint64_t *twobit,
                                              const uint64_t *specialbits,
                                              uint64_t n) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   if (c->bits != 2) {
     gtamd_set_error("packed input is defined for the 2-bit DNA layout only");
@@ -2773,6 +2799,7 @@ extern "C" int gtamd_esa_set_sequence_packed(gtamd_esa_ctx *c,
   c->text.nw_tb = div_up(n, 32); c->text.nw_sp = div_up(n + 1, 64);
   c->have_text = true;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 // ---------------------------------------------------------------------------
@@ -3234,6 +3261,7 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   *fkey = reinterpret_cast<u64 *>(ko);
   *fval = po;
   *local_entries = N - nbigentries;
+  c->stats.msd_big_entries = nbigentries;
   return 0;
 }
 
@@ -4466,6 +4494,12 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   c->timing.scatter_ms = sc;
   c->timing.scatter_launches = (u32) nev;
   c->timing.scatter_items = msd ? msd_local : NL;
+  // what the dominant kernel moves per launch: k_msd_local reads every run that fits
+  // its tile and writes the tables of those it sorts itself -- the runs with a crowded
+  // bin it only reads (k_msd_local_radix sorts and writes them)
+  c->timing.scatter_read_items = c->timing.scatter_items;
+  c->timing.scatter_written_items = msd ? msd_local - c->h_stats->crowded : NL;
+  c->stats.msd_crowded_entries = msd ? c->h_stats->crowded : 0;
   c->timing.dominant_kernel = msd ? 1u : 0u;
   c->timing.alloc_ms = c->alloc_ms;
   c->want = want;
@@ -4474,6 +4508,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
 }
 
 extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   if (!c->have_text) { gtamd_set_error("no sequence set"); return -1; }
   if ((want & 15u) == 0) { gtamd_set_error("nothing requested"); return -1; }
@@ -4493,6 +4528,7 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
   if (c->bits == 2)
     return wide ? run_impl<2, true>(c, want, dist) : run_impl<2, false>(c, want, dist);
   return wide ? run_impl<5, true>(c, want, dist) : run_impl<5, false>(c, want, dist);
+  GTAMD_ABI_END(-1)
 }
 
 // ---------------------------------------------------------------------------
@@ -4500,14 +4536,17 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
 // ---------------------------------------------------------------------------
 extern "C" uint64_t gtamd_esa_table_entries(const gtamd_esa_ctx *c,
                                             gtamd_table which) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran) return 0;
   if (which == GTAMD_TAB_BCK)
     return (c->want & GTAMD_WANT_BCK) ? c->bck_codes + 1 + c->bck_special + c->bck_dist : 0;
   return which == GTAMD_TAB_LLV ? c->llv_pairs : c->NL;
+  GTAMD_ABI_END(0)
 }
 extern "C" int gtamd_esa_bck_layout(const gtamd_esa_ctx *c, uint64_t *numofallcodes,
                                     uint64_t *numofspecialcodes,
                                     uint64_t *numofdistpfxidxcounters) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran || !(c->want & GTAMD_WANT_BCK)) {
     gtamd_set_error("no bucket table was requested");
     return -1;
@@ -4516,12 +4555,16 @@ extern "C" int gtamd_esa_bck_layout(const gtamd_esa_ctx *c, uint64_t *numofallco
   *numofspecialcodes = c->bck_special;
   *numofdistpfxidxcounters = c->bck_dist;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 extern "C" uint64_t gtamd_esa_table_offset(const gtamd_esa_ctx *c) {
+  GTAMD_ABI_BEGIN
   return (c == nullptr || !c->ran) ? 0 : c->index_offset;
+  GTAMD_ABI_END(0)
 }
 extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
                                               gtamd_table which) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran) return nullptr;
   switch (which) {
     case GTAMD_TAB_SUF: return (c->want & GTAMD_WANT_SUF) ? c->suf.p : nullptr;
@@ -4531,9 +4574,11 @@ extern "C" const void *gtamd_esa_table_device(const gtamd_esa_ctx *c,
     case GTAMD_TAB_BCK: return (c->want & GTAMD_WANT_BCK) ? c->bck : nullptr;
   }
   return nullptr;
+  GTAMD_ABI_END(nullptr)
 }
 extern "C" int gtamd_esa_table_copy(gtamd_esa_ctx *c, gtamd_table which,
                                     void *dst, uint64_t first, uint64_t count) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
   const void *src = gtamd_esa_table_device(c, which);
   const u64 entries = gtamd_esa_table_entries(c, which);
@@ -4550,23 +4595,30 @@ extern "C" int gtamd_esa_table_copy(gtamd_esa_ctx *c, gtamd_table which,
   HIP_TRY(hipMemcpy(dst, (const u8 *) src + first * esz, count * esz,
                     hipMemcpyDeviceToHost));
   return 0;
+  GTAMD_ABI_END(-1)
 }
 // for the consumers inside the library (esa_pck.hip): where the tables live
 extern "C" int gtamd_esa_internal_info(const gtamd_esa_ctx *c, int *device, u32 *sigma,
                                        u32 *numparts) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
   *device = c->device; *sigma = c->sigma; *numparts = c->numparts;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 extern "C" int gtamd_esa_get_stats(const gtamd_esa_ctx *c, gtamd_esa_stats *s) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
   *s = c->stats;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 extern "C" int gtamd_esa_get_timing(const gtamd_esa_ctx *c, gtamd_esa_timing *t) {
+  GTAMD_ABI_BEGIN
   if (c == nullptr || !c->ran) { gtamd_set_error("no completed run"); return -1; }
   *t = c->timing;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_esa_build(const uint8_t *enc, uint64_t n,
@@ -4574,6 +4626,7 @@ extern "C" int gtamd_esa_build(const uint8_t *enc, uint64_t n,
                                uint64_t *suf, uint8_t *lcp, uint8_t *bwt,
                                uint64_t *llv, uint64_t llv_capacity,
                                uint64_t *llv_pairs, gtamd_esa_stats *st) {
+  GTAMD_ABI_BEGIN
   gtamd_esa_ctx *c = gtamd_esa_create(0, n, numofchars);
   if (c == nullptr) return -1;
   int rc = gtamd_esa_set_sequence_bytes(c, enc, n, 0);
@@ -4600,4 +4653,5 @@ extern "C" int gtamd_esa_build(const uint8_t *enc, uint64_t n,
   if (rc == 0 && st != nullptr) rc = gtamd_esa_get_stats(c, st);
   gtamd_esa_destroy(c);
   return rc;
+  GTAMD_ABI_END(-1)
 }

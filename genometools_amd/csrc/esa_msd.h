@@ -970,7 +970,10 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
       lds_barrier();
       if (s_binw[MD_BINS / 2 + 1] != 0) {     // (the same for every thread)
         // a crowded bin: this run is left to k_msd_local_radix
-        if (tid == 0) crowdlist[atomicAdd(&counters[4], 1u)] = t;
+        if (tid == 0) {
+          crowdlist[atomicAdd(&counters[4], 1u)] = t;
+          atomicAdd(&o.stats->crowded, (unsigned long long) cnt);
+        }
         skip = true;
       } else {
         // every entry to its bin, in the order the atomics came back, as

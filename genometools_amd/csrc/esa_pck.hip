@@ -652,6 +652,7 @@ struct gtamd_pck {
   u64 *rlist; u64 rlist_cap;
   u64 *d_totals;
   u64 *d_tail;
+  u64 tail_cap;          // buckets d_tail has room for
   u64 *spbits; u64 spbits_cap;     // -sprank: bitmap of the text's specials, word prefix counts,
   u32 *sppre; u64 sppre_cap;       // scan workspace
   u32 *spws; u64 spws_cap;
@@ -662,6 +663,7 @@ struct gtamd_pck {
 
 extern "C" int gtamd_pck_default_toggles(uint32_t block_size, uint32_t bucket_blocks,
                                          uint32_t locate_interval, int locbitmap) {
+  GTAMD_ABI_BEGIN
   // gt_computePackedIndexDefaults / estimateBestLocateTypeFeature,
   // src/match/eis-bwtseq-param.c:69-103
   if (locbitmap >= 0) return locbitmap ? GTAMD_PCK_LOCATE_BITMAP : GTAMD_PCK_LOCATE_COUNT;
@@ -669,9 +671,11 @@ extern "C" int gtamd_pck_default_toggles(uint32_t block_size, uint32_t bucket_bl
   const u32 seg = block_size * bucket_blocks;
   if (seg > (seg + 1) * reqbits(seg) / locate_interval) return GTAMD_PCK_LOCATE_COUNT;
   return GTAMD_PCK_LOCATE_BITMAP;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" gtamd_pck *gtamd_pck_create(int device) {
+  GTAMD_ABI_BEGIN
   if (gtamd_device_count() <= device || device < 0) {
     gtamd_set_error("no HIP device %d available (this library has no CPU fallback)", device);
     return nullptr;
@@ -688,7 +692,9 @@ extern "C" gtamd_pck *gtamd_pck_create(int device) {
     delete p;
     return nullptr;
   }
+  p->tail_cap = PCK_TAIL_RECORDS;
   return p;
+  GTAMD_ABI_END(nullptr)
 }
 
 extern "C" void gtamd_pck_destroy(gtamd_pck *p) {
@@ -744,12 +750,16 @@ static int fix_stale_bits(gtamd_pck *p, const PckGeom &g, u64 var_bits_total,
   if (rc == -1) gtamd_set_error("packed index: cannot copy the tail of the image between device and host");
   if (rc == -2) gtamd_set_error("packed index: the replay of the staging buffers needs more than the last %llu buckets",
                                 (unsigned long long) tail_off.size());
-  return rc == 0 ? 0 : -1;
+  if (rc == -3) gtamd_set_error("packed index: the var offsets of the last %llu buckets read back from the device "
+                                "are not increasing or exceed the %llu bits of the var part",
+                                (unsigned long long) tail_off.size(), (unsigned long long) var_bits_total);
+  return rc;
 }
 
 extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t *suf,
                                uint64_t total_len, uint32_t sigma, uint64_t longest,
                                const gtamd_pck_params *pp) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || bwt == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build"); return -1; }
   const u32 B = pp->block_size, K = pp->bucket_blocks, locint = pp->locate_interval;
   const bool loc_bitmap = locint && (pp->feature_toggles & GTAMD_PCK_LOCATE_BITMAP);
@@ -830,6 +840,14 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   u64 nspecial = 0;
   HIP_TRY(hipStreamSynchronize(p->st));
   HIP_TRY(hipMemcpy(&nspecial, p->d_totals, 8, hipMemcpyDeviceToHost));
+  // (numbers read back from the device are checked before they size or index
+  // anything on the host: a bogus one ends in -1 + message, not in a container
+  // of 2^64 entries)
+  if (nspecial == 0 || nspecial > total_len) {
+    gtamd_set_error("packed index: %llu special symbols counted in a BWT of %llu entries",
+                    (unsigned long long) nspecial, (unsigned long long) total_len);
+    return -1;
+  }
   g.first_special_row = total_len - nspecial;
   if (reversible) {
     // buildSpRTable / gt_createBWTSeqGeneric, eis-bwtseq-construct.c:206-229,
@@ -861,6 +879,12 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   HIP_TRY(hipMemcpy(totals, p->d_totals, ncols * sizeof(u64), hipMemcpyDeviceToHost));
   const u64 var_bits_total = totals[sigma], nregions = totals[sigma + 1];
   if (totals[sigma + 2] != nregions) { gtamd_set_error("packed index: region starts and ends disagree"); return -1; }
+  if (nregions > total_len + 1 || var_bits_total > (total_len + g.L) * PCK_REPLAY_MAX_BITS_PER_POSITION) {
+    gtamd_set_error("packed index: counting pass returned %llu regions and %llu var bits for %llu positions",
+                    (unsigned long long) nregions, (unsigned long long) var_bits_total,
+                    (unsigned long long) total_len);
+    return -1;
+  }
 
   // widths of the occurrence counters: symSumBitsDefaultSetup eis-blockcomp.c:757-774
   // without sequence statistics (trsuftab); with them (mkindex) as many bits as the
@@ -932,7 +956,7 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   TRY(grow(&p->rlist, &rl_cap, std::max<u64>(1, nregions) * 2 * sizeof(u64)));
   p->rlist_cap = rl_cap;
   HIP_TRY(hipMemsetAsync(p->img, 0, ((file_bytes + 7) & ~7ull) + 64, p->st));
-  const u64 tail_n = std::min<u64>(g.nb, PCK_TAIL_RECORDS);
+  u64 tail_n = std::min<u64>(g.nb, std::max<u64>(PCK_TAIL_RECORDS, p->tail_cap));
   // LDS copies of a tile's parts of the bit strings: the whole cw part, and as
   // much of the 64 KB as is left (at most 24 KB) for the var part -- a tile with
   // more var bits writes them straight into the image, and so does every tile
@@ -1000,10 +1024,30 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
     const u64 nr = nregions + 1;
     HIP_TRY(hipMemcpy(p->img + range_enc_pos, &nr, 8, hipMemcpyHostToDevice));
   }
-  {
+  for (;;) {
     std::vector<u64> tail_off((size_t) tail_n);
     HIP_TRY(hipMemcpy(tail_off.data(), p->d_tail, tail_n * sizeof(u64), hipMemcpyDeviceToHost));
-    TRY(fix_stale_bits(p, g, var_bits_total, tail_off));
+    const int frc = fix_stale_bits(p, g, var_bits_total, tail_off);
+    if (frc == 0) break;
+    if (frc != -2 || tail_n >= g.nb) return -1;
+    // the replay wants var offsets of more buckets than were kept: keep 16 times
+    // as many and emit again (the emission ORs the same bits into the same places
+    // and the replay has not patched anything yet, so the image is unchanged)
+    tail_n = std::min<u64>(g.nb, tail_n * 16);
+    if (tail_n > p->tail_cap) {
+      (void) hipFree(p->d_tail);
+      p->d_tail = nullptr; p->tail_cap = 0;
+      if (hipMalloc(&p->d_tail, tail_n * sizeof(u64)) != hipSuccess) {
+        gtamd_set_error("packed index: cannot allocate the var offsets of %llu buckets", (unsigned long long) tail_n);
+        return -1;
+      }
+      p->tail_cap = tail_n;
+    }
+    k_pck_tile<true><<<g.ntiles, PCK_THREADS, lds_emit, p->st>>>(g, bwt, suf, p->lut, p->tile_tot, (u64 *) p->img,
+                                                           p->rlist, p->rlist + std::max<u64>(1, nregions),
+                                                           p->d_tail, g.nb - tail_n, p->spbits, p->sppre);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(p->st));
   }
 
   memset(&p->info, 0, sizeof p->info);
@@ -1013,10 +1057,12 @@ extern "C" int gtamd_pck_build(gtamd_pck *p, const uint8_t *bwt, const uint64_t 
   HIP_TRY(hipEventElapsedTime(&p->info.build_ms, p->ev0, p->ev1));
   p->built = true;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_pck_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa,
                                         const gtamd_pck_params *pp) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || esa == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build_from_esa"); return -1; }
   int device = 0; u32 sigma = 0, numparts = 0;
   TRY(gtamd_esa_internal_info(esa, &device, &sigma, &numparts));
@@ -1031,11 +1077,13 @@ extern "C" int gtamd_pck_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa,
     return -1;
   }
   return gtamd_pck_build(p, bwt, suf, st.numberofallsortedsuffixes, sigma, st.longest, pp);
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_pck_build_host(gtamd_pck *p, const uint8_t *bwt, const uint64_t *suf,
                                     uint64_t total_len, uint32_t sigma, uint64_t longest,
                                     const gtamd_pck_params *pp) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || bwt == nullptr || pp == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_build_host"); return -1; }
   HIP_TRY(hipSetDevice(p->device));
   u8 *d_bwt = nullptr;
@@ -1054,20 +1102,26 @@ extern "C" int gtamd_pck_build_host(gtamd_pck *p, const uint8_t *bwt, const uint
   if (d_bwt) (void) hipFree(d_bwt);
   if (d_suf) (void) hipFree(d_suf);
   return rc;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_pck_get_info(const gtamd_pck *p, gtamd_pck_info *info) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || !p->built || info == nullptr) { gtamd_set_error("no packed index built"); return -1; }
   *info = p->info;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 extern "C" const void *gtamd_pck_image_device(const gtamd_pck *p) {
+  GTAMD_ABI_BEGIN
   return (p != nullptr && p->built) ? p->img : nullptr;
+  GTAMD_ABI_END(nullptr)
 }
 extern "C" int gtamd_pck_image_copy(gtamd_pck *p, void *dst, uint64_t offset, uint64_t count) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || !p->built) { gtamd_set_error("no packed index built"); return -1; }
   if (count == 0) return 0;
-  if (dst == nullptr || offset + count > p->info.file_bytes) {
+  if (dst == nullptr || offset > p->info.file_bytes || count > p->info.file_bytes - offset) {
     gtamd_set_error("packed index: range [%llu,+%llu) outside the %llu bytes of the image",
                     (unsigned long long) offset, (unsigned long long) count,
                     (unsigned long long) p->info.file_bytes);
@@ -1076,11 +1130,13 @@ extern "C" int gtamd_pck_image_copy(gtamd_pck *p, void *dst, uint64_t offset, ui
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipMemcpy(dst, p->img + offset, count, hipMemcpyDeviceToHost));
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 // ---- the context map (-ctxilog, `gt packedindex mkctxmap`) ------------------------
 extern "C" int gtamd_pck_ctxmap_build(gtamd_pck *p, const uint64_t *suf, uint64_t total_len,
                                       int ilog, int *ilog_used) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || suf == nullptr || total_len < 2) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build"); return -1; }
   // CTX_MAP_ILOG_AUTOSIZE, initBWTSeqContextRetrieverFactory eis-bwtseq-context.c:65-68
   if (ilog < 0) ilog = (int) reqbits(reqbits(total_len));
@@ -1117,10 +1173,12 @@ extern "C" int gtamd_pck_ctxmap_build(gtamd_pck *p, const uint64_t *suf, uint64_
   p->cxm_bytes = size;
   if (ilog_used != nullptr) *ilog_used = ilog;
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_pck_ctxmap_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx *esa, int ilog,
                                                int *ilog_used) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || esa == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build_from_esa"); return -1; }
   int device = 0; u32 sigma = 0, numparts = 0;
   TRY(gtamd_esa_internal_info(esa, &device, &sigma, &numparts));
@@ -1128,10 +1186,12 @@ extern "C" int gtamd_pck_ctxmap_build_from_esa(gtamd_pck *p, const gtamd_esa_ctx
   const u64 *suf = (const u64 *) gtamd_esa_table_device(esa, GTAMD_TAB_SUF);
   if (suf == nullptr) { gtamd_set_error("context map: the last run did not produce the .suf table"); return -1; }
   return gtamd_pck_ctxmap_build(p, suf, gtamd_esa_table_entries(esa, GTAMD_TAB_SUF), ilog, ilog_used);
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" int gtamd_pck_ctxmap_build_host(gtamd_pck *p, const uint64_t *suf, uint64_t total_len,
                                            int ilog, int *ilog_used) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || suf == nullptr) { gtamd_set_error("invalid argument to gtamd_pck_ctxmap_build_host"); return -1; }
   HIP_TRY(hipSetDevice(p->device));
   u64 *d_suf = nullptr;
@@ -1144,15 +1204,18 @@ extern "C" int gtamd_pck_ctxmap_build_host(gtamd_pck *p, const uint64_t *suf, ui
     rc = gtamd_pck_ctxmap_build(p, d_suf, total_len, ilog, ilog_used);
   if (d_suf) (void) hipFree(d_suf);
   return rc;
+  GTAMD_ABI_END(-1)
 }
 
 extern "C" uint64_t gtamd_pck_ctxmap_bytes(const gtamd_pck *p) { return p != nullptr ? p->cxm_bytes : 0; }
 
 extern "C" int gtamd_pck_ctxmap_copy(gtamd_pck *p, void *dst, uint64_t offset, uint64_t count) {
+  GTAMD_ABI_BEGIN
   if (p == nullptr || p->cxm_bytes == 0) { gtamd_set_error("no context map built"); return -1; }
   if (count == 0) return 0;
-  if (dst == nullptr || offset + count > p->cxm_bytes) { gtamd_set_error("context map: range outside the image"); return -1; }
+  if (dst == nullptr || offset > p->cxm_bytes || count > p->cxm_bytes - offset) { gtamd_set_error("context map: range outside the image"); return -1; }
   HIP_TRY(hipSetDevice(p->device));
   HIP_TRY(hipMemcpy(dst, p->cxm + offset, count, hipMemcpyDeviceToHost));
   return 0;
+  GTAMD_ABI_END(-1)
 }

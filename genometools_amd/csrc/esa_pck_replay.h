@@ -90,7 +90,12 @@ inline bool replay_tail(const std::vector<u8> &stream, u64 stream_byte0, const s
 
 // tail_off: bit offsets of the var parts of the last tail_off.size() buckets
 // (the field in the cw record may have lost its high bits).  Returns 0, -1 when
-// an image access fails, -2 when the replay needs more than the buckets given.
+// an image access fails, -2 when the replay needs more than the buckets given,
+// -3 when the numbers handed in cannot be right: offsets that decrease or lie
+// behind var_bits_total, a var part longer than a bucket can make it.  (The
+// offsets come back from the device; used unchecked, one wrapped difference
+// sizes a container with ~2^64 entries -- std::length_error)
+constexpr uint64_t PCK_REPLAY_MAX_BITS_PER_POSITION = 192;   // permutation index + mark + rank, generous
 inline int pck_fix_stale_bits(const PckTailGeom &g, uint64_t var_bits_total,
                               const std::vector<uint64_t> &tail_off, pck_image_read_fn rd,
                               pck_image_write_fn wr, void *user) {
@@ -103,6 +108,17 @@ inline int pck_fix_stale_bits(const PckTailGeom &g, uint64_t var_bits_total,
   // record when the locate callback runs (appendCallBackOutput sets the position
   // behind the extension bits), else up to the last composition index stored
   const u64 last_cw_adv = g.locint ? g.cw_bits : (u64) g.pre_comp_idx + (u64) nblk_last * g.comp_idx_bits;
+  if (g.nb == 0 || g.L == 0 || g.B == 0 || g.cw_bits == 0 || last_pos > g.N ||
+      tail_off.empty() || tail_off.size() > g.nb || g.var_data_pos < g.cw_data_pos)
+    return -3;
+  {
+    // what one bucket's var part can hold at most
+    const u64 max_rec = (u64) g.L * PCK_REPLAY_MAX_BITS_PER_POSITION + 256;
+    for (size_t k = 0; k < tail_off.size(); k++) {
+      const u64 next = k + 1 < tail_off.size() ? tail_off[k + 1] : var_bits_total;
+      if (tail_off[k] > next || next - tail_off[k] > max_rec) return -3;
+    }
+  }
   for (u64 window = 64; ; window *= 4) {
     const u64 j0 = last + 1 > window ? last + 1 - window : 0;
     if (last + 1 - j0 > tail_off.size()) return -2;

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void k_synth(SynthParams P, u8 *__restrict__ d
 
 extern "C" int gtamd_synth_bytes(int device, int model, uint64_t seed,
                                  uint64_t n, uint8_t *dst_device) {
+  GTAMD_ABI_BEGIN
   if (model < 0 || model > 3) {
     gtamd_set_error("unknown synthetic model %d", model);
     return -1;
@@ -159,6 +160,7 @@ extern "C" int gtamd_synth_bytes(int device, int model, uint64_t seed,
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
   return 0;
+  GTAMD_ABI_END(-1)
 }
 
 // ---------------------------------------------------------------------------
@@ -175,6 +177,7 @@ static u64 ipow64(u64 b, unsigned e) {
 
 extern "C" uint32_t gtamd_recommended_prefixlength(uint32_t numofchars,
                                                    uint64_t n) {
+  GTAMD_ABI_BEGIN
   if (numofchars < 2) return 1;
   const u64 w = n + 1 <= (u64) UINT_MAX ? 4 : 8;
   // largest exponent that keeps numofchars^k below the code range
@@ -197,4 +200,5 @@ extern "C" uint32_t gtamd_recommended_prefixlength(uint32_t numofchars,
   k--;
   if (k == 0) return 1;
   return mbp >= 1 && mbp < k ? mbp : k;
+  GTAMD_ABI_END(0)
 }

@@ -73,6 +73,12 @@ typedef struct {
   uint64_t pair_suffixes;              /* ... of these, in tie groups of two
                                           (settled by one text comparison) */
   uint64_t device_bytes;               /* device memory the context holds */
+  /* MSD first sort (DNA builds from 2^25 entries): entries in runs too long for
+     the LDS kernel (sorted in global memory by k_msd_big / the device-wide
+     sort), and entries of runs the LDS kernel read but left to its radix
+     fallback because one bin of its counting pass was crowded */
+  uint64_t msd_big_entries;
+  uint64_t msd_crowded_entries;
 } gtamd_esa_stats;
 
 /* per-stage device time of the last run, measured with HIP events on the
@@ -102,6 +108,13 @@ typedef struct {
      ~140 GB at 3 Gbp, the following runs on the context nothing) */
   float alloc_ms;
   uint32_t dominant_kernel;
+  /* entries the dominant kernel reads / writes per launch (k_rs_scatter: both
+     the pairs of the pass; k_msd_local: reads every run that fits its tile,
+     writes the tables of the runs it sorts itself): the roofline's algorithmic
+     bytes are 8 x read + 14.125 x written for k_msd_local, 12 x read + 12 x
+     written for k_rs_scatter */
+  uint64_t scatter_read_items;
+  uint64_t scatter_written_items;
 } gtamd_esa_timing;
 
 typedef struct gtamd_esa_ctx gtamd_esa_ctx;
@@ -114,6 +127,11 @@ const char *gtamd_esa_last_error(void);
 
 /* arithmetic of src/match/sfx-apfxlen.c:83-109 (host only, no device) */
 uint32_t gtamd_recommended_prefixlength(uint32_t numofchars, uint64_t n);
+/* Host-only self test of the exception barrier every entry point of this
+   library runs behind (C callers expect -1 + message, never a C++ exception
+   across the ABI): sizes a host container with `host_bytes` bytes inside the
+   barrier; 0 when the allocation succeeded, -1 (message set) when it threw. */
+int gtamd_abi_selftest(uint64_t host_bytes);
 
 /* ---- context ---------------------------------------------------------- */
 /* Create an engine on HIP device `device` for sequences of up to max_n

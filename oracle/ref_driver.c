@@ -18,7 +18,15 @@
   All reference sources are compiled where they lie under /root/reference by
   oracle/Makefile.ref; the binary lands in oracle/_ref/ (git-ignored).
 
-  usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V]
+  Second oracle: with -sain the tables come from the
+  reference's OTHER construction -- SA-IS + the Phi algorithm,
+    gt_sain_encseq_sortsuffixes           src/match/sfx-sain.c:1577
+    gt_plain_lcp_phialgorithm             src/match/sfx-linlcp.c:131
+  (uint32 only, what `gt dev sain` runs) -- written in the same file layouts, so
+  that the two constructions of the reference can be compared with each other
+  and with the goldens (tests/test_oracle_golden.py).
+
+  usage: gt_ref_sfx (-dna|-protein) [-suf] [-lcp] [-bwt] [-pl K] [-dc V] [-sain]
                     [-dir fwd|rev|cpl|rcl] [-mirrored] [-sat TYPE] [-bck] [-suftabuint] [-clipdesc] [-smap FILE] [-lossless]
                     -db FASTA... -indexname IDX [-time]
 */
@@ -45,6 +53,8 @@
 #include "match/sfx-outprj.h"
 #include "match/sfx-strategy.h"
 #include "match/sfx-suffixer.h"
+#include "match/sfx-sain.h"
+#include "match/sfx-linlcp.h"
 
 static double now_s(void)
 {
@@ -69,7 +79,7 @@ int main(int argc, char **argv)
   int numdb = 0;
   bool dna = true, want_suf = false, want_lcp = false, want_bwt = false,
        showtime = false, haserr = false, mirrored = false, want_bck = false,
-       suftabuint = false, clipdesc = false, lossless = false;
+       suftabuint = false, clipdesc = false, lossless = false, sain = false;
   GtReadmode readmode = GT_READMODE_FORWARD;
   unsigned int userpl = 0, dc = 0, prefixlength, numofchars;
   int i;
@@ -98,6 +108,7 @@ int main(int argc, char **argv)
     else if (!strcmp(argv[i], "-clipdesc")) clipdesc = true;
     else if (!strcmp(argv[i], "-lossless")) lossless = true;
     else if (!strcmp(argv[i], "-mirrored")) mirrored = true;
+    else if (!strcmp(argv[i], "-sain")) sain = true;
     else if (!strcmp(argv[i], "-dir") && i + 1 < argc) {
       const char *d = argv[++i];
       readmode = !strcmp(d, "rev") ? GT_READMODE_REVERSE
@@ -178,6 +189,67 @@ int main(int argc, char **argv)
   }
   totallength = gt_encseq_total_length(encseq);
   numofchars = gt_alphabet_num_of_chars(gt_encseq_alphabet(encseq));
+  if (sain) {
+    /* SA-IS + Phi: .suf (GtUword), .lcp (bytes, 255 = overflow), .llv (index, value) */
+    GtUword nonspecial = totallength - gt_encseq_specialcharacters(encseq), idx,
+            maxlcp = 0;
+    GtUsainindextype *suftab;
+    FILE *fp;
+    if (gt_sain_checkmaxsequencelength(totallength, true, err) != 0) {
+      fprintf(stderr, "gt dev sain: error: %s\n", gt_error_get(err));
+      return EXIT_FAILURE;
+    }
+    t0 = now_s();
+    suftab = gt_sain_encseq_sortsuffixes(encseq, readmode, false, false, NULL, NULL);
+    if (want_suf) {
+      fp = open_tab(indexname, GT_SUFTABSUFFIX);
+      for (idx = 0; idx <= totallength; idx++) {
+        GtUword v = (GtUword) suftab[idx];
+        fwrite(&v, sizeof v, 1, fp);
+      }
+      fclose(fp);
+    }
+    if (want_bwt) {
+      fp = open_tab(indexname, GT_BWTTABSUFFIX);
+      for (idx = 0; idx <= totallength; idx++) {
+        GtUword startpos = (GtUword) suftab[idx];
+        fputc(startpos == 0 ? (int) UNDEFBWTCHAR
+                            : (int) gt_encseq_get_encoded_char(encseq, startpos - 1, readmode),
+              fp);
+      }
+      fclose(fp);
+    }
+    if (want_lcp) {
+      GtUchar *seq = gt_malloc(totallength + 1);
+      unsigned int *lcptab;
+      FILE *fpllv = open_tab(indexname, GT_LARGELCPTABSUFFIX);
+      if (totallength > 0)
+        gt_encseq_extract_encoded(encseq, seq, 0, totallength - 1);
+      lcptab = gt_plain_lcp_phialgorithm(false, &maxlcp, seq, true, nonspecial,
+                                         totallength, suftab);
+      fp = open_tab(indexname, GT_LCPTABSUFFIX);
+      for (idx = 0; idx <= totallength; idx++) {
+        GtUword v = (idx > 0 && idx < nonspecial) ? (GtUword) lcptab[idx] : 0;
+        if (v >= 255UL) {
+          fwrite(&idx, sizeof idx, 1, fpllv);
+          fwrite(&v, sizeof v, 1, fpllv);
+          v = 255UL;
+        }
+        fputc((int) v, fp);
+      }
+      fclose(fp);
+      fclose(fpllv);
+      gt_free(lcptab);
+      gt_free(seq);
+    }
+    gt_free(suftab);
+    if (showtime)
+      printf("# TIME totallength=" GT_WU " sain=%.3f maxlcp=" GT_WU "\n", totallength,
+             now_s() - t0, maxlcp);
+    gt_encseq_delete(encseq);
+    gt_error_delete(err);
+    return EXIT_SUCCESS;
+  }
   prefixlength = userpl > 0
                    ? userpl
                    : gt_recommendedprefixlength(numofchars, totallength,

@@ -80,3 +80,23 @@ def test_no_cpu_fallback():
     from genometools_amd import esa
     with pytest.raises(esa.EsaError):
         esa.suffixerator_tables(enc)
+
+
+def test_exceptions_do_not_cross_the_c_abi():
+    """every extern "C" entry point runs behind a try/catch barrier
+    (GTAMD_ABI_BEGIN / _END, csrc/esa_common.h): a host container that cannot be
+    allocated -- e.g. sized from a bogus device-returned count, the pck2 abort of
+    round 2, DESIGN.md 9a -- ends in -1 + message, not in std::terminate()"""
+    lib = _lib.load()
+    assert lib.gtamd_abi_selftest(0) == 0
+    assert lib.gtamd_abi_selftest(1 << 16) == 0
+    assert lib.gtamd_abi_selftest((1 << 64) - 1) == -1        # std::length_error
+    assert b"gtamd_abi_selftest" in lib.gtamd_esa_last_error()
+    assert lib.gtamd_abi_selftest(1 << 62) == -1              # std::bad_alloc
+    assert b"memory" in lib.gtamd_esa_last_error()
+    # the barrier is in every entry point that has a body of its own
+    import re
+    for f in ("esa_engine.hip", "esa_encode.hip", "esa_pck.hip", "esa_synth.hip"):
+        src = open(os.path.join(_lib.HERE, "csrc", f)).read()
+        for m in re.finditer(r'^extern "C" (?!void)[^\n;{]*?\b(gtamd_\w+)\([^;{]*\{\n(.*)$', src, re.M):
+            assert "GTAMD_ABI_BEGIN" in m.group(2), (f, m.group(1))

@@ -124,3 +124,44 @@ def test_replay_restores_the_reference_file(key, shim):
     rc = shim.pck_replay_run(buf, len(img), ctypes.byref(g), var_bits, arr, len(tail))
     assert rc == 0
     assert hashlib.md5(bytes(img)).hexdigest() == GOLDEN[key]["md5"]
+
+
+def _case(key, shim, mangle):
+    """the replay on an oracle image with the var offsets changed by `mangle`"""
+    name, kw = ou.parse_pck_key(key)
+    enc, sigma, suf, bwt = _project(name, kw.pop("direction", None))
+    raw = ou.pck_bdx(enc, sigma, suf, bwt, **kw)
+    var_bits = ou.lib().ora_pck_last_var_bits()
+    g, pre_var_idx, vdob = _geometry(raw, sigma, kw["locfreq"])
+    cw = int.from_bytes(raw[g.cw_data_pos:g.var_data_pos], "big")
+    nbits = (g.var_data_pos - g.cw_data_pos) * 8
+    fields = [(cw >> (nbits - (j * g.cw_bits + pre_var_idx) - vdob)) & ((1 << vdob) - 1)
+              for j in range(g.nb)]
+    tail = mangle(fields, var_bits, vdob)
+    img = bytearray(raw)
+    buf = (ctypes.c_uint8 * len(img)).from_buffer(img)
+    arr = (ctypes.c_uint64 * len(tail))(*tail)
+    return shim.pck_replay_run(buf, len(img), ctypes.byref(g), var_bits, arr, len(tail)), fields
+
+
+def test_offsets_that_cannot_be_right_are_refused(shim):
+    """What killed the process in round 2 (gpurun_out/pck2_tests.log):
+    var offsets taken from the cw FIELDS, which lose their high bits on
+    Atinsert_seqrange_3-7.fna in mkindex + bitmap mode, so that a difference of two
+    neighbours wrapped to ~2^64 and sized a std::vector.  The replay now checks the
+    numbers it is handed (-3), whoever hands them in."""
+    wrapped = None
+    for key in sorted(GOLDEN):
+        if not key.startswith("Atinsert_seqrange_3-7.fna"):
+            continue
+        rc, fields = _case(key, shim, lambda f, vb, w: f[-65536:])
+        if any(b < a for a, b in zip(fields, fields[1:])):
+            wrapped = key
+            assert rc == -3, key       # the truncated fields as they are
+    assert wrapped is not None, "no golden case with a wrapped offset field"
+    key = sorted(GOLDEN)[0]
+    # decreasing, behind the end of the var part, a var part longer than a bucket can make it
+    assert _case(key, shim, lambda f, vb, w: [f[-1]] + f[-4:-1])[0] == -3
+    assert _case(key, shim, lambda f, vb, w: f[-3:-1] + [vb + 1])[0] == -3
+    assert _case(key, shim, lambda f, vb, w: [0])[0] in (0, -2, -3)      # (tiny images: one bucket)
+    assert _case(key, shim, lambda f, vb, w: [])[0] == -3

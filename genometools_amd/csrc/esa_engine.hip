@@ -2513,6 +2513,9 @@ struct gtamd_esa_ctx {
   DevBuf winbuf;           // bitmaps and list of the rank-table windows
   DevBuf lcpfull_buf;      // LCP values beyond the byte, by table index (when the pairs'
                            // entries are written beside the refinement)
+  DevBuf partws;           // part builds: suffixes kept per text tile, and their scan
+  DevBuf posw;             // part builds with 64-bit positions: positions of the kept
+                           // suffixes in text order
   u64 *llv;
   u64 llv_pairs, llv_cap;
   u32 *bck;                      // .bck sections, back to back
@@ -2584,7 +2587,7 @@ extern "C" void gtamd_esa_destroy(gtamd_esa_ctx *c) {
   DevBuf *bufs[] = {&c->tb_own, &c->sp_own, &c->k0, &c->k1, &c->v0, &c->v1, &c->isa_tmp,
                     &c->rws, &c->dig0, &c->dig1, &c->suf, &c->lcp, &c->bwt, &c->tiebits,
                     &c->tiebits2, &c->arena, &c->arena_p, &c->xrecv, &c->winbuf, &c->msd,
-                    &c->lcpfull_buf};
+                    &c->lcpfull_buf, &c->partws, &c->posw};
   for (DevBuf *b : bufs) free_buf(*b);
   free_dev(c->llv); free_dev(c->bck); free_dev(c->d_stats);
   free_dev(c->d_parthist); free_dev(c->d_owner); free_dev(c->d_counts);
@@ -3107,11 +3110,23 @@ static int msd_level_prepare(gtamd_esa_ctx *c, const MsdWs &w, const u32 *pstart
 // on return the tables are emitted (provisional for tied entries, as after
 // k_finalize): *sa_out holds the positions in suffix order, (*fkey, *fval) are
 // free buffers of 8 / 4 bytes per entry, the tie bitmap and stats->numties are set
-static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_out,
+//
+// A part build (src != nullptr): the entries are the N keys the part has filtered
+// from the text (k_part_filter), not all suffixes of the text; density_n is the
+// length of the whole table (the depth of level C goes by how crowded the ranges
+// are, which is a property of the text, not of the slice).
+struct MsdPartSrc {
+  const u64 *ck;       // the kept keys, text order
+  const u32 *cp32;     // their positions, or nullptr: the value is the entry's number
+  u64 index_offset;    // of the slice
+  const unsigned long long *prev_key;   // device: largest key of the ranges below
+  int has_prev;
+};
+static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u64 density_n,
+                         const MsdPartSrc *src, u32 **sa_out,
                          u64 **fkey, u32 **fval, u64 *local_entries) {
-  const u64 N = c->N;
   hipStream_t st = c->st;
-  const int cmax = msd_cbits_max(N);
+  const int cmax = msd_cbits_max(density_n);
   int cb = msd_cbits_forced() >= 0 ? msd_cbits_forced() : cmax;
   MsdWs w;
   const u64 bytes = msd_carve(N, cb > cmax ? cb : cmax, nullptr, &w);    // room for the deepest level C
@@ -3126,13 +3141,20 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   u32 *kb = c->k1.as<u32>(), *pb = c->v1.as<u32>();
   u8 *xa = c->k1.as<u8>() + pad * 4;
   // ---- level A
-  k_msd_hist_a<<<ntA, MS_THREADS, 0, st>>>(c->text, N, w.hist);
+  if (src != nullptr)
+    k_msd_hist_a_keys<<<ntA, MS_THREADS, 0, st>>>(src->ck, N, w.hist);
+  else
+    k_msd_hist_a<<<ntA, MS_THREADS, 0, st>>>(c->text, N, w.hist);
   HIP_TRY(hipGetLastError());
   TRY(radix_scan_tile_rows(w.hist, ntA, w.scanws, st));
   k_msd_starts_a<<<1, 256, 0, st>>>(w.hist, (u32) N, w.startA);
   HIP_TRY(hipGetLastError());
-  k_msd_scatter_a<<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(c->text, N, last_valid, w.hist,
-                                                               ntA, ka, xa, pa);
+  if (src != nullptr)
+    k_msd_scatter_a<true><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+        c->text, N, last_valid, w.hist, ntA, src->ck, src->cp32, ka, xa, pa);
+  else
+    k_msd_scatter_a<false><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+        c->text, N, last_valid, w.hist, ntA, nullptr, nullptr, ka, xa, pa);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[1], st));
   // ---- level B: (ka, xa, pa) -> (kb, pb)
@@ -3220,6 +3242,9 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
   o.lastkey = w.lastkey;
   o.stats = c->d_stats;
   o.prefixlength = prefixlength;
+  o.index_offset = src != nullptr ? src->index_offset : 0;
+  o.val_is_index = src != nullptr && src->cp32 == nullptr;
+  if (o.val_is_index) o.suf = nullptr;     // (k_part_positions writes it)
   HIP_TRY(hipMemsetAsync(o.tiebits, 0, (div_up(N, 64) + 2) * 8, st));
   if (ntD > 0) {
     // (GTAMD_MSD_RADIX=1: every run takes the LSD passes a run with a crowded
@@ -3254,7 +3279,8 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u32 **sa_
     HIP_TRY(hipGetLastError());
   }
   if (ntD > 0) {
-    k_msd_seams<<<(ntD + 255) / 256, 256, 0, st>>>(w.dtiles, ntD, o);
+    k_msd_seams<<<(ntD + 255) / 256, 256, 0, st>>>(w.dtiles, ntD, src != nullptr ? src->prev_key : nullptr,
+                                                   src != nullptr ? src->has_prev : 0, o);
     HIP_TRY(hipGetLastError());
   }
   *sa_out = pf;
@@ -3321,13 +3347,24 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     const char *e = getenv("GTAMD_MSD");
     msd = e != nullptr ? e[0] == '1' : N >= (1ull << 25);
   }
+  // DNA part builds: the part's suffixes are filtered from the replicated text by
+  // their key range and sorted most significant digit first -- no pair is
+  // exchanged (GTAMD_MSD=0: tile keygen + alltoallv of the pairs + LSD sort, which
+  // is what the 5-bit alphabets still take)
+  bool msd_part = false;
+  u64 prev_key = 0;
+  int has_prev = 0;
+  if (dist && BITS == 2) {
+    const char *e = getenv("GTAMD_MSD");
+    msd_part = !(e != nullptr && e[0] == '0');
+  }
   if (!dist) {
     TRY(ensure_workspace(c, N, want, false));
     HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
     HIP_TRY(hipEventRecord(c->ev[0], st));
     const char *fz = getenv("GTAMD_FUSED_PASS0");
     if (msd) {
-      TRY(msd_sort_emit(c, want, prefixlength, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
+      TRY(msd_sort_emit(c, want, prefixlength, N, N, nullptr, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
       HIP_TRY(hipEventRecord(c->ev_emitted, st));   // (what the joins below wait for)
     } else if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
@@ -3346,6 +3383,101 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       k_keygen<BITS><<<(u32) div_up(N, 1024), 256, 0, st>>>(c->text, 0, N, c->k0.as<u64>(),
                                                             c->v0.as<u32>());
     HIP_TRY(hipGetLastError());
+  } else if (msd_part) {
+    msd = true;
+    // tile geometry of the rank table (cut by text position, see below)
+    tl.T = div_up(div_up(N, R), 4096) * 4096;
+    {
+      const u64 first = (u64) c->part * tl.T < N ? (u64) c->part * tl.T : N;
+      const u64 end = first + tl.T < N ? first + tl.T : N;
+      Tn = end - first;
+    }
+    auto part_sort = [&]() -> int {
+      HIP_TRY(hipMemsetAsync(c->d_stats, 0, sizeof(Stats), st));
+      HIP_TRY(hipEventRecord(c->ev[0], st));
+      // ---- range cuts from a histogram of the key bins over every stride-th
+      // suffix of the WHOLE text: every part computes the same counts (integer
+      // sums) and so the same cuts -- nothing to agree on
+      u32 *hist = c->h_hist;
+      const u64 stride = N > (1ull << 30) ? 64 : (N > (1u << 24) ? 16 : 1);
+      HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
+      k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, 0, N, stride, c->d_parthist);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(hist, c->d_parthist, PART_BINS * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      u64 nsamp = 0;
+      for (int b = 0; b < PART_BINS; b++) nsamp += hist[b];
+      std::vector<u32> cut(R + 1);
+      cut[0] = 0;
+      cut[R] = PART_BINS;
+      {
+        u64 run = 0;
+        u32 b = 0;
+        for (u32 r = 1; r < R; r++) {
+          const u64 target = (u64) (((unsigned __int128) nsamp * r) / R);
+          while (b < (u32) PART_BINS && run < target) run += hist[b++];
+          cut[r] = b;
+        }
+      }
+      const u32 lo = cut[c->part], hi = cut[c->part + 1];
+      // ---- what the part keeps: per text tile, below its range, in all
+      const u64 ntT64 = div_up(N, MS_TILE);
+      if (ntT64 >= (1ull << 31)) { gtamd_set_error("text of %llu tiles", (unsigned long long) ntT64); return -1; }
+      const u32 ntT = (u32) ntT64;
+      TRY(ensure_buf(c, c->partws, ((u64) ntT + 64 + scan_workspace_words(ntT)) * 4, "the tile counts of the part"));
+      u32 *tkeep = c->partws.as<u32>(), *tscan = tkeep + ntT + 32;
+      unsigned long long *acc = reinterpret_cast<unsigned long long *>(c->d_counts);
+      unsigned long long *hacc = reinterpret_cast<unsigned long long *>(c->h_counts);
+      HIP_TRY(hipMemsetAsync(acc, 0, 32, st));
+      HIP_TRY(hipMemsetAsync(tkeep, 0, (u64) ntT * 4, st));
+      k_part_count<<<ntT < 4096u ? ntT : 4096u, MS_THREADS, 0, st>>>(c->text, N, ntT, lo, hi, tkeep, acc);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(hacc, acc, 24, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      index_offset = hacc[0];
+      const u32 binbelow = hacc[0] > 0 ? (u32) hacc[1] : (u32) PART_BINS;
+      has_prev = hacc[0] > 0;
+      NL = hacc[2];
+      if (NL >= SINGLE_LIMIT) {
+        gtamd_set_error("slice of %llu entries exceeds the 32-bit index range of one "
+                        "part: use more parts", (unsigned long long) NL);
+        return -1;
+      }
+      // (everything behind the sort is sized for the slice or the text tile,
+      // whichever is larger: the rank table of the tile lives in the sort's buffers)
+      const u64 cap = NL > Tn ? NL : Tn;
+      TRY(ensure_workspace(c, cap, want, true));
+      if (WIDE) TRY(ensure_buf(c, c->posw, (NL + 8) * 8, "the positions of the part's suffixes"));
+      msd_sa = c->v0.as<u32>();
+      msd_fkey = c->k1.as<u64>();
+      msd_fval = c->v1.as<u32>();
+      if (NL == 0) {
+        HIP_TRY(hipMemsetAsync(c->tiebits.p, 0, 16, st));
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        return 0;
+      }
+      // ---- its keys and positions, in text order
+      TRY(scan_u32(SCAN_SUM, tkeep, tkeep, ntT, false, tscan, st));
+      u64 *ck = c->isa_tmp.as<u64>();
+      HIP_TRY(hipMemsetAsync(acc + 3, 0, 8, st));     // (the largest key below, made beside the filter)
+      if (WIDE)
+        k_part_filter<u64><<<ntT, MS_THREADS, 0, st>>>(c->text, N, lo, hi, binbelow, tkeep, ck,
+                                                      c->posw.as<u64>(), acc + 3);
+      else
+        k_part_filter<u32><<<ntT, MS_THREADS, 0, st>>>(c->text, N, lo, hi, binbelow, tkeep, ck,
+                                                      c->v1.as<u32>(), acc + 3);
+      HIP_TRY(hipGetLastError());
+      MsdPartSrc src;
+      src.ck = ck;
+      src.cp32 = WIDE ? nullptr : c->v1.as<u32>();
+      src.index_offset = index_offset;
+      src.prev_key = acc + 3;
+      src.has_prev = has_prev;
+      TRY(msd_sort_emit(c, want, prefixlength, NL, N, &src, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
+      return 0;
+    };
+    fail = part_sort() != 0;
+    HIP_TRY(hipEventRecord(c->ev_emitted, st));
   } else {
     // the own text tile: T positions per part, a multiple of the keygen tile
     tl.T = div_up(div_up(N, R), 4096) * 4096;
@@ -3476,7 +3608,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     fprintf(stderr, "gtamd: part %u/%u: tile %llu positions, slice %llu entries at %llu%s\n",
             c->part, R, (unsigned long long) Tn, (unsigned long long) NL,
             (unsigned long long) index_offset, WIDE ? " (64-bit positions)" : "");
-  if (dist) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
+  // (a part that filters its suffixes from the text reports a failure with the
+  // count of its ties, further down: no exchange of its own for it)
+  if (dist && !msd_part) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
   if (!msd) HIP_TRY(hipEventRecord(c->ev[1], st));   // (the MSD sort: after its level A)
 
   // ---- first sort: all key bits above the payload
@@ -3520,8 +3654,13 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   // positions at the width the refinement works with
   P *sa;
   if (WIDE) {
-    u64 *sa64 = c->isa_tmp.as<u64>();   // (the bucketing scratch is dead)
-    if (NL > 0) {
+    u64 *sa64 = c->isa_tmp.as<u64>();   // (the bucketing scratch / the kept keys are dead)
+    if (NL > 0 && msd_part && !fail) {
+      k_part_positions<<<(u32) div_up(NL, 256), 256, 0, st>>>(
+          sa32, c->posw.as<u64>(), NL, index_offset, sa64, want_suf ? c->suf.as<u64>() : nullptr,
+          c->d_stats);
+      HIP_TRY(hipGetLastError());
+    } else if (NL > 0 && !msd_part) {
       k_wide_positions<BITS><<<(u32) div_up(NL, 256), 256, 0, st>>>(skey, sa32, NL, sa64);
       HIP_TRY(hipGetLastError());
     }
@@ -3532,10 +3671,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   u8 *d_lcp = want_lcp ? c->lcp.as<u8>() : nullptr;
   u8 *d_bwt = want_bwt ? c->bwt.as<u8>() : nullptr;
 
-  // ---- finalize; a part needs the last key of the preceding range
-  u64 prev_key = 0;
-  int has_prev = 0;
-  if (R > 1) {
+  // ---- finalize; a part needs the last key of the preceding range (the MSD
+  // sort of a part has it from its count of the text)
+  if (R > 1 && !msd_part) {
     u64 mine[2] = {NL, 0};
     HIP_TRY(hipStreamSynchronize(st));
     if (NL > 0)   // (blocking copy: the destination is on this stack frame)
@@ -3571,12 +3709,13 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->ev[3], st));
-  TRY(fetch_stats(c));
-  const u64 numties = c->h_stats->numties;
+  if (!(msd_part && fail)) TRY(fetch_stats(c));
+  const u64 numties = (msd_part && fail) ? 0 : c->h_stats->numties;
   u64 anyties = numties;
+  if (msd_part && fail && R == 1) return -1;
   if (R > 1) {
     std::vector<u64> all(R);
-    TRY(comm_allgather(c, 0, &numties, all.data(), 8));
+    TRY(comm_allgather(c, msd_part ? fail : 0, &numties, all.data(), 8));
     anyties = 0;
     for (u32 r = 0; r < R; r++) anyties += all[r];
   }

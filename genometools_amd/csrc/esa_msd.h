@@ -64,6 +64,10 @@ struct MsdOut {
   u64 *firstkey, *lastkey;   // per level-D tile: its first and last key, for the seams
   Stats *stats;
   u32 prefixlength;
+  u64 index_offset;   // part builds: index of the slice's first entry in the whole table
+  u32 val_is_index;   // part builds with 64-bit positions: the sort's value is the entry's
+                      // number in text order among the part's suffixes, not its position
+                      // (k_part_positions turns it into one afterwards and writes .suf)
 };
 struct MsdAcc {
   unsigned long long sum, ties;
@@ -208,6 +212,279 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_hist_a(Text t, u64 N,
   }
 }
 
+// ---------------------------------------------------------------------------
+// part builds: the suffixes of this part's key range, taken from
+// the replicated text by a scan -- no (key, position) pair leaves the device
+// ---------------------------------------------------------------------------
+// A part owns the suffixes whose PART_BITS leading key bits lie in [lo, hi).
+// Both passes over the text look at those bits only (seven symbols and the
+// special bits of seven positions: a few instructions per suffix where the whole
+// key takes ~40); the whole key is made for the suffixes the part keeps.
+struct DnaWin {       // the text around the suffixes p0 .. p0+7 (p0 a multiple of 8)
+  u64 a_hi, a_lo;     // symbols p0 .. p0+31 and what the word pair holds behind them
+  u64 S;              // bit j: position p0 + j is special
+  u32 pay0;           // payload (symbol in front) of suffix p0
+};
+__device__ __forceinline__ DnaWin dna_win(const Text &t, u64 p0) {
+  using P = Pay<2>;
+  DnaWin r;
+  const u64 w = p0 >> 5;
+  const int o = (int) (p0 & 31) * 2;
+  const u64 hi = tb_word(t, w), lo = tb_word(t, w + 1);
+  r.a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;
+  r.a_lo = lo << o;
+  const u64 sw = p0 >> 6;
+  const int so = (int) (p0 & 63);
+  const u64 s0 = sp_word(t, sw), s1 = sp_word(t, sw + 1);
+  r.S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;
+  if (p0 == 0) {
+    r.pay0 = P::UNDEF;
+  } else {
+    const u32 c = o ? (u32) (hi >> (64 - o)) & 3u : (u32) tb_word(t, w - 1) & 3u;
+    const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
+    r.pay0 = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+  return r;
+}
+// the same from the four words a thread has loaded for its bins
+__device__ __forceinline__ DnaWin dna_win_from(const Text &t, u64 p0, u64 hi, u64 lo, u64 s0, u64 s1) {
+  using P = Pay<2>;
+  DnaWin r;
+  const u64 w = p0 >> 5;
+  const int o = (int) (p0 & 31) * 2;
+  r.a_hi = o ? (hi << o) | (lo >> (64 - o)) : hi;
+  r.a_lo = lo << o;
+  const u64 sw = p0 >> 6;
+  const int so = (int) (p0 & 63);
+  r.S = so ? (s0 >> so) | (s1 << (64 - so)) : s0;
+  if (p0 == 0) {
+    r.pay0 = P::UNDEF;
+  } else {
+    const u32 c = o ? (u32) (hi >> (64 - o)) & 3u : (u32) tb_word(t, w - 1) & 3u;
+    const bool sp = c < 2u && (so ? (s0 >> (so - 1)) & 1ull : sp_word(t, sw - 1) >> 63);
+    r.pay0 = sp ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+  return r;
+}
+// what the bins of p0 .. p0+7 need of it (no payload: two loads less)
+__device__ __forceinline__ void dna_win_bins(const Text &t, u64 p0, u64 &a_hi, u32 &s14) {
+  const u64 w = p0 >> 5;
+  const int o = (int) (p0 & 31) * 2;
+  const u64 hi = tb_word(t, w);
+  a_hi = o ? (hi << o) | (tb_word(t, w + 1) >> (64 - o)) : hi;
+  const u64 sw = p0 >> 6;
+  const int so = (int) (p0 & 63);      // a multiple of 8
+  u64 S = sp_word(t, sw) >> so;
+  if (so > 64 - 14) S |= sp_word(t, sw + 1) << (64 - so);
+  s14 = (u32) S & 0x3FFFu;             // special bits of p0 .. p0+13
+}
+// bit g: the key bin of suffix p0 + g lies in [lo, lo + width); also the number of
+// suffixes with a bin below lo and the largest such bin
+__device__ __forceinline__ u32 dna_bins8_in_range(u64 a_hi, u32 s14, int npos, u32 lo, u32 width,
+                                                  u32 &nbelow, u32 &mxbin) {
+  u32 mask = 0;
+  if (s14 == 0 && npos == KP_PER) {
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) {
+      const u32 bin = (u32) ((a_hi << (2 * g)) >> (64 - PART_BITS));
+      if (bin - lo < width) mask |= 1u << g;
+      else if (bin < lo) { nbelow++; mxbin = bin > mxbin ? bin : mxbin; }
+    }
+    return mask;
+  }
+#pragma unroll
+  for (int g = 0; g < KP_PER; g++) {
+    if (g < npos) {
+      u32 bin = (u32) ((a_hi << (2 * g)) >> (64 - PART_BITS));
+      const u32 s7 = (s14 >> g) & 0x7Fu;
+      if (s7) {
+        const int d = __ffs((int) s7) - 1;
+        bin = d == 0 ? (u32) PART_BINS - 1u : bin | ((1u << (2 * (7 - d))) - 1u);
+      }
+      if (bin - lo < width) mask |= 1u << g;
+      else if (bin < lo) { nbelow++; mxbin = bin > mxbin ? bin : mxbin; }
+    }
+  }
+  return mask;
+}
+// the PART_BITS leading bits of the key of suffix p0 + g: seven symbols, padded
+// with 1-bits behind a special (make_key<2>; key_bin<2>)
+__device__ __forceinline__ u32 dna_bin(const DnaWin &w, int g) {
+  static_assert(PART_BITS == 14 && KP_PER + 7 <= 32, "seven symbols of the first word");
+  u32 b = (u32) ((w.a_hi << (2 * g)) >> (64 - PART_BITS));
+  const u32 s7 = (u32) (w.S >> g) & 0x7Fu;
+  if (s7) {
+    const int d = __ffs((int) s7) - 1;
+    b = d == 0 ? (u32) PART_BINS - 1u : b | ((1u << (2 * (7 - d))) - 1u);
+  }
+  return b;
+}
+// the key of suffix p0 + g, bit for bit that of make_key<2> / dna_keys8
+__device__ __forceinline__ u64 dna_key_at(const DnaWin &w, int g) {
+  using K = Key<2>;
+  using P = Pay<2>;
+  constexpr int SYMS = K::SYMS;
+  u32 pay = w.pay0;
+  if (g > 0) {
+    const u32 c = (u32) (w.a_hi >> (64 - 2 * g)) & 3u;
+    pay = (c < 2u && ((w.S >> (g - 1)) & 1ull)) ? ((c & 1u) ? P::SEP : P::WILD) : c;
+  }
+  const u64 win = g ? (w.a_hi << (2 * g)) | (w.a_lo >> (64 - 2 * g)) : w.a_hi;
+  const u64 s = (w.S >> g) & ((1ull << SYMS) - 1ull);
+  const int d = s ? __ffsll((unsigned long long) s) - 1 : SYMS;
+  if (d == 0) return (~0ull << K::DSHIFT) | pay;
+  u64 pre = win >> K::LOW_BITS;
+  u32 dc = 0;
+  if (d < SYMS) {
+    pre |= (1ull << (2 * (SYMS - d))) - 1ull;
+    dc = (u32) (SYMS - d);
+  }
+  return (pre << K::LOW_BITS) | ((u64) dc << K::DSHIFT) | pay;
+}
+
+// k_part_count: per text tile the number of suffixes the part keeps (tkeep, zeroed
+// by the host; their scan is where the tile's keys go), and over the whole text
+// the number of suffixes BELOW the range (the slice's offset in the table) and the
+// largest key bin among them.  acc: [0] suffixes below, [1] largest bin below, [2]
+// suffixes kept.  No barrier per tile: a wave adds its count to the tile's.
+__global__ __launch_bounds__(MS_THREADS) void k_part_count(
+    Text t, u64 N, u32 ntiles, u32 lo, u32 hi, u32 *__restrict__ tkeep,
+    unsigned long long *__restrict__ acc) {
+  __shared__ unsigned long long s_below[MS_WAVES], s_kept[MS_WAVES];
+  __shared__ u32 s_max[MS_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long below = 0;
+  u32 kept = 0, mxbin = 0;
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const u64 p0 = (u64) tile * MS_TILE + (u64) tid * KP_PER;
+    u32 k = 0;
+    if (p0 < N) {
+      const int npos = N - p0 < KP_PER ? (int) (N - p0) : KP_PER;
+      u64 a_hi;
+      u32 s14, nb = 0;
+      dna_win_bins(t, p0, a_hi, s14);
+      k = (u32) __popc(dna_bins8_in_range(a_hi, s14, npos, lo, hi - lo, nb, mxbin));
+      below += nb;
+    }
+    kept += k;
+    const u32 wsum = wave_scan_incl<SCAN_SUM>(k);
+    if (lane == 63 && wsum) atomicAdd(&tkeep[tile], wsum);
+  }
+  unsigned long long kept64 = kept;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    below += __shfl_xor(below, d, 64);
+    kept64 += __shfl_xor(kept64, d, 64);
+    const u32 o = __shfl_xor(mxbin, d, 64);
+    mxbin = o > mxbin ? o : mxbin;
+  }
+  if (lane == 0) { s_below[w] = below; s_kept[w] = kept64; s_max[w] = mxbin; }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long B = 0, K = 0;
+    u32 M = 0;
+    for (int i = 0; i < MS_WAVES; i++) { B += s_below[i]; K += s_kept[i]; M = s_max[i] > M ? s_max[i] : M; }
+    if (B) atomicAdd(&acc[0], B);
+    if (M) atomicMax(&acc[1], (unsigned long long) M);
+    if (K) atomicAdd(&acc[2], K);
+  }
+}
+
+// k_part_filter: the keys of the suffixes the part keeps, and their positions, in
+// text order (toff: exclusive scan of k_part_count's tile counts), one workgroup
+// per tile.  PV: u32 positions (n < 2^32) or u64.  Beside it the largest key of
+// bin `binbelow` -- the largest bin below the range that holds a suffix -- which
+// is the neighbour of the slice's first entry: its LCP needs nothing else, two
+// keys of different ranges differ inside their PART_BITS leading bits.
+// (binbelow >= PART_BINS: none.)
+// (What the kernel is bound by, measured at 3 Gbp / 8 parts: the bins and the scan
+// 1.9 ms; the keys of the kept suffixes made one by one behind the compaction, with
+// their six loads each, +2.5 ms; made where the bins are looked at with a function
+// per key, every thread walks through eight of them for the one it keeps, +3 ms;
+// stores of single keys, 12 bytes to a line, +1 ms.  So: all eight keys of a thread
+// at once -- dna_keys8 is a few instructions per key away from specials --, the kept
+// ones to LDS, whole lines out.)
+template <typename PV>
+__global__ __launch_bounds__(MS_THREADS) void k_part_filter(
+    Text t, u64 N, u32 lo, u32 hi, u32 binbelow, const u32 *__restrict__ toff,
+    u64 *__restrict__ ck, PV *__restrict__ cp, unsigned long long *__restrict__ prevkey) {
+  __shared__ u64 s_k[MS_TILE];       // the kept keys of the tile, in text order
+  __shared__ u16 s_off[MS_TILE];     // and where in the tile their suffixes start
+  __shared__ u32 s_scan[MS_WAVES];
+  const int tid = threadIdx.x;
+  const u64 tile_base = (u64) blockIdx.x * MS_TILE;
+  const u64 p0 = tile_base + (u64) tid * KP_PER;
+  u64 key[KP_PER];
+  u32 mask = 0;
+  unsigned long long mx = 0;
+  if (p0 < N) {
+    const int npos = N - p0 < KP_PER ? (int) (N - p0) : KP_PER;
+    dna_keys8(t, p0, key);
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) {
+      const u32 bin = (u32) (key[g] >> (64 - PART_BITS));
+      if (g < npos) {
+        if (bin - lo < hi - lo) mask |= 1u << g;
+        else if (bin == binbelow) mx = key[g] > mx ? key[g] : mx;
+      }
+    }
+  }
+  if (mx) atomicMax(prevkey, mx);    // (N / 2^14 suffixes of the text at most)
+  u32 all;
+  u32 at = block_scan_excl<SCAN_SUM, MS_THREADS>((u32) __popc(mask), &all, s_scan);
+#pragma unroll
+  for (int g = 0; g < KP_PER; g++) {
+    if ((mask >> g) & 1u) {
+      s_k[at] = key[g];
+      s_off[at] = (u16) (tid * KP_PER + g);
+      at++;
+    }
+  }
+  __syncthreads();
+  const u64 base = toff[blockIdx.x];
+  for (u32 i = tid; i < all; i += MS_THREADS) {
+    ck[base + i] = s_k[i];
+    cp[base + i] = (PV) (tile_base + (u64) s_off[i]);
+  }
+}
+
+// level A's histogram over a tile of the kept keys
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist_a_keys(const u64 *__restrict__ ck, u64 M,
+                                                                u32 *__restrict__ hist) {
+  __shared__ u32 h[MS_WAVES][256];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < MS_WAVES * 256; i += MS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 base = (u64) blockIdx.x * MS_TILE;
+#pragma unroll
+  for (int j = 0; j < MS_ITEMS; j++) {
+    const u64 e = base + (u64) j * MS_THREADS + tid;
+    if (e < M) atomicAdd(&h[w][(u32) (ck[e] >> 56)], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < MS_WAVES; i++) c += h[i][tid];
+    hist[(u64) blockIdx.x * 256 + tid] = c;
+  }
+}
+
+// positions of a part build with 64-bit positions: the sort carried the entry's
+// number in text order (val_is_index); its position is cp[that number].  Also .suf
+// and the index of suffix 0.
+__global__ __launch_bounds__(256) void k_part_positions(const u32 *__restrict__ idx,
+                                                        const u64 *__restrict__ cp, u64 M,
+                                                        u64 index_offset, u64 *__restrict__ sa64,
+                                                        u64 *__restrict__ suf, Stats *stats) {
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const u64 p = cp[idx[i]];
+  sa64[i] = p;
+  if (suf != nullptr) suf[i] = p;
+  if (p == 0) stats->longest = index_offset + i;
+}
+
 // starts of the 256 level-A ranges: row 0 of the scanned histogram
 __global__ void k_msd_starts_a(const u32 *__restrict__ scanned, u32 N, u32 *__restrict__ start) {
   const u32 d = threadIdx.x;
@@ -215,8 +492,12 @@ __global__ void k_msd_starts_a(const u32 *__restrict__ scanned, u32 N, u32 *__re
   if (d == 0) start[256] = N;
 }
 
+// FROMKEYS: the entries are the keys a part build has filtered from the text (ck,
+// their values cp32 or -- nullptr -- their numbers), not all suffixes of the text
+template <bool FROMKEYS>
 __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     Text t, u64 N, u32 last_valid, const u32 *__restrict__ scanned, u32 ntiles,
+    const u64 *__restrict__ ck, const u32 *__restrict__ cp32,
     u32 *__restrict__ k1out, u8 *__restrict__ xout, u32 *__restrict__ pout) {
   // 40 KB: first the keys in (suffix of the thread, thread) order, padded
   // against bank conflicts; then the staging area in digit order
@@ -234,27 +515,37 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
   u32 gbase = 0;
   if (tid < 256) gbase = scanned[(u64) tile * 256 + tid];
+  u64 key[MS_ITEMS];
+  u32 rk[MS_ITEMS], val[MS_ITEMS];
+  if (FROMKEYS) {
+    // (already in the (wave, item, lane) order of the ranking: no transposition)
+#pragma unroll
+    for (int j = 0; j < MS_ITEMS; j++) {
+      const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;
+      key[j] = e < valid ? ck[tile_base + e] : ~0ull;
+      val[j] = (e < valid && cp32 != nullptr) ? cp32[tile_base + e] : (u32) tile_base + e;
+    }
+  } else {
   {
-    u64 key[KP_PER];
+    u64 key8[KP_PER];
     const u64 p0 = tile_base + (u64) tid * KP_PER;
     if (p0 < N) {
-      dna_keys8(t, p0, key);
+      dna_keys8(t, p0, key8);
     } else {
 #pragma unroll
-      for (int g = 0; g < KP_PER; g++) key[g] = ~0ull;
+      for (int g = 0; g < KP_PER; g++) key8[g] = ~0ull;
     }
 #pragma unroll
-    for (int g = 0; g < KP_PER; g++) s_t[g * MS_PAD + tid] = key[g];
+    for (int g = 0; g < KP_PER; g++) s_t[g * MS_PAD + tid] = key8[g];
   }
   __syncthreads();
-  u64 key[MS_ITEMS];
-  u32 rk[MS_ITEMS];
 #pragma unroll
   for (int j = 0; j < MS_ITEMS; j++) {
     const u32 e = (u32) w * MS_WCHUNK + (u32) j * 64 + lane;   // suffix tile_base + e
     key[j] = s_t[(e & 7u) * MS_PAD + (e >> 3)];
   }
-  __syncthreads();   // the transposition area is free
+  }
+  __syncthreads();   // the transposition area is free (the counters are zero)
   ms_vu16 *cnt_w = (ms_vu16 *) s_cnt_mem + w * 256;
 #pragma unroll
   for (int j = 0; j < MS_ITEMS; j++) {
@@ -300,7 +591,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     const u32 d = rk[j] & 255u;
     const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
     s_k1[pos] = (u32) (key[j] >> 24);
-    s_p[pos] = (u32) tile_base + e;
+    s_p[pos] = FROMKEYS ? val[j] : (u32) tile_base + e;
     s_x[pos] = (u8) ((((u32) (key[j] >> 19) & 31u) << 3) | ((u32) key[j] & 7u));
     s_d[pos] = (u8) d;
   }
@@ -745,7 +1036,7 @@ __device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val,
         acc.mx = l > acc.mx ? l : acc.mx;
         if (db >= o.prefixlength) acc.sum += l;
       }
-      if (pv[c] == 0) o.stats->longest = g0 + (u64) c;
+      if (pv[c] == 0 && !o.val_is_index) o.stats->longest = o.index_offset + g0 + (u64) c;
     }
   }
   if (INTERIOR || (i0 >= 0 && i0 + 4 <= (int) cnt)) {
@@ -1316,9 +1607,12 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_emit_run(
   msd_acc_flush(acc, o.stats);
 }
 
-// lcp of every run's first entry with the last entry of the run in front of it
+// lcp of every run's first entry with the last entry of the run in front of it;
+// a part build: of the slice's first entry with the largest key of the ranges
+// below (prev_key, if has_prev)
 __global__ __launch_bounds__(256) void k_msd_seams(const MdTile *__restrict__ tiles, u32 ntiles,
-                                                   MsdOut o) {
+                                                   const unsigned long long *__restrict__ prev_key_p,
+                                                   int has_prev, MsdOut o) {
   using K = Key<2>;
   const u32 t = blockIdx.x * 256u + threadIdx.x;
   MsdAcc acc;
@@ -1326,10 +1620,14 @@ __global__ __launch_bounds__(256) void k_msd_seams(const MdTile *__restrict__ ti
   acc.mx = 0;
   if (t < ntiles) {
     const MdTile td = tiles[t];
-    if (td.end > td.begin && td.begin > 0) {
-      u32 u = t - 1;
-      while (u > 0 && tiles[u].end == tiles[u].begin) u--;   // (an entry in front exists: begin > 0)
-      const u64 a = o.lastkey[u], b = o.firstkey[t];
+    if (td.end > td.begin && (td.begin > 0 || has_prev)) {
+      u64 a = has_prev ? (u64) *prev_key_p : 0ull;
+      if (td.begin > 0) {
+        u32 u = t - 1;
+        while (u > 0 && tiles[u].end == tiles[u].begin) u--;   // (an entry in front exists: begin > 0)
+        a = o.lastkey[u];
+      }
+      const u64 b = o.firstkey[t];
       const u32 da = K::letters(a), db = K::letters(b);
       const u64 x = (a ^ b) >> K::LOW_BITS;
       const u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;

@@ -1,5 +1,6 @@
-"""The sharded build (lexicographic range parts; every part keys its own text
-tile and sends the pairs to the range owners; rank table cut by text position,
+"""The sharded build (lexicographic range parts; every part filters the suffixes
+of its key range from the replicated text -- DNA -- or keys its own text tile and
+sends the pairs to the range owners -- protein; rank table cut by text position,
 queried and updated through alltoallv): R engine contexts on one device must
 produce, slice by slice, exactly the tables of the single build."""
 import numpy as np
@@ -82,9 +83,10 @@ def test_part_contexts_are_reusable(gpu):
 
 
 def test_part_work_is_a_share_of_the_whole(gpu):
-    """a part keys its own text tile only: its slice, and the device memory it
-    holds, are about 1/R of the single build's"""
-    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 4, 4_000_000)
+    """a part sorts its own slice only: the device memory it holds is about 1/R of
+    the single build's (at a size where the fixed tables of the MSD sort -- 65 536
+    histogram rows, 67 MB -- do not weigh)"""
+    enc = synth.generate(synth.MODEL_UNIFORM_DNA, 4, 48_000_000)
     from genometools_amd import esa
     whole = esa.suffixerator_tables(enc, 4)
     tabs, stats, per_part = build_in_parts(enc, 4, 4)

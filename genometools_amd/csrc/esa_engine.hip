@@ -701,8 +701,7 @@ template <typename P> struct InitialRanks {
   u64 c0, index_offset;
   Tiles tl;
   P *isa;              // this part's tile of the rank table
-  u32 *soff;
-  P *srank;
+  u32 *srec;           // records: offset in the owner's tile, rank (one or two words)
   const u32 *sel;      // windows of 2^wb positions whose ranks travel (nullptr: all)
   int wb;
   __device__ __forceinline__ u32 dest(u64 j) const {
@@ -731,8 +730,43 @@ template <typename P> struct InitialRanks {
   __device__ __forceinline__ void emit(u64 j, u32 at) const {
     u64 off;
     (void) tl.owner((u64) sa[c0 + j], &off);
-    soff[at] = (u32) off;
-    srank[at] = rank_of(c0 + j);
+    const u64 r = (u64) rank_of(c0 + j);
+    u32 *rec = srec + (u64) at * (1 + sizeof(P) / 4);
+    rec[0] = (u32) off;
+    rec[1] = (u32) r;
+    if (sizeof(P) == 8) rec[2] = (u32) (r >> 32);
+  }
+};
+
+// the same for the entries k_win_filter has listed (position, head of the tie group):
+// only the suffixes of the windows whose ranks travel are looked at, once.  The
+// ranks leave as records (offset in the owner's tile, rank) -- one exchange.
+template <typename P> struct FilteredRanks {
+  const P *fpos;
+  const u32 *fhead;
+  u64 index_offset;
+  Tiles tl;
+  P *isa;
+  u32 *srec;           // records of RANKREC words: offset, rank (one or two words)
+  static constexpr int RANKREC = 1 + (int) (sizeof(P) / 4);
+  __device__ __forceinline__ u32 dest(u64 j) const {
+    u64 off;
+    const u32 d = tl.owner((u64) fpos[j], &off);
+    return d == tl.self ? DEST_LOCAL : d;
+  }
+  __device__ __forceinline__ void local(u64 j) const {
+    u64 off;
+    (void) tl.owner((u64) fpos[j], &off);
+    isa[off] = (P) (index_offset + fhead[j]);
+  }
+  __device__ __forceinline__ void emit(u64 j, u32 at) const {
+    u64 off;
+    (void) tl.owner((u64) fpos[j], &off);
+    const u64 r = index_offset + fhead[j];
+    u32 *rec = srec + (u64) at * RANKREC;
+    rec[0] = (u32) off;
+    rec[1] = (u32) r;
+    if (sizeof(P) == 8) rec[2] = (u32) (r >> 32);
   }
 };
 
@@ -753,10 +787,12 @@ template <typename P> struct RankQueries {
     const u32 d = tl.owner(target(j), &off);
     return d == tl.self ? DEST_LOCAL : d;
   }
-  __device__ __forceinline__ void local(u64 j) const {
+  // (the look-ups in the own tile: by k_local_lookups, once the new ranks the
+  // other parts send with their queries are stored -- not here)
+  __device__ __forceinline__ void local(u64) const {}
+  __device__ __forceinline__ void lookup_local(u64 j) const {
     u64 off;
-    (void) tl.owner(target(j), &off);
-    k2[j] = isa[off];
+    if (tl.owner(target(j), &off) == tl.self) k2[j] = isa[off];
   }
   __device__ __forceinline__ void emit(u64 j, u32 at) const {
     u64 off;
@@ -765,6 +801,11 @@ template <typename P> struct RankQueries {
     order[at] = (u32) j;
   }
 };
+template <typename P>
+__global__ __launch_bounds__(256) void k_local_lookups(RankQueries<P> rq, u64 m) {
+  const u64 j = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (j < m) rq.lookup_local(j);
+}
 
 // new ranks of the suffixes a round has refined (slot j moved to a new group)
 template <typename P> struct RankUpdates {
@@ -801,6 +842,87 @@ __global__ __launch_bounds__(256) void k_isa_store(const u32 *__restrict__ off,
                                                    P *__restrict__ isa) {
   const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
   if (i < cnt) isa[off[i]] = rank[i];
+}
+
+// records (offset, rank) as FilteredRanks / the fused round exchange send them
+template <typename P>
+__global__ __launch_bounds__(256) void k_isa_store_rec(const u32 *__restrict__ rec, u64 cnt,
+                                                       P *__restrict__ isa) {
+  constexpr int W = 1 + (int) (sizeof(P) / 4);
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i >= cnt) return;
+  const u32 *r = rec + i * W;
+  u64 v = r[1];
+  if (sizeof(P) == 8) v |= (u64) r[2] << 32;
+  isa[r[0]] = (P) v;
+}
+
+// ---- one exchange per round for the new ranks of the last round AND the queries
+// of this one.  The message for part d: its update records (offset, rank), then
+// its query offsets, 32-bit words.  FuseTab (by value): for the SEND side the
+// words before part d's message, its updates, its queries; the same for the
+// RECEIVE side per source part.
+struct FuseTab {
+  u32 n;                          // parts
+  u32 upre[DEST_MAXPARTS + 1];    // updates for / from the parts before
+  u32 qpre[DEST_MAXPARTS + 1];    // queries ...
+  u64 wpre[DEST_MAXPARTS + 1];    // message words ...
+};
+__device__ __forceinline__ u32 fuse_part(const u32 *pre, u32 n, u32 i) {
+  u32 lo = 0, hi = n;             // largest d with pre[d] <= i
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (pre[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// soff/srank: the bucketed updates (part-major), sq: the bucketed query offsets
+template <typename P>
+__global__ __launch_bounds__(256) void k_fuse_pack(FuseTab tab, const u32 *__restrict__ soff,
+                                                   const P *__restrict__ srank,
+                                                   const u32 *__restrict__ sq,
+                                                   u32 *__restrict__ msg) {
+  constexpr int W = 1 + (int) (sizeof(P) / 4);
+  const u32 nu = tab.upre[tab.n], nq = tab.qpre[tab.n];
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i < nu) {
+    const u32 d = fuse_part(tab.upre, tab.n, (u32) i);
+    u32 *rec = msg + tab.wpre[d] + (u64) ((u32) i - tab.upre[d]) * W;
+    const u64 r = (u64) srank[i];
+    rec[0] = soff[i];
+    rec[1] = (u32) r;
+    if (sizeof(P) == 8) rec[2] = (u32) (r >> 32);
+  } else if (i < (u64) nu + nq) {
+    const u32 k = (u32) (i - nu);
+    const u32 d = fuse_part(tab.qpre, tab.n, k);
+    const u32 ud = tab.upre[d + 1] - tab.upre[d];
+    msg[tab.wpre[d] + (u64) ud * W + (k - tab.qpre[d])] = sq[k];
+  }
+}
+// received messages: first all updates ...
+template <typename P>
+__global__ __launch_bounds__(256) void k_fuse_updates(FuseTab tab, const u32 *__restrict__ msg,
+                                                      P *__restrict__ isa) {
+  constexpr int W = 1 + (int) (sizeof(P) / 4);
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i >= tab.upre[tab.n]) return;
+  const u32 s = fuse_part(tab.upre, tab.n, (u32) i);
+  const u32 *rec = msg + tab.wpre[s] + (u64) ((u32) i - tab.upre[s]) * W;
+  u64 v = rec[1];
+  if (sizeof(P) == 8) v |= (u64) rec[2] << 32;
+  isa[rec[0]] = (P) v;
+}
+// ... then the answers to the queries, source by source
+template <typename P>
+__global__ __launch_bounds__(256) void k_fuse_answers(FuseTab tab, const u32 *__restrict__ msg,
+                                                      const P *__restrict__ isa,
+                                                      P *__restrict__ ans) {
+  constexpr int W = 1 + (int) (sizeof(P) / 4);
+  const u64 i = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (i >= tab.qpre[tab.n]) return;
+  const u32 s = fuse_part(tab.qpre, tab.n, (u32) i);
+  const u32 us = tab.upre[s + 1] - tab.upre[s];
+  ans[i] = isa[msg[tab.wpre[s] + (u64) us * W + ((u32) i - tab.qpre[s])]];
 }
 
 template <typename P>
@@ -1338,10 +1460,14 @@ constexpr u64 WF_SPAN = (u64) WF_THREADS * 4 * WF_Q;      // 16384 entries per w
 
 // (64 registers, not 67: two workgroups of 1024 threads fit a CU, so one computes
 // while the other waits for its loads or for the cursor)
+// P: positions of 32 bits, or of 64 (part builds of n >= 2^32); cap: room in the
+// list -- a workgroup that would write behind it writes nothing and sets
+// stats->count2 (the caller takes another way then)
+template <typename P>
 __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_win_filter(
-    const u32 *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
+    const P *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
     const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
-    u32 *__restrict__ fpos, u32 *__restrict__ fhead, Stats *stats) {
+    P *__restrict__ fpos, u32 *__restrict__ fhead, u64 cap, Stats *stats) {
   // One walk.  Every lane loads four consecutive entries per step (the wave
   // reads 1 KB in one piece), all steps' loads are issued before the first is
   // used; ONE atomic per 16384 entries reserves the workgroup's room in the
@@ -1349,17 +1475,23 @@ __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   __shared__ u32 s_scan[WF_THREADS / 64];
   __shared__ u32 s_base;
   const u64 first = (u64) blockIdx.x * WF_SPAN;
-  u32 p[WF_Q][4];
+  P p[WF_Q][4];
   u32 mask[WF_Q];
 #pragma unroll
   for (int q = 0; q < WF_Q; q++) {
     const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
     if (i0 + 4 <= NL) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
-      p[q][0] = v.x; p[q][1] = v.y; p[q][2] = v.z; p[q][3] = v.w;
+      if (sizeof(P) == 4) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
+        p[q][0] = (P) v.x; p[q][1] = (P) v.y; p[q][2] = (P) v.z; p[q][3] = (P) v.w;
+      } else {
+        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(sa + i0);
+        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(sa + i0 + 2);
+        p[q][0] = (P) v0.x; p[q][1] = (P) v0.y; p[q][2] = (P) v1.x; p[q][3] = (P) v1.y;
+      }
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) p[q][k] = i0 + k < NL ? sa[i0 + k] : 0u;
+      for (int k = 0; k < 4; k++) p[q][k] = i0 + k < NL ? sa[i0 + k] : (P) 0;
     }
   }
   u32 mine = 0;
@@ -1369,7 +1501,7 @@ __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     u32 m = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const u32 w = p[q][k] >> wb;
+      const u64 w = (u64) p[q][k] >> wb;
       if (i0 + k < NL) m |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
     }
     mask[q] = m;
@@ -1377,8 +1509,13 @@ __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
   }
   u32 tot;
   u32 o = block_scan_excl<SCAN_SUM, WF_THREADS>(mine, &tot, s_scan);
-  if (threadIdx.x == 0) s_base = tot ? atomicAdd(&stats->count, tot) : 0u;
+  if (threadIdx.x == 0) {
+    u32 b = tot ? atomicAdd(&stats->count, tot) : 0u;
+    if ((u64) b + tot > cap) { stats->count2 = 1u; b = ~0u; }
+    s_base = b;
+  }
   __syncthreads();
+  if (s_base == ~0u) return;
   o += s_base;
 #pragma unroll
   for (int q = 0; q < WF_Q; q++) {
@@ -3851,10 +3988,18 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       srec = a.take<u32>(sp);
       ssize = a.take<u8>(sp);
     };
+    // (GTAMD_APPLY_EARLY, see below: the table entries of the pairs beside the
+    // rounds need a buffer of their own for the LCP values beyond the byte; both
+    // buffers of this step are agreed on in one exchange)
+    int apply_early = 2;
+    if (const char *e = getenv("GTAMD_APPLY_EARLY")) apply_early = atoi(e);
+    if (apply_early < 0 || apply_early > 2) apply_early = 0;
     {
       Bump sz = {nullptr, 0};
       layout_p(sz);
       fail = ensure_buf(c, c->arena_p, sz.off + 4096, "the pairs of tied suffixes") != 0;
+      if (!fail && want_lcp && apply_early && nrec > 0)
+        fail = ensure_buf(c, c->lcpfull_buf, (NL + 8) * 4, "the LCP values beyond the byte") != 0;
       if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
       else if (fail) return -1;
       Bump a = {c->arena_p.as<u8>(), 0};
@@ -3894,7 +4039,10 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       // pairs per thread: a chunk's first pair pays its whole comparison, the
       // others ride on the diagonal (3 Gbp, alternating in one process, 16 / 32 /
       // 64 / 128 pairs: 145.0 / 144.4 / 144.0 / 143.6 ms)
-      int pair_chunk = 128;
+      // -- with a million threads at least: the kernel waits for its loads, and a
+      // part of eight has an eighth of the records (3 Gbp, 43 M records a part, 8 /
+      // 32 / 128 / 512 pairs per thread: 4.7 / 4.7 / 5.6 / 11.5 ms)
+      int pair_chunk = (int) (nrec >> 20 < 16 ? 16 : (nrec >> 20 > 128 ? 128 : nrec >> 20));
       if (const char *e = getenv("GTAMD_PAIR_CHUNK")) { const int v = atoi(e); if (v >= 4 && v <= 1024) pair_chunk = v; }
       k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256)), 256, 0, st>>>(
           c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk);
@@ -3917,19 +4065,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     // byte of the entries costs its time again (k_win_filter 7.8 -> 13 ms beside
     // them); the rounds wait for latency and launches, and there the entries
     // are nearly free (3 Gbp, one process: 142.5 / 137.5 / 133.0 ms).
-    int apply_early = 2;
-    if (const char *e = getenv("GTAMD_APPLY_EARLY")) apply_early = atoi(e);
-    if (apply_early < 0 || apply_early > 2) apply_early = 0;
     u32 *lcpfull = nullptr;
-    if (want_lcp && apply_early) {
-      // (every part takes this step, with or without pairs of its own: the
-      // parts agree on the outcome)
-      fail = nrec > 0 &&
-             ensure_buf(c, c->lcpfull_buf, (NL + 8) * 4, "the LCP values beyond the byte") != 0;
-      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
-      else if (fail) return -1;
-      if (nrec > 0) lcpfull = c->lcpfull_buf.as<u32>();
-    }
+    if (want_lcp && apply_early && nrec > 0) lcpfull = c->lcpfull_buf.as<u32>();   // (allocated above)
     if (nrec == 0) apply_early = 0;
     // Beside the refinement the two kernels get a grid of one workgroup per CU:
     // with a workgroup per 256 pairs the dispatcher kept every wave slot filled
@@ -4027,7 +4164,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         *koff = nullptr, *fgrp = nullptr, *fj = nullptr, *perm_a = nullptr, *perm_b = nullptr,
         *gk_a = nullptr, *gk_b = nullptr, *fhv = nullptr, *lv_a = nullptr, *lv_b = nullptr,
         *rws2 = nullptr, *scanws2 = nullptr, *xoff = nullptr, *xorder = nullptr,
-        *xbc_q = nullptr, *xbo_q = nullptr, *xbc_u = nullptr, *xbo_u = nullptr;
+        *xbc_q = nullptr, *xbo_q = nullptr, *xbc_u = nullptr, *xbo_u = nullptr, *xqoff = nullptr,
+        *xmsg = nullptr;
+    constexpr u64 RANKREC = 1 + sizeof(P) / 4;     // words of an (offset, rank) record
     u64 *keep = nullptr;
     u8 *xdest_q = nullptr, *xdest_u = nullptr;
     u32 *flagbits = nullptr, *tstart = nullptr;
@@ -4057,6 +4196,10 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       if (dist) {
         xoff = a.take<u32>(xm + 64); xorder = a.take<u32>(xm + 64);
         xrank = a.take<P>(xm + 64); xans = a.take<P>(xm + 64);
+        xqoff = a.take<u32>(xm + 64);
+        // one message per exchange: the first ranks as records; a round's new
+        // ranks (records) and queries (offsets) together
+        xmsg = a.take<u32>((xm + 64) * (RANKREC + 1));
         xdest_q = a.take<u8>(xm + 64); xdest_u = a.take<u8>(xm + 64);
         xbc_q = a.take<u32>(dest_words(R, xm)); xbo_q = a.take<u32>(dest_words(R, xm));
         xbc_u = a.take<u32>(dest_words(R, xm)); xbo_u = a.take<u32>(dest_words(R, xm));
@@ -4067,15 +4210,20 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       layout(sz);
       fail = ensure_buf(c, c->arena, sz.off + 4096, "the refinement of tied suffixes") != 0;
       if (dist && !fail)
-        fail = ensure_buf(c, c->xrecv, xrecv_n * (4 + sizeof(P)) + 512,
+        fail = ensure_buf(c, c->xrecv, xrecv_n * (8 + 2 * sizeof(P)) + 1024,
                           "the exchange of ranks") != 0;
+      if (dist && !fail)      // (bitmaps of the windows of 2^16 positions, see below)
+        fail = ensure_buf(c, c->winbuf, (3 * (div_up(N, 1ull << 16) / 32 + 2) + 16) * 4,
+                          "the rank windows") != 0;
       if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
       else if (fail) return -1;
       Bump a = {c->arena.as<u8>(), 0};
       layout(a);
     }
-    u32 *xrecv_off = c->xrecv.as<u32>();
-    P *xrecv_val = reinterpret_cast<P *>(c->xrecv.as<u8>() + ((xrecv_n * 4 + 255) & ~255ull));
+    // received: a message of up to xrecv_n records and xrecv_n offsets, and behind
+    // it the answers to the offsets
+    u32 *xrecv_msg = c->xrecv.as<u32>();
+    P *xrecv_ans = reinterpret_cast<P *>(c->xrecv.as<u8>() + ((xrecv_n * (4 + 4 * RANKREC) + 255) & ~255ull));
     P *rank = nullptr;       // whole table (single build) ...
     P *isa = nullptr;        // ... or the ranks of the own text tile (part build)
     // ---- unresolved list of what is left
@@ -4189,8 +4337,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         }
         // the pairs of the selected windows, partitioned by window
         HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 4, st));
-        k_win_filter<<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
-            spos, NL, wb, w_sel, tiebits2, carry, ppos, phead, c->d_stats);
+        k_win_filter<u32><<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
+            spos, NL, wb, w_sel, tiebits2, carry, ppos, phead, ~0ull, c->d_stats);
         HIP_TRY(hipGetLastError());
         TRY(fetch_stats(c));
         const u64 M = c->h_stats->count;   // nsel windows (the last one of the text is short)
@@ -4214,16 +4362,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       TRY(build_rank(true));
     }
     std::vector<u64> qcounts(R), ucounts(R), zero(R, 0);
-    std::vector<u64> gathered((size_t) R * (2 * R + 1)), mine(2 * R + 1);
-    auto recv_of = [&](const std::vector<u64> &g, u32 which, std::vector<u64> &rc) -> u64 {
-      // counts this part receives: entry [s][which * R + part] of the gathered rows
-      u64 tot = 0;
-      for (u32 s = 0; s < R; s++) {
-        rc[s] = g[(size_t) s * (2 * R + 1) + which * R + c->part];
-        tot += rc[s];
-      }
-      return tot;
-    };
+    const size_t GW = 2 * (size_t) R + 2;    // a part's row in a round's allgather
+    std::vector<u64> gathered((size_t) R * GW), mine(GW);
     // part builds: the first ranks go to the owners of the positions, ISA_CHUNK
     // entries at a time -- only for the windows of positions the rounds can
     // reach (the union over the parts; see k_win_mark), which is a fifth of the
@@ -4238,26 +4378,47 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       dw_nww = rk_nwin / 32 + 2;
       const char *we = getenv("GTAMD_RANK_ALL_WINDOWS");           // A/B switch
       rk_windows = !(we != nullptr && we[0] == '1');
-      fail = ensure_buf(c, c->winbuf, (3 * dw_nww + 16) * 4, "the rank windows") != 0;
-      if (R > 1) TRY(comm_allgather(c, fail, nullptr, nullptr, 0));
-      else if (fail) return -1;
+      // (a part that cannot get the buffers of this step says so in the first
+      // allgather of send_ranks)
+      fail |= ensure_buf(c, c->winbuf, (3 * dw_nww + 16) * 4, "the rank windows") != 0;
+      if (fail && R == 1) return -1;
       w_need = c->winbuf.as<u32>(); w_built = w_need + dw_nww; w_sel = w_built + dw_nww;
       h_need.assign(dw_nww, 0u); h_built.assign(dw_nww, 0u); h_all.assign((size_t) dw_nww * R, 0u);
-      HIP_TRY(hipMemsetAsync(w_need, 0, 3 * dw_nww * 4, st));
+      if (!fail) HIP_TRY(hipMemsetAsync(w_need, 0, 3 * dw_nww * 4, st));
       rk_h0 = (u64) K::SYMS << 9;
       if (rk_h0 > (3ull << rk_wb)) rk_h0 = 3ull << rk_wb;
-      if (rk_windows && m0 > 0) {
+      if (!fail && rk_windows && m0 > 0) {
         k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, rk_wb, rk_nwin,
                                                             w_need);
         HIP_TRY(hipGetLastError());
       }
+      // where the entries of the windows that travel are listed: a buffer that has
+      // done its work (the keys the part filtered from the text; their positions)
+      P *fpos = nullptr;
+      u32 *fhead = nullptr;
+      u64 list_cap = 0;
+      if (!WIDE) {
+        list_cap = NL;
+        fpos = c->isa_tmp.as<P>();
+        fhead = c->isa_tmp.as<u32>() + ((NL + 3) & ~3ull);
+      } else if (msd_part && c->posw.bytes >= 4096) {
+        list_cap = (c->posw.bytes - 256) / 12;
+        fpos = c->posw.as<P>();
+        fhead = reinterpret_cast<u32 *>(c->posw.as<u8>() + ((list_cap * 8 + 255) & ~255ull));
+        list_cap -= 64;
+      }
       send_ranks = [&]() -> int {
-        // the windows any part needs and nobody has sent yet
+        // the windows any part needs and nobody has sent yet (the first allgather of
+        // this step also says whether a part could not get its buffers)
         const u32 *d_sel = nullptr;
+        int agreed = 0;
         if (rk_windows) {
-          HIP_TRY(hipStreamSynchronize(st));
-          HIP_TRY(hipMemcpy(h_need.data(), w_need, dw_nww * 4, hipMemcpyDeviceToHost));
-          TRY(comm_allgather(c, 0, h_need.data(), h_all.data(), (u32) (dw_nww * 4)));
+          if (!fail) {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h_need.data(), w_need, dw_nww * 4, hipMemcpyDeviceToHost));
+          }
+          TRY(comm_allgather(c, fail, h_need.data(), h_all.data(), (u32) (dw_nww * 4)));
+          agreed = 1;
           u64 fresh = 0, all = 0;
           for (u64 w = 0; w < dw_nww; w++) {
             u32 x = 0;
@@ -4277,38 +4438,72 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           HIP_TRY(hipMemcpyAsync(w_built, h_built.data(), dw_nww * 4, hipMemcpyHostToDevice, st));
           d_sel = w_sel;
         }
-        u64 chunks = div_up(NL, ISA_CHUNK);
-        if (R > 1) {
+        // the entries of those windows, listed in one walk over the slice (a fifth of
+        // it for the human-like workload): what is bucketed and sent is the list.  A
+        // list that does not fit its buffer (or all windows): the slice itself, chunk
+        // by chunk.
+        bool listed = false;
+        u64 M = 0;
+        if (!fail && d_sel != nullptr && NL > 0 && list_cap > 0) {
+          HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 8, st));     // count, count2
+          k_win_filter<P><<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
+              sa, NL, rk_wb, d_sel, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
+          HIP_TRY(hipGetLastError());
+          TRY(fetch_stats(c));
+          listed = c->h_stats->count2 == 0;
+          M = c->h_stats->count;
+        }
+        const u64 items = listed ? M : NL, per = listed ? (xm ? xm : 1) : ISA_CHUNK;
+        u64 chunks = div_up(items, per);
+        if (R > 1 || !agreed) {
           std::vector<u64> all(R);
-          TRY(comm_allgather(c, 0, &chunks, all.data(), 8));
+          TRY(comm_allgather(c, agreed ? 0 : fail, &chunks, all.data(), 8));
           for (u32 r = 0; r < R; r++) chunks = all[r] > chunks ? all[r] : chunks;
         }
         for (u64 ch = 0; ch < chunks; ch++) {
-          const u64 c0 = ch * ISA_CHUNK < NL ? ch * ISA_CHUNK : NL;
-          const u64 cm = NL - c0 < ISA_CHUNK ? NL - c0 : ISA_CHUNK;
-          InitialRanks<P> ir;
-          ir.sa = sa; ir.tiebits = tiebits2; ir.carry = carry; ir.c0 = c0;
-          ir.index_offset = index_offset; ir.tl = tl; ir.isa = isa; ir.soff = xoff; ir.srank = xrank;
-          ir.sel = d_sel; ir.wb = rk_wb;
-          TRY(dest_count(c, ir, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
-          HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
-                                 hipMemcpyDeviceToHost, st));
-          TRY(dest_place(c, ir, cm, xdest_q, xbo_q));
+          const u64 c0 = ch * per < items ? ch * per : items;
+          const u64 cm = items - c0 < per ? items - c0 : per;
+          if (listed) {
+            FilteredRanks<P> fr;
+            fr.fpos = fpos + c0; fr.fhead = fhead + c0; fr.index_offset = index_offset; fr.tl = tl;
+            fr.isa = isa; fr.srec = xmsg;
+            TRY(dest_count(c, fr, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
+            HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
+                                   hipMemcpyDeviceToHost, st));
+            TRY(dest_place(c, fr, cm, xdest_q, xbo_q));
+          } else {
+            InitialRanks<P> ir;
+            ir.sa = sa; ir.tiebits = tiebits2; ir.carry = carry; ir.c0 = c0;
+            ir.index_offset = index_offset; ir.tl = tl; ir.isa = isa; ir.srec = xmsg;
+            ir.sel = d_sel; ir.wb = rk_wb;
+            TRY(dest_count(c, ir, cm, xdest_q, xbc_q, xbo_q, scanws2, 0));
+            HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, DEST_MAXPARTS * 4,
+                                   hipMemcpyDeviceToHost, st));
+            TRY(dest_place(c, ir, cm, xdest_q, xbo_q));
+          }
           HIP_TRY(hipStreamSynchronize(st));
           std::vector<u64> sc(R), rc(R), mat((size_t) R * R);
           for (u32 r = 0; r < R; r++) sc[r] = c->h_counts[r];
           TRY(comm_allgather(c, 0, sc.data(), mat.data(), R * 8));
           u64 nrecv = 0;
           for (u32 s = 0; s < R; s++) { rc[s] = mat[(size_t) s * R + c->part]; nrecv += rc[s]; }
-          if (nrecv + 64 > xrecv_n) {
+          // (every part sees the whole matrix: all of them leave here, or none)
+          int toobig = 0;
+          for (u32 q = 0; q < R && !toobig; q++) {
+            u64 tot = 0;
+            for (u32 s = 0; s < R; s++) tot += mat[(size_t) s * R + q];
+            const u64 first_q = (u64) q * tl.T < N ? (u64) q * tl.T : N;
+            const u64 tile_q = first_q + tl.T < N ? tl.T : N - first_q;
+            if (tot > tile_q) toobig = 1;
+          }
+          if (toobig || nrecv + 64 > xrecv_n) {
             gtamd_set_error("rank exchange: %llu ranks for a tile of %llu positions",
                             (unsigned long long) nrecv, (unsigned long long) Tn);
             return -1;
           }
-          TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "rank offsets"));
-          TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "ranks"));
+          TRY(comm_alltoallv(c, xmsg, sc.data(), xrecv_msg, rc.data(), (u32) (4 * RANKREC), "first ranks"));
           if (nrecv > 0) {
-            k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
+            k_isa_store_rec<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_msg, nrecv, isa);
             HIP_TRY(hipGetLastError());
           }
         }
@@ -4337,7 +4532,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     u64 m_upd = 0;            // slots of the last round (its updates are pending)
     if (anyleft > 0 && dist) {
       rq.upos = upos; rq.h = h; rq.n = n; rq.tl = tl; rq.isa = isa; rq.k2 = k2;
-      rq.sendq = xoff; rq.order = xorder;
+      rq.sendq = xqoff; rq.order = xorder;
       TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
       HIP_TRY(hipMemsetAsync(c->d_counts + DEST_MAXPARTS, 0, DEST_MAXPARTS * 4, st));
     }
@@ -4348,88 +4543,116 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         gtamd_set_error("prefix doubling did not converge after 64 rounds");
         return -1;
       }
-      if (dist && rk_windows && h > rk_h0) {
-        // does this round's offset reach windows whose ranks have not travelled?
-        // (all parts decide together; never happens while h <= rk_h0)
-        HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, 4, st));
-        if (m > 0) {
-          k_win_check<P><<<(u32) div_up(m, 256), 256, 0, st>>>(upos, m, h, rk_wb, rk_nwin, w_built,
-                                                             w_need, c->d_stats);
-          HIP_TRY(hipGetLastError());
-        }
-        TRY(fetch_stats(c));
-        u64 more = c->h_stats->count2 != 0;
-        if (R > 1) {
-          std::vector<u64> all(R);
-          TRY(comm_allgather(c, 0, &more, all.data(), 8));
-          for (u32 r = 0; r < R; r++) more |= all[r];
-        }
-        if (more) {
-          TRY(send_ranks());
-          // (the exchange used the bucketing buffers of this round's queries)
-          TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
-        }
-      }
       if (dist) {
-        // one allgather per round: pending updates, queries, and who is left
+        // does this round's offset reach windows whose ranks have not travelled?
+        // (never while h <= rk_h0; the parts decide together, in the allgather below)
+        u64 more = 0;
+        if (rk_windows && h > rk_h0) {
+          HIP_TRY(hipMemsetAsync(&c->d_stats->count2, 0, 4, st));
+          if (m > 0) {
+            k_win_check<P><<<(u32) div_up(m, 256), 256, 0, st>>>(upos, m, h, rk_wb, rk_nwin, w_built,
+                                                               w_need, c->d_stats);
+            HIP_TRY(hipGetLastError());
+          }
+          HIP_TRY(hipMemcpyAsync(c->h_stats, c->d_stats, sizeof(Stats), hipMemcpyDeviceToHost, st));
+        }
+        // ONE allgather per round: pending updates, queries, who is left, and
+        // whether more first ranks have to travel
         HIP_TRY(hipMemcpyAsync(c->h_counts, c->d_counts, 2 * DEST_MAXPARTS * 4,
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (rk_windows && h > rk_h0) more = c->h_stats->count2 != 0;
         for (u32 r = 0; r < R; r++) {
           mine[r] = c->h_counts[r];                        // queries to r
           mine[R + r] = c->h_counts[DEST_MAXPARTS + r];    // updates to r
         }
         mine[2 * R] = m;
-        TRY(comm_allgather(c, 0, mine.data(), gathered.data(), (2 * R + 1) * 8));
+        mine[2 * R + 1] = more;
+        TRY(comm_allgather(c, 0, mine.data(), gathered.data(), (u32) (GW * 8)));
         u64 left = 0, upd = 0;
         for (u32 s = 0; s < R; s++) {
-          left += gathered[(size_t) s * (2 * R + 1) + 2 * R];
-          for (u32 r = 0; r < R; r++) upd += gathered[(size_t) s * (2 * R + 1) + R + r];
+          left += gathered[(size_t) s * GW + 2 * R];
+          more |= gathered[(size_t) s * GW + 2 * R + 1];
+          for (u32 r = 0; r < R; r++) upd += gathered[(size_t) s * GW + R + r];
         }
         if (left == 0) break;   // (ranks nobody will ask for need not travel)
-        // the new ranks of the last round, before anybody looks them up
-        if (m_upd > 0) TRY(dest_place(c, ru, m_upd, xdest_u, xbo_u));
-        if (upd > 0 && R > 1) {
-          std::vector<u64> sc(R), rc(R);
-          for (u32 r = 0; r < R; r++) sc[r] = mine[R + r];
-          const u64 nrecv = recv_of(gathered, 1, rc);
-          if (nrecv + 64 > xrecv_n) {
-            gtamd_set_error("rank exchange: %llu updates for a tile of %llu positions",
-                            (unsigned long long) nrecv, (unsigned long long) Tn);
-            return -1;
-          }
-          TRY(comm_alltoallv(c, xoff + 0, sc.data(), xrecv_off, rc.data(), 4, "update offsets"));
-          TRY(comm_alltoallv(c, xrank, sc.data(), xrecv_val, rc.data(), sizeof(P), "updates"));
-          if (nrecv > 0) {
-            k_isa_store<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, xrecv_val, nrecv, isa);
-            HIP_TRY(hipGetLastError());
-          }
+        if (more) {
+          TRY(send_ranks());
+          // (the exchange used the bucketing buffers of this round's queries; the
+          // counts come out the same)
+          TRY(dest_count(c, rq, m, xdest_q, xbc_q, xbo_q, scanws2, 0));
         }
+        // the new ranks of the last round and the queries of this one: bucketed by
+        // owner (own tile: stored / answered in place) ...
+        if (m_upd > 0) TRY(dest_place(c, ru, m_upd, xdest_u, xbo_u));
         m_upd = 0;
-        // rank queries of this round: own tile answered in place, the others
-        // by the owners
-        rq.sendq = xoff; rq.order = xorder;
+        rq.sendq = xqoff; rq.order = xorder;
         TRY(dest_place(c, rq, m, xdest_q, xbo_q));
         if (R > 1) {
-          std::vector<u64> sc(R), rc(R);
-          u64 msent = 0;
-          for (u32 r = 0; r < R; r++) { sc[r] = mine[r]; msent += sc[r]; }
-          const u64 nrecv = recv_of(gathered, 0, rc);
-          if (nrecv + 64 > xrecv_n) {
-            gtamd_set_error("rank exchange: %llu queries for a tile of %llu positions",
-                            (unsigned long long) nrecv, (unsigned long long) Tn);
+          // ... and sent as ONE message per part: its update records, then its query
+          // offsets; the owners store the updates before they look anything up
+          // (k_fuse_updates, then k_fuse_answers) and send the answers back
+          constexpr u32 W = (u32) RANKREC;
+          FuseTab ts, tr;
+          ts.n = tr.n = R;
+          std::vector<u64> sw(R), rw(R), sq(R), rqc(R);
+          ts.upre[0] = ts.qpre[0] = tr.upre[0] = tr.qpre[0] = 0;
+          ts.wpre[0] = tr.wpre[0] = 0;
+          for (u32 r = 0; r < R; r++) {
+            const u64 us = mine[R + r], qs = mine[r];
+            const u64 ur = gathered[(size_t) r * GW + R + c->part], qr = gathered[(size_t) r * GW + c->part];
+            sw[r] = us * W + qs; rw[r] = ur * W + qr;
+            sq[r] = qs; rqc[r] = qr;
+            ts.upre[r + 1] = ts.upre[r] + (u32) us; ts.qpre[r + 1] = ts.qpre[r] + (u32) qs;
+            ts.wpre[r + 1] = ts.wpre[r] + sw[r];
+            tr.upre[r + 1] = tr.upre[r] + (u32) ur; tr.qpre[r + 1] = tr.qpre[r] + (u32) qr;
+            tr.wpre[r + 1] = tr.wpre[r] + rw[r];
+          }
+          // (a position of a tile is updated and asked for at most once per round;
+          // every part sees the whole matrix, so all of them leave here or none)
+          int toobig = 0;
+          for (u32 q = 0; q < R; q++) {
+            u64 tu = 0, tq = 0;
+            for (u32 s = 0; s < R; s++) {
+              tu += gathered[(size_t) s * GW + R + q];
+              tq += gathered[(size_t) s * GW + q];
+            }
+            const u64 first_q = (u64) q * tl.T < N ? (u64) q * tl.T : N;
+            const u64 tile_q = first_q + tl.T < N ? tl.T : N - first_q;
+            if (tu > tile_q || tq > tile_q) toobig = 1;
+          }
+          if (toobig || (u64) tr.upre[R] + 64 > xrecv_n || (u64) tr.qpre[R] + 64 > xrecv_n) {
+            gtamd_set_error("rank exchange: %u updates and %u queries for a tile of %llu positions",
+                            tr.upre[R], tr.qpre[R], (unsigned long long) Tn);
             return -1;
           }
-          TRY(comm_alltoallv(c, xoff, sc.data(), xrecv_off, rc.data(), 4, "queries"));
-          if (nrecv > 0) {
-            k_answer<P><<<(u32) div_up(nrecv, 256), 256, 0, st>>>(xrecv_off, nrecv, isa, xrecv_val);
+          const u64 nsend = (u64) ts.upre[R] + ts.qpre[R];
+          if (nsend > 0) {
+            k_fuse_pack<P><<<(u32) div_up(nsend, 256), 256, 0, st>>>(ts, xoff, xrank, xqoff, xmsg);
             HIP_TRY(hipGetLastError());
           }
-          TRY(comm_alltoallv(c, xrecv_val, rc.data(), xans, sc.data(), sizeof(P), "answers"));
-          if (msent > 0) {
-            k_k2_scatter<P><<<(u32) div_up(msent, 256), 256, 0, st>>>(xans, xorder, msent, k2);
+          TRY(comm_alltoallv(c, xmsg, sw.data(), xrecv_msg, rw.data(), 4, "new ranks and queries"));
+          if (tr.upre[R] > 0) {
+            k_fuse_updates<P><<<(u32) div_up(tr.upre[R], 256), 256, 0, st>>>(tr, xrecv_msg, isa);
             HIP_TRY(hipGetLastError());
           }
+          if (tr.qpre[R] > 0) {
+            k_fuse_answers<P><<<(u32) div_up(tr.qpre[R], 256), 256, 0, st>>>(tr, xrecv_msg, isa, xrecv_ans);
+            HIP_TRY(hipGetLastError());
+          }
+          // (the look-ups in the own tile, now that everybody's new ranks are in)
+          if (m > 0) {
+            k_local_lookups<P><<<(u32) div_up(m, 256), 256, 0, st>>>(rq, m);
+            HIP_TRY(hipGetLastError());
+          }
+          TRY(comm_alltoallv(c, xrecv_ans, rqc.data(), xans, sq.data(), sizeof(P), "answers"));
+          if (ts.qpre[R] > 0) {
+            k_k2_scatter<P><<<(u32) div_up(ts.qpre[R], 256), 256, 0, st>>>(xans, xorder, ts.qpre[R], k2);
+            HIP_TRY(hipGetLastError());
+          }
+        } else if (m > 0) {
+          k_local_lookups<P><<<(u32) div_up(m, 256), 256, 0, st>>>(rq, m);
+          HIP_TRY(hipGetLastError());
         }
       }
       rounds++;

@@ -84,7 +84,9 @@ def _engine_worker(rank, world, port, q, wide):
         torch.cuda.set_device(0)
         comm = TorchComm("cuda:0")          # device buffers, host transport
         assert comm.staged
-        enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 17, 350000)
+        # (tandem arrays: groups that go through the doubling rounds -- a DNA part
+        # build exchanges nothing but their ranks, the sort of a part is local)
+        enc = synth.generate(synth.MODEL_REPEAT_HEAVY, 17, 350000)
         ora = ou.esa(enc, 4)
         with esa.EsaEngine(enc.size, 4) as eng:
             eng.set_sequence(enc)
@@ -102,11 +104,11 @@ def _engine_worker(rank, world, port, q, wide):
         assert st["lcptabsum"] == int(ora["stats"]["lcptabsum"])
         assert st["longest"] == ora["stats"]["longest"]
         assert st["maxbranchdepth"] == ora["stats"]["maxbranchdepth"]
-        assert comm.calls > 0 and comm.bytes_exchanged > 0
-        q.put((rank, "ok", cnt))
+        assert st["refine_rounds"] > 0 and comm.calls > 0
+        q.put((rank, "ok", cnt, comm.bytes_exchanged))
     except Exception as e:   # noqa: BLE001
         import traceback
-        q.put((rank, repr(e) + traceback.format_exc(), 0))
+        q.put((rank, repr(e) + traceback.format_exc(), 0, 0))
     finally:
         dist.destroy_process_group()
 
@@ -132,3 +134,4 @@ def test_engine_across_processes(gpu, wide):
         p.join(timeout=120)
     assert sorted(o[:2] for o in out) == [(r, "ok") for r in range(world)], out
     assert sum(o[2] for o in out) == 350001
+    assert sum(o[3] for o in out) > 0          # ranks travelled

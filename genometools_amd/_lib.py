@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 LIB_PATH = os.path.join(HERE, "libgtamd_esa.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in
            ("esa_prims.hip", "esa_engine.hip", "esa_synth.hip", "esa_encode.hip",
-            "esa_pck.hip")]
+            "esa_pck.hip", "esa_comm.hip")]
 HEADERS = [os.path.join(HERE, "csrc", f) for f in ("esa_common.h", "esa_prims.h", "esa_devutil.h", "esa_msd.h",
                                                      "esa_pck_replay.h")] + \
           [os.path.join(ROOT, "include", h) for h in ("gtamd_esa.h", "gtamd_encode.h", "gtamd_pck.h")]
@@ -121,6 +121,12 @@ ABI = {
     "gtamd_esa_set_prefixlength": (_INT, [_P, _U32]),
     "gtamd_esa_set_readmode": (_INT, [_P, _INT]),
     "gtamd_esa_set_comm": (_INT, [_P, _P, _P, _P]),
+    "gtamd_comm_threads_create": (_P, [_U32]),
+    "gtamd_comm_rccl_unique_id": (_INT, [_P]),
+    "gtamd_comm_rccl_create": (_P, [_P, _U32, _U32, _INT]),
+    "gtamd_comm_attach": (_INT, [_P, _U32, _P, _INT]),
+    "gtamd_comm_abort": (None, [_P]),
+    "gtamd_comm_destroy": (None, [_P]),
     "gtamd_esa_set_sequence_bytes": (_INT, [_P, _P, _U64, _INT]),
     "gtamd_esa_set_sequence_packed": (_INT, [_P, _P, _P, _U64]),
     "gtamd_esa_run": (_INT, [_P, _U32]),

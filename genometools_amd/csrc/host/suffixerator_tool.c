@@ -7,6 +7,7 @@
 #include "gtamd_pck.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdarg.h>
 #include <string.h>
 #include <time.h>
 #include <pthread.h>
@@ -16,6 +17,15 @@
 static int fail(char *err, size_t errlen, const char *msg, const char *arg)
 {
   snprintf(err, errlen, msg, arg);
+  return -1;
+}
+
+static int failf(char *err, size_t errlen, const char *fmt, ...)
+{
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err, errlen, fmt, ap);
+  va_end(ap);
   return -1;
 }
 
@@ -86,12 +96,13 @@ static void *table_writer_main(void *arg)
   }
 }
 
-static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
+/* the table `which` of a build -- of its parts in part order: the slices of a
+   build in parts tile the table -- through two staging buffers to the file */
+static int write_table(gtamd_esa_ctx *const *ctxs, uint32_t nctx, gtamd_table which, const char *index,
                        const char *suffix, size_t entrysize, char *err, size_t errlen)
 {
   const int narrow = which == GTAMD_TAB_SUF && entrysize == 4;
   char path[4096];
-  const uint64_t entries = gtamd_esa_table_entries(ctx, which);
   /* 64 MiB staging buffers (GTAMD_TABLE_CHUNK=BYTES: a test hook that forces
      many pieces through the two-buffer hand-over on small tables) */
   const char *chunkenv = getenv("GTAMD_TABLE_CHUNK");
@@ -117,6 +128,9 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
     free(w.buf[0]); free(w.buf[1]); fclose(w.fp);
     return fail(err, errlen, "cannot start the writer of file '%s'", path);
   }
+  for (uint32_t part = 0; part < nctx && rc == 0; part++) {
+  gtamd_esa_ctx *ctx = ctxs[part];
+  const uint64_t entries = gtamd_esa_table_entries(ctx, which);
   for (uint64_t first = 0; first < entries && rc == 0; first += chunk, k ^= 1) {
     const uint64_t cnt = entries - first < chunk ? entries - first : chunk;
     pthread_mutex_lock(&w.mu);
@@ -138,6 +152,7 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
     pthread_cond_broadcast(&w.cv);
     pthread_mutex_unlock(&w.mu);
   }
+  }
   pthread_mutex_lock(&w.mu);
   while (w.full[0] || w.full[1]) pthread_cond_wait(&w.cv, &w.mu);
   w.done = 1;
@@ -152,6 +167,109 @@ static int write_table(gtamd_esa_ctx *ctx, gtamd_table which, const char *index,
     rc = -1;
   }
   if (fclose(w.fp) != 0 && rc == 0) return fail(err, errlen, "cannot close file '%s'", path);
+  return rc;
+}
+
+/* ---------------------------------------------------------------------------
+   -gpus R (not a reference option; the reference's -parts cuts the same way,
+   src/match/sfx-partssuf.c:172-347, to save memory): R lexicographic ranges of the
+   suffix table, one engine context and one host thread per range, on the GPUs of
+   the node in turn (all on the one GPU when there is one: the tests).  The
+   transport is the library's own (gtamd_comm_threads_create, include/gtamd_esa.h).
+   --------------------------------------------------------------------------- */
+typedef struct {
+  gtamd_comm *comm;
+  uint32_t part, numparts, userpl, want;
+  int device, numofchars, rc;
+  const uint8_t *enc;
+  uint64_t n;
+  gtamd_esa_ctx *ctx;
+  gtamd_esa_stats es;
+  char err[1024];
+} part_job;
+
+static void *part_main(void *arg)
+{
+  part_job *j = arg;
+  j->rc = -1;
+  j->ctx = gtamd_esa_create(j->device, j->n, (uint32_t) j->numofchars);
+  if (j->ctx != NULL && gtamd_comm_attach(j->comm, j->part, j->ctx, j->device) == 0 &&
+      gtamd_esa_set_prefixlength(j->ctx, j->userpl) == 0 &&
+      gtamd_esa_set_sequence_bytes(j->ctx, j->enc, j->n, 0) == 0 &&
+      gtamd_esa_run(j->ctx, j->want) == 0 && gtamd_esa_get_stats(j->ctx, &j->es) == 0)
+    j->rc = 0;
+  if (j->rc != 0) {
+    snprintf(j->err, sizeof j->err, "%s", gtamd_esa_last_error());
+    gtamd_comm_abort(j->comm);      /* the other parts must not wait for this one */
+  }
+  return NULL;
+}
+
+/* ctxs[0 .. R): the contexts holding the slices (the caller destroys them);
+   es: the statistics of the whole table */
+static int build_in_parts(const uint8_t *enc, uint64_t n, int numofchars, uint32_t userpl,
+                          uint32_t want, uint32_t R, gtamd_esa_ctx **ctxs, gtamd_esa_stats *es,
+                          char *err, size_t errlen)
+{
+  part_job *jobs = calloc(R, sizeof *jobs);
+  pthread_t *threads = calloc(R, sizeof *threads);
+  gtamd_comm *comm = gtamd_comm_threads_create(R);
+  const char *same = getenv("GTAMD_GPUS_SAME_DEVICE");
+  int ndev = gtamd_device_count(), rc = 0;
+  uint32_t started = 0;
+  uint64_t expect = 0;
+  if (jobs == NULL || threads == NULL || comm == NULL) {
+    free(jobs); free(threads); gtamd_comm_destroy(comm);
+    return failf(err, errlen, "cannot set up a build in %u parts", R);
+  }
+  if (ndev < 1 || (same != NULL && same[0] == '1')) ndev = 1;
+  for (uint32_t r = 0; r < R; r++) {
+    jobs[r].comm = comm; jobs[r].part = r; jobs[r].numparts = R; jobs[r].userpl = userpl;
+    jobs[r].want = want; jobs[r].device = (int) (r % (uint32_t) ndev);
+    jobs[r].numofchars = numofchars; jobs[r].enc = enc; jobs[r].n = n;
+    if (pthread_create(&threads[r], NULL, part_main, &jobs[r]) != 0) {
+      gtamd_comm_abort(comm);
+      rc = failf(err, errlen, "cannot start the thread of part %u", r);
+      break;
+    }
+    started++;
+  }
+  for (uint32_t r = 0; r < started; r++) pthread_join(threads[r], NULL);
+  memset(es, 0, sizeof *es);
+  for (uint32_t r = 0; r < R; r++) {
+    ctxs[r] = jobs[r].ctx;
+    if (r < started && jobs[r].rc != 0 && rc == 0) {
+      /* (the message of the part that failed first, not of those it took along) */
+      uint32_t first = r;
+      for (uint32_t q = 0; q < started; q++)
+        if (jobs[q].rc != 0 && strstr(jobs[q].err, "of the build failed") == NULL &&
+            strstr(jobs[q].err, "callback failed") == NULL) { first = q; break; }
+      rc = failf(err, errlen, "part %u of %u: %s", first, R, jobs[first].err);
+    }
+  }
+  for (uint32_t r = 0; r < R && rc == 0; r++) {
+    const gtamd_esa_stats *p = &jobs[r].es;
+    if (gtamd_esa_table_offset(ctxs[r]) != expect)
+      rc = failf(err, errlen, "the slices of the parts do not tile the table (part %u)", r);
+    expect += gtamd_esa_table_entries(ctxs[r], (want & GTAMD_WANT_SUF) ? GTAMD_TAB_SUF :
+                                               (want & GTAMD_WANT_LCP) ? GTAMD_TAB_LCP : GTAMD_TAB_BWT);
+    es->totallength = p->totallength;
+    es->numberofallsortedsuffixes = p->numberofallsortedsuffixes;
+    es->prefixlength = p->prefixlength;
+    es->longest += p->longest;                 /* (0 from the parts without suffix 0) */
+    es->largelcpvalues += p->largelcpvalues;
+    es->lcptabsum += p->lcptabsum;
+    es->tied_suffixes += p->tied_suffixes;
+    es->pair_suffixes += p->pair_suffixes;
+    es->device_bytes += p->device_bytes;
+    if (p->maxbranchdepth > es->maxbranchdepth) es->maxbranchdepth = p->maxbranchdepth;
+    if (p->refine_rounds > es->refine_rounds) es->refine_rounds = p->refine_rounds;
+  }
+  if (rc == 0 && expect != n + 1)
+    rc = failf(err, errlen, "the parts hold %llu of the %llu table entries",
+              (unsigned long long) expect, (unsigned long long) (n + 1));
+  gtamd_comm_destroy(comm);
+  free(jobs); free(threads);
   return rc;
 }
 
@@ -328,7 +446,8 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
   gtamd_seqstats ss;
   gtamd_encinfo info;
   gtamd_esa_stats es;
-  gtamd_esa_ctx *ctx;
+  gtamd_esa_ctx *ctx = NULL, **ctxs = NULL;
+  uint32_t gpus = 1, nctx = 1;
   gtamd_encoder *de = NULL;
   int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0, lossless = 0;
   const char *reader = "host";
@@ -374,6 +493,14 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
         return fail(err, errlen, "argument to option -dir must be fwd or rev or cpl or rcl, not %s", argv[i]);
     } else if (!strcmp(a, "-mirrored")) {
       mirrored = 1;
+    } else if (!strcmp(a, "-gpus")) {
+      /* not a reference option: build the tables in that many lexicographic ranges,
+         one per GPU (or all on the one there is) */
+      long v = i + 1 < argc ? strtol(argv[i + 1], NULL, 10) : 0;
+      if (v < 1 || v > 128)
+        return failf(err, errlen, "argument to option \"-%s\" must be an integer from 1 to 128", "gpus");
+      gpus = (uint32_t) v;
+      i++;
     } else if (!strcmp(a, "-parts") || !strcmp(a, "-memlimit") || !strcmp(a, "-dc") ||
                !strcmp(a, "-maxwidthrealmedian")) {
       /* space/strategy knobs of the CPU algorithm: the tables do not depend on
@@ -579,12 +706,35 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
       return fail(err, errlen, "cannot open file '%s' for writing", path);
     return 0;
   }
+  if (gpus > 1) {
+    /* in parts: every part packs the sequence on its own device from the host copy */
+    if ((want & GTAMD_WANT_BCK) || pr != NULL) {
+      failf(err, errlen, "option \"-gpus\" cannot be combined with %s: that needs the whole "
+           "table in one build", pr != NULL ? "the packed index" : "option \"-bck\"");
+      goto done;
+    }
+    if (enc == NULL) {
+      if ((enc = malloc(n ? n : 1)) == NULL || gtamd_encoder_copy_symbols(de, enc, 0, n) != 0) {
+        failf(err, errlen, "cannot bring the encoded sequence to the host: %s", gtamd_esa_last_error());
+        goto done;
+      }
+    }
+    gtamd_encoder_destroy(de);
+    de = NULL;
+    if ((ctxs = calloc(gpus, sizeof *ctxs)) == NULL) { failf(err, errlen, "out of memory"); goto done; }
+    nctx = gpus;
+    t_create = 0;
+    if (build_in_parts(enc, n, (int) ss.numofchars, userpl, want, gpus, ctxs, &es, err, errlen) != 0) goto done;
+    ctx = ctxs[0];
+    goto built;
+  }
   t_create = now_s();
   ctx = gtamd_esa_create(0, n, ss.numofchars);
   t_create = now_s() - t_create;
   if (ctx == NULL) {
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     free(enc); gtamd_encoder_destroy(de);
+    gtamd_alphabet_free(&alpha);
     return -1;
   }
   if (gtamd_esa_set_prefixlength(ctx, userpl) != 0 ||
@@ -594,7 +744,9 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
   }
+built:
   t_build = now_s() - t0 - t_seq;
+  if (verbose && gpus > 1) printf("# tables built in %u parts\n", gpus);
   if (verbose)
     printf("# prefixlength=%u\n# tied suffixes after the first sort=%llu, refinement rounds=%u\n",
            es.prefixlength, (unsigned long long) es.tied_suffixes, es.refine_rounds);
@@ -611,14 +763,17 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
     rc = 0;
     goto done;
   }
-  if ((want & GTAMD_WANT_SUF) &&
-      write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", suftabuint ? 4 : 8, err, errlen) != 0) goto done;
-  if ((want & GTAMD_WANT_BCK) && write_bcktab(ctx, indexname, err, errlen) != 0) goto done;
-  if (want & GTAMD_WANT_LCP) {
-    if (write_table(ctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0) goto done;
-    if (write_table(ctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0) goto done;
+  {
+    gtamd_esa_ctx *const *tabs = ctxs != NULL ? ctxs : &ctx;
+    if ((want & GTAMD_WANT_SUF) &&
+        write_table(tabs, nctx, GTAMD_TAB_SUF, indexname, ".suf", suftabuint ? 4 : 8, err, errlen) != 0) goto done;
+    if ((want & GTAMD_WANT_BCK) && write_bcktab(ctx, indexname, err, errlen) != 0) goto done;
+    if (want & GTAMD_WANT_LCP) {
+      if (write_table(tabs, nctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0) goto done;
+      if (write_table(tabs, nctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0) goto done;
+    }
+    if ((want & GTAMD_WANT_BWT) && write_table(tabs, nctx, GTAMD_TAB_BWT, indexname, ".bwt", 1, err, errlen) != 0) goto done;
   }
-  if ((want & GTAMD_WANT_BWT) && write_table(ctx, GTAMD_TAB_BWT, indexname, ".bwt", 1, err, errlen) != 0) goto done;
   {
     char path[4096];
     snprintf(path, sizeof path, "%s.prj", indexname);
@@ -651,7 +806,11 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
   rc = 0;
 done:
   gtamd_alphabet_free(&alpha);
-  gtamd_esa_destroy(ctx);
+  if (ctxs != NULL) {
+    for (uint32_t r = 0; r < nctx; r++) gtamd_esa_destroy(ctxs[r]);
+    free(ctxs);
+  } else
+    gtamd_esa_destroy(ctx);
   gtamd_encoder_destroy(de);
   free(enc);
   return rc;
@@ -728,9 +887,9 @@ int gtamd_mergeesa(int argc, const char **argv, char *err, size_t errlen)
     snprintf(err, errlen, "%s", gtamd_esa_last_error());
     goto done;
   }
-  if (write_table(ctx, GTAMD_TAB_SUF, indexname, ".suf", 8, err, errlen) != 0 ||
-      write_table(ctx, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0 ||
-      write_table(ctx, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0)
+  if (write_table(&ctx, 1, GTAMD_TAB_SUF, indexname, ".suf", 8, err, errlen) != 0 ||
+      write_table(&ctx, 1, GTAMD_TAB_LCP, indexname, ".lcp", 1, err, errlen) != 0 ||
+      write_table(&ctx, 1, GTAMD_TAB_LLV, indexname, ".llv", 16, err, errlen) != 0)
     goto done;
   rc = 0;
 done:

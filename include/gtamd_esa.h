@@ -148,12 +148,15 @@ void gtamd_esa_destroy(gtamd_esa_ctx *ctx);
    mechanism (src/match/sfx-partssuf.c:172-347) used here to shard over GPUs.
    Default 0 of 1.  Every part holds the whole packed sequence and builds the
    slice [table_offset, table_offset + table_entries) of each table.  The work
-   of a part falls with the number of parts: it makes the sort keys of ITS 1/R
-   tile of the text only and sends each (key, position) pair to the part that
-   owns the key range; the rank table of the prefix-doubling rounds is cut by
-   text position (part t holds the ranks of the suffixes starting in tile t),
-   so a round asks the tile owners for ranks and sends them the new ones -- all
-   through the callbacks of gtamd_esa_set_comm.  A part build addresses up to
+   of a part falls with the number of parts: a DNA part takes the suffixes of its
+   key range from the text by a scan (two cheap passes over the packed text) and
+   sorts them where they are -- no pair travels; a part over a larger alphabet
+   makes the sort keys of ITS 1/R tile of the text and sends each (key, position)
+   pair to the part that owns the key range.  The rank table of the
+   prefix-doubling rounds is cut by text position (part t holds the ranks of the
+   suffixes starting in tile t), so a round sends the tile owners the new ranks
+   and this round's questions in one message and gets the answers in another --
+   all through the callbacks of gtamd_esa_set_comm.  A part build addresses up to
    2^40 positions (a single build: 2^32 - 4096); one slice must stay below 2^32
    entries.  The statistics of a part cover its slice: the caller adds
    lcptabsum / largelcpvalues, takes the max of maxbranchdepth, and `longest`
@@ -182,6 +185,34 @@ typedef int (*gtamd_alltoallv_fn)(void *user, const void *send,
                                   uint32_t elem_bytes, void *stream);
 int gtamd_esa_set_comm(gtamd_esa_ctx *ctx, gtamd_allgather_fn allgather,
                        gtamd_alltoallv_fn alltoallv, void *user);
+
+/* ---- transports that ship with the library ----------------------------- */
+/* (genometools_amd/csrc/esa_comm.hip)  A C caller needs no Python and no torch
+   for a build on several GPUs:
+
+   THREADS -- one process, one host thread per part, as the reference runs its
+   own parallel sorting (gt -j N, src/core/thread_api.h): create the transport
+   once, one context per part on the device of your choice (the same device for
+   all is fine), gtamd_comm_attach(comm, part, ctx, device) instead of
+   gtamd_esa_set_part / gtamd_esa_set_comm, then gtamd_esa_run on every context
+   from its own thread.  The alltoallv is a set of peer copies each part pulls
+   onto its stream (hipMemcpyPeerAsync).  A thread that leaves early calls
+   gtamd_comm_abort so that the others do not wait for it.
+
+   RCCL -- one process per part: rank 0 makes the id (gtamd_comm_rccl_unique_id)
+   and hands it to the others by whatever means the launcher has; every rank
+   creates its communicator and attaches its context.  alltoallv = grouped
+   ncclSend / ncclRecv on the engine's stream.  librccl is loaded when this
+   transport is asked for, not before. */
+typedef struct gtamd_comm gtamd_comm;
+gtamd_comm *gtamd_comm_threads_create(uint32_t numparts);
+int gtamd_comm_rccl_unique_id(uint8_t id[128]);
+gtamd_comm *gtamd_comm_rccl_create(const uint8_t id[128], uint32_t rank,
+                                   uint32_t numparts, int device);
+int gtamd_comm_attach(gtamd_comm *comm, uint32_t part, gtamd_esa_ctx *ctx,
+                      int device);
+void gtamd_comm_abort(gtamd_comm *comm);
+void gtamd_comm_destroy(gtamd_comm *comm);
 
 /* Read mode of the sequence (the `readmode` argument of
    gt_Sfxiterator_new_withadditionalvalues, src/match/sfx-suffixer.h:48-60;

@@ -501,3 +501,62 @@ def test_packedindex_context_maps_through_the_tools(cli, tmp_path):
     assert not os.path.exists(idx + ".3cxm")
     r = subprocess.run([cli, "packedindex", "mkctxmap", "-ctxilog", "40", idx], capture_output=True, text=True)
     assert r.returncode == 1 and "gt packedindex mkctxmap: error:" in r.stderr
+
+
+@pytest.mark.parametrize("name,gpus", [("Atinsert.fna", 3), ("Duplicate.fna", 2), ("RandomN.fna", 5),
+                                       ("Verysmall.fna", 4), ("sw100K1.fsa", 3)])
+def test_cli_gpus_writes_reference_files(cli, name, gpus, tmp_path):
+    """-gpus R: the tables built in R lexicographic ranges, one engine context and
+    one host thread per range, over the transport the library ships
+    (gtamd_comm_threads_create: peer copies; here all parts on the one GPU) -- C all
+    the way, no Python in the build -- and streamed to the files in part order:
+    the reference's files, .prj included"""
+    e = GOLDEN[name]
+    idx = str(tmp_path / "idx")
+    subprocess.run([cli, "-" + e["alphabet"], "-suf", "-lcp", "-bwt", "-gpus", str(gpus), "-db",
+                    os.path.basename(ou.fixture_path(name)), "-indexname", idx],
+                   check=True, cwd=os.path.dirname(ou.fixture_path(name)))
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        with open(idx + "." + ext, "rb") as f:
+            raw = f.read()
+        assert len(raw) == e["tables"][ext]["bytes"], ext
+        assert hashlib.md5(raw).hexdigest() == e["tables"][ext]["md5"], ext
+    with open(idx + ".prj") as f:
+        assert f.read() == e["prj"]
+
+
+def test_cli_gpus_40mbp_equals_reference_tables(cli, tmp_path):
+    """a 40 Mbp human-like sequence through the C tool in three parts (range filter +
+    MSD sort per part, pairs, rank exchange over the thread transport) against the
+    tables the reference's own engine wrote for it (tests/golden/golden_large.json)"""
+    import json
+    from genometools_amd import synth
+    with open(os.path.join(ou.GOLDEN_DIR, "golden_large.json")) as f:
+        e = json.load(f)["humanlike_40m"]
+    fasta = str(tmp_path / "h40.fna")
+    synth.write_fasta(fasta, synth.generate(getattr(synth, e["model"]), e["seed"], e["n"]))
+    idx = str(tmp_path / "idx")
+    out = subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-gpus", "3", "-v", "-db", fasta,
+                          "-indexname", idx], check=True, capture_output=True, text=True).stdout
+    assert "tables built in 3 parts" in out
+    for ext in ("suf", "lcp", "llv", "bwt"):
+        h = hashlib.md5()
+        with open(idx + "." + ext, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 22), b""):
+                h.update(blk)
+        assert os.path.getsize(idx + "." + ext) == e["tables"][ext]["bytes"], ext
+        assert h.hexdigest() == e["tables"][ext]["md5"], ext
+    prj = dict(l.split("=") for l in e["prj"].splitlines())
+    got = dict(l.split("=") for l in open(idx + ".prj").read().splitlines())
+    for k in ("totallength", "numberofallsortedsuffixes", "longest", "prefixlength", "largelcpvalues",
+              "averagelcp", "maxbranchdepth", "specialcharacters", "numofsequences"):
+        assert got[k] == prj[k], k
+
+
+def test_cli_gpus_refuses_what_needs_the_whole_table(cli, tmp_path):
+    r = subprocess.run([cli, "-dna", "-suf", "-bck", "-gpus", "2", "-db", ou.fixture_path("Atinsert.fna"),
+                        "-indexname", str(tmp_path / "x")], capture_output=True, text=True)
+    assert r.returncode == 1 and "-gpus" in r.stderr and "-bck" in r.stderr
+    r = subprocess.run([cli, "-dna", "-suf", "-gpus", "0", "-db", ou.fixture_path("Atinsert.fna"),
+                        "-indexname", str(tmp_path / "x")], capture_output=True, text=True)
+    assert r.returncode == 1 and "1 to 128" in r.stderr

@@ -135,3 +135,44 @@ def test_engine_across_processes(gpu, wide):
     assert sorted(o[:2] for o in out) == [(r, "ok") for r in range(world)], out
     assert sum(o[2] for o in out) == 350001
     assert sum(o[3] for o in out) > 0          # ranks travelled
+
+
+_RCCL_WORLD1 = r"""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+sys.path.insert(0, %(root)r)
+os.environ["GTAMD_FORCE_WIDE"] = "1"      # the exchange machinery of a part build, one part
+import oracle_util as ou
+from genometools_amd import _lib, esa, synth
+lib = _lib.load()
+ident = (ctypes.c_uint8 * 128)()
+_lib.check(lib.gtamd_comm_rccl_unique_id(ident))
+comm = lib.gtamd_comm_rccl_create(ident, 0, 1, 0)
+assert comm, lib.gtamd_esa_last_error()
+enc = synth.generate(synth.MODEL_REPEAT_HEAVY, 3, 200000)
+ora = ou.esa(enc, 4)
+with esa.EsaEngine(enc.size, 4) as eng:
+    eng.set_sequence(enc)
+    _lib.check(lib.gtamd_comm_attach(comm, 0, eng._ctx, 0))
+    eng.run()
+    res = eng.result()
+    assert eng.timing()["comm_calls"] > 0
+for tab in ("suf", "lcp", "llv", "bwt"):
+    assert np.array_equal(getattr(res, tab), ora[tab]), tab
+lib.gtamd_comm_destroy(comm)
+print("rccl world 1 ok")
+"""
+
+
+def test_library_rccl_transport_world_1(gpu):
+    """the RCCL transport that ships with the library (genometools_amd/csrc/esa_comm.hip:
+    librccl bound at run time, ncclAllGather / grouped ncclSend-ncclRecv) as a plumbing
+    test with one rank -- RCCL refuses two ranks on one device, and the box has one.
+    In a process of its own: a fault inside librccl must not take the test run along."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_WORLD1 % {"root": root}], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "rccl world 1 ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

@@ -5,10 +5,11 @@ oracle's comparison sort cannot run at these sizes):
   checker (permutation + sortedness, oracle/esa_oracle.c ora_check_suffix_array)
   and LCP/BWT equal the tables the oracle derives from that suffix array
   (Kasai).  Together that is bit-exactness of all three tables.
-* configs[2], 3 Gbp human-like DNA: permutation checksum over the whole suffix
-  array on the device, plus order and LCP of thousands of sampled neighbour
-  pairs re-derived on the CPU from the encoded sequence, plus the tail layout
-  (specials in text order, then n).
+* configs[2], 3 Gbp human-like DNA (the bench workload): the suffix table
+  EXACTLY -- permutation + every neighbour pair ordered by (first symbol, rank of
+  the successor), the reference's lightweight check restated on the device
+  (tests/device_check.py) --, .bwt for every entry, .lcp on 2 * 10^7 samples,
+  every .llv entry, the tail layout (specials in text order, then n).
 * configs[4], 10^9 protein residues: the same properties on the 5-bit path.
 * the position range of configs[3] (n >= 2^32; the 24 Gbp input itself needs
   the 8 GPUs it is defined on): 2^32 + 4 M bases of uniform DNA built in two
@@ -59,7 +60,16 @@ def test_config1_256mbp_uniform_bit_exact(gpu):
     assert np.array_equal(enc[:1 << 20], synth.generate(synth.MODEL_UNIFORM_DNA, 42, n, 0, 1 << 20))
 
 
-def test_config2_3gbp_humanlike_properties(gpu):
+def test_config2_3gbp_humanlike_exact(gpu):
+    """BASELINE.json configs[2], the bench workload, with the switches the bench
+    runs with (none).  The suffix table is checked EXACTLY, on the device
+    (tests/device_check.py: the reference's lightweight check restated -- a
+    permutation whose every neighbour pair is ordered by (first symbol, rank of the
+    successor) is the sorted table); .bwt for every entry; .lcp on 2 * 10^7 sampled
+    entries against the symbols; every one of the 117 M .llv entries (position,
+    mismatch right behind its value, agreement at its last and at 16 random
+    offsets); the statistics of .prj from the tables."""
+    import device_check as dc
     n = 3 * 1000 * 1000 * 1000
     N = n + 1
     buf = _device_sequence(synth.MODEL_HUMANLIKE_DNA, 43, n)
@@ -67,55 +77,40 @@ def test_config2_3gbp_humanlike_properties(gpu):
         eng.set_sequence_device(buf.data_ptr(), n)
         eng.run()
         st = eng.stats()
-        # permutation: sum and sum of squares (mod 2^64) of the whole table
-        sa = torch.as_tensor(_Wrap(eng.device_pointer(esa.TAB_SUF), N, "<i8"), device="cuda:0")
-        assert int(sa.sum().item()) == N * (N - 1) // 2
-        sq = int((sa * sa).sum().item()) % (1 << 64)
-        assert sq == ((N - 1) * N * (2 * N - 1) // 6) % (1 << 64)
+        assert st["msd_big_entries"] > 0 and st["pair_suffixes"] > 3e8 and st["refine_rounds"] >= 9
+        sa = dc.as_tensor(eng.device_pointer(esa.TAB_SUF), N, "<i8")
+        lcp = dc.as_tensor(eng.device_pointer(esa.TAB_LCP), N, "|u1")
+        bwt = dc.as_tensor(eng.device_pointer(esa.TAB_BWT), N, "|u1")
+        ok, msg = dc.check_suffix_array_exact(sa, buf)
+        assert ok, msg
         assert int(sa[st["longest"]].item()) == 0
-        del sa
-        enc = buf.cpu().numpy()
-        del buf
-        torch.cuda.empty_cache()
-        specials = int(np.count_nonzero(enc >= 254))
-        # tail: every suffix that starts with a special, in text order, then n
-        tail = eng.table(esa.TAB_SUF, N - 1 - 2000, 2001)
-        assert tail[-1] == n
-        assert np.all(enc[tail[:-1].astype(np.int64)] >= 254)
-        assert np.all(np.diff(tail[:-1].astype(np.int64)) > 0)
-        first_special = eng.table(esa.TAB_SUF, N - 1 - specials, 1)[0]
-        assert enc[int(first_special)] >= 254
-        before_tail = eng.table(esa.TAB_SUF, N - 2 - specials, 1)[0]
-        assert enc[int(before_tail)] < 254
-        # sampled neighbour pairs: order, LCP byte, BWT byte
-        rng = np.random.default_rng(2026)
-        idx = np.sort(rng.integers(1, N - specials - 1, 4000))
-        bad = 0
-        for i in idx:
-            i = int(i)
-            p, q = (int(x) for x in eng.table(esa.TAB_SUF, i - 1, 2))
-            lcpb = int(eng.table(esa.TAB_LCP, i, 1)[0])
-            bwtb = int(eng.table(esa.TAB_BWT, i, 1)[0])
-            l = 0
-            while p + l < n and q + l < n and enc[p + l] < 254 and enc[p + l] == enc[q + l]:
-                l += 1
-            ka = 256 + p + l if (p + l >= n or enc[p + l] >= 254) else int(enc[p + l])
-            kb = 256 + q + l if (q + l >= n or enc[q + l] >= 254) else int(enc[q + l])
-            ok = ka < kb and lcpb == min(l, 255) and bwtb == (254 if q == 0 else int(enc[q - 1]))
-            bad += not ok
-        assert bad == 0
-        # every .llv entry: index ascending, value >= 255, lcp byte is 255
-        llv = eng.table(esa.TAB_LLV)
-        assert len(llv) == st["largelcpvalues"] > 0
-        assert np.all(np.diff(llv[:, 0].astype(np.int64)) > 0)
-        assert int(llv[:, 1].min()) >= 255 and int(llv[:, 1].max()) == st["maxbranchdepth"]
-        some = llv[rng.integers(0, len(llv), 200)]
-        for i, v in some:
-            assert int(eng.table(esa.TAB_LCP, int(i), 1)[0]) == 255
-            p, q = (int(x) for x in eng.table(esa.TAB_SUF, int(i) - 1, 2))
-            v = int(v)
-            assert np.array_equal(enc[p:p + v], enc[q:q + v]) and np.all(enc[p:p + v] < 254)
-            assert p + v >= n or q + v >= n or enc[p + v] >= 254 or enc[q + v] >= 254 or enc[p + v] != enc[q + v]
+        ok, msg = dc.check_bwt_exact(sa, buf, bwt)
+        assert ok, msg
+        # the special tail: every suffix that starts with a special, in text order, then n
+        specials = int((buf >= 254).sum().item())
+        tail = sa[N - 1 - specials:]
+        assert int(tail[-1].item()) == n
+        assert bool((buf[tail[:-1]] >= 254).all()) and bool((tail[1:] > tail[:-1]).all())
+        assert int(buf[sa[N - 2 - specials]].item()) < 254
+        assert bool((lcp[N - specials:] == 0).all())
+        # .llv: all of it
+        nl = eng.entries(esa.TAB_LLV)
+        assert nl == st["largelcpvalues"] > 10 ** 8
+        llv = dc.as_tensor(eng.device_pointer(esa.TAB_LLV), 2 * nl, "<i8").view(-1, 2)
+        llv_idx, llv_val = llv[:, 0].contiguous(), llv[:, 1].contiguous()
+        assert dc.count_lcp_overflows(lcp) == nl
+        assert int(llv_val.max().item()) == st["maxbranchdepth"]
+        ok, msg = dc.check_llv_all(sa, buf, lcp, llv_idx, llv_val)
+        assert ok, msg
+        # .lcp on samples (2 * 10^7 entries, a tenth of them where the LCP is large)
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(2026)
+        idx = torch.randint(1, N - specials, (18_000_000,), device="cuda:0", generator=g)
+        pick = llv_idx[torch.randint(0, nl, (2_000_000,), device="cuda:0", generator=g)]
+        for part in (idx, pick, torch.clamp(pick + 1, max=N - 1)):
+            for a in range(0, part.numel(), 1 << 22):
+                ok, msg = dc.check_lcp_samples(sa, buf, lcp, llv_idx, llv_val, part[a:a + (1 << 22)])
+                assert ok, msg
 
 
 def _sampled_neighbours(eng, enc_of, n, lo, hi, rng, samples, index_offset=0, wildcard_ok=True):

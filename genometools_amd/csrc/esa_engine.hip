@@ -1501,7 +1501,7 @@ __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     u32 m = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const u64 w = (u64) p[q][k] >> wb;
+      const u32 w = (u32) (p[q][k] >> wb);      // (2^40 positions, windows of >= 2^16)
       if (i0 + k < NL) m |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
     }
     mask[q] = m;
@@ -1820,6 +1820,7 @@ __global__ __launch_bounds__(256) void k_pair_emit(
 // here, the tables get their entries from k_pair_apply, which walks the pairs
 // in TABLE order (in text order its five accesses per pair were five random
 // lines: 18 ms for 170 M pairs)
+constexpr int PR_LINE = 16;     // records a thread loads at once (a chunk is a multiple of it)
 template <int BITS, typename P>
 __global__ __launch_bounds__(256) void k_pair_resolve(
     Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 nrec, u64 np,
@@ -1842,11 +1843,49 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
     u64 ra[RING] = {0, 0, 0, 0}, rb[RING] = {0, 0, 0, 0}, rl[RING] = {0, 0, 0, 0};
     bool rf[RING] = {true, true, true, true};
     int filled = 0;
-    for (int e = 0; e < chunk; e++) {
-      const u64 s = c * chunk + e;
-      if (s >= nrec) break;
-      const u64 a = pkey[s];
-      const u64 iv = pval[s];
+    // A thread's records are consecutive in the list: it takes PR_LINE of them at a
+    // time as whole lines (the keys of one step are one 64-byte line, the values
+    // two).  Loaded one record per step, every line was touched 16 times over the
+    // life of a chunk -- long, when a comparison comes between -- and the 3 million
+    // chunks' lines did not stay in the L2 that long: the kernel fetched 62 GB for
+    // its 4.8 GB of records (PMC) and was bound by exactly that.
+    for (int e0 = 0; e0 < chunk; e0 += PR_LINE) {
+      const u64 s0 = c * chunk + e0;
+      if (s0 >= nrec) break;
+      P ak[PR_LINE];
+      u64 ivk[PR_LINE];
+      if (s0 + PR_LINE <= nrec) {
+        if (sizeof(P) == 4) {
+#pragma unroll
+          for (int q = 0; q < PR_LINE / 4; q++) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(pkey + s0 + 4 * q);
+            ak[4 * q] = (P) v.x; ak[4 * q + 1] = (P) v.y; ak[4 * q + 2] = (P) v.z; ak[4 * q + 3] = (P) v.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < PR_LINE / 2; q++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pkey + s0 + 2 * q);
+            ak[2 * q] = (P) v.x; ak[2 * q + 1] = (P) v.y;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < PR_LINE / 2; q++) {
+          const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(pval + s0 + 2 * q);
+          ivk[2 * q] = v.x; ivk[2 * q + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PR_LINE; q++) {
+          ak[q] = s0 + q < nrec ? pkey[s0 + q] : (P) 0;
+          ivk[q] = s0 + q < nrec ? pval[s0 + q] : 0ull;
+        }
+      }
+#pragma unroll
+    for (int e = 0; e < PR_LINE; e++) {
+      const u64 s = s0 + e;
+      if (s >= nrec || e0 + e >= chunk) continue;
+      const u64 a = ak[e];
+      const u64 iv = ivk[e];
       const u64 j = iv >> 32;
       const u64 b = sizeof(P) == 4 ? (iv & 0xFFFFFFFFull) : (u64) sa[(iv & 0xFFFFFFFFull) + 1];
       u64 l = 0;
@@ -1892,6 +1931,7 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
         nlarge += lv >= GTAMD_LCPOVERFLOW;
         mx = lv > mx ? lv : mx;
       }
+    }
     }
   }
 #pragma unroll
@@ -3388,9 +3428,11 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u6
     // bin of the counting pass is left to; tests)
     const char *fr = getenv("GTAMD_MSD_RADIX");
     HIP_TRY(hipEventRecord(c->ev_scatter[0], st));
+    u32 bin_limit = MD_BIN_LIMIT_DEFAULT;
+    if (const char *e = getenv("GTAMD_MSD_BIN_LIMIT")) { const long v = atol(e); if (v >= 2 && v <= 4096) bin_limit = (u32) v; }
     k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
-                                                        fr != nullptr && fr[0] == '1', w.crowdlist,
-                                                        w.counters, o);
+                                                        fr != nullptr && fr[0] == '1', bin_limit,
+                                                        w.crowdlist, w.counters, o);
     HIP_TRY(hipEventRecord(c->ev_scatter[1], st));
     HIP_TRY(hipGetLastError());
     k_msd_local_radix<<<ntD < 2048u ? ntD : 2048u, MS_THREADS, 0, st>>>(kf, pf, w.dtiles,
@@ -4044,6 +4086,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       // 32 / 128 / 512 pairs per thread: 4.7 / 4.7 / 5.6 / 11.5 ms)
       int pair_chunk = (int) (nrec >> 20 < 16 ? 16 : (nrec >> 20 > 128 ? 128 : nrec >> 20));
       if (const char *e = getenv("GTAMD_PAIR_CHUNK")) { const int v = atoi(e); if (v >= 4 && v <= 1024) pair_chunk = v; }
+      pair_chunk = (pair_chunk + PR_LINE - 1) / PR_LINE * PR_LINE;    // (whole lines of records per thread)
       k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256)), 256, 0, st>>>(
           c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk);
       HIP_TRY(hipGetLastError());

@@ -1155,7 +1155,7 @@ static_assert(MD_RADIX == MS_THREADS, "one thread per digit in the scan");
 // (three or four 9-bit digits, ballot-ranked like the scatter kernels).
 constexpr int MD_BINBITS = 12;
 constexpr int MD_BINS = 1 << MD_BINBITS;
-constexpr u32 MD_BIN_LIMIT = 128;
+constexpr u32 MD_BIN_LIMIT_DEFAULT = 128;
 
 __device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
   return (s_binw[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu;
@@ -1163,7 +1163,7 @@ __device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
 
 __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
-    u32 ntiles, int cb, int force_radix, u32 *__restrict__ crowdlist,
+    u32 ntiles, int cb, int force_radix, u32 bin_limit, u32 *__restrict__ crowdlist,
     u32 *__restrict__ counters, MsdOut o) {
   __shared__ u32 s_key[MS_TILE];
   __shared__ u32 s_val[MS_TILE];
@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
         reinterpret_cast<uint4 *>(s_binw)[tid] =
             make_uint4(wd[0] + pre, wd[1] + pre, wd[2] + pre, wd[3] + pre);
         if (tid == 0) s_binw[MD_BINS / 2] = cnt;           // end of the last bin
-        if (mx > MD_BIN_LIMIT || force_radix) s_binw[MD_BINS / 2 + 1] = 1u;
+        if (mx > bin_limit || force_radix) s_binw[MD_BINS / 2 + 1] = 1u;
       }
       lds_barrier();
       if (s_binw[MD_BINS / 2 + 1] != 0) {     // (the same for every thread)

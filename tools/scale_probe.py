@@ -42,11 +42,12 @@ def main():
         eng.run(a.want)
         dt = time.time() - t0
         tm, st = eng.timing(), eng.stats()
-        print(("[%s=%s] " % (a.ab, os.environ.get(a.ab)) if a.ab else "") + "run%d wall %.3fs dev %.1f ms -> %.3f Gbp/s | keygen %.1f sort %.1f (scatter %.1f/%d) fin %.1f refine %.1f fix %.1f | tied %d (pairs %d) rounds %d large %d maxlcp %d | device memory %.1f GB" % (
+        print(("[%s=%s] " % (a.ab, os.environ.get(a.ab)) if a.ab else "") + "run%d wall %.3fs dev %.1f ms -> %.3f Gbp/s | keygen %.1f sort %.1f (scatter %.1f/%d) fin %.1f refine %.1f fix %.1f | tied %d (pairs %d) rounds %d large %d maxlcp %d | msd big %d crowded %d | device memory %.1f GB" % (
             r, dt, tm["total_ms"], n / tm["total_ms"] / 1e6, tm["keygen_ms"], tm["sort_ms"],
             tm["scatter_ms"], tm["scatter_launches"], tm["finalize_ms"], tm["refine_ms"],
             tm["tie_fix_ms"], st["tied_suffixes"], st["pair_suffixes"], st["refine_rounds"],
-            st["largelcpvalues"], st["maxbranchdepth"], st["device_bytes"] / 1e9), flush=True)
+            st["largelcpvalues"], st["maxbranchdepth"], st["msd_big_entries"], st["msd_crowded_entries"],
+            st["device_bytes"] / 1e9), flush=True)
     if a.check:
         N = n + 1
         # permutation checksum on the device

@@ -149,6 +149,12 @@ template <int BITS> struct Pay {
 template <int BITS> struct Key {
   using L = KeyLayout<BITS>;
   static constexpr int SYMS = L::KEY_SYMS;
+  // symbols two suffixes share FOR SURE when the first sort leaves them tied: all
+  // of the key's; eight for the 5-bit alphabets, whose MSD sort (esa_msd.h, FMT 1)
+  // looks at eight symbols and the class of the ninth.  Everything behind the sort
+  // starts from this bound (a smaller one is never wrong: comparisons start
+  // earlier, the doubling rounds at a smaller offset).
+  static constexpr int KNOWN = BITS == 2 ? SYMS : 8;
   static constexpr int PFX_BITS = SYMS * BITS;
   static constexpr int LOW_BITS = 64 - PFX_BITS;          // below the prefix
   static constexpr int DSHIFT = LOW_BITS - L::DCODE_BITS; // dcode sits right
@@ -1894,7 +1900,7 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
       for (int k = 0; k < RING; k++) {
         if (k < filled && !known) {
           const u64 d = a - ra[k];
-          if (b >= rb[k] && b - rb[k] == d && rl[k] >= (u64) Key<BITS>::SYMS + d) {
+          if (b >= rb[k] && b - rb[k] == d && rl[k] >= (u64) Key<BITS>::KNOWN + d) {
             // a record on the same diagonal: the same first difference decides,
             // d symbols nearer -- nothing to read
             l = rl[k] - d;
@@ -1904,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
         }
       }
       if (!known) {
-        l = lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::SYMS);
+        l = lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::KNOWN);
         // the first difference decides: a special is larger than every letter,
         // two specials compare by position
         const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
@@ -2415,7 +2421,7 @@ constexpr u64 DIRECT_MAX_LCP = 250;   // below LCPOVERFLOW: never an .llv entry
 
 template <int BITS>
 __device__ bool suffix_less(const Text &t, u64 p, u64 q, bool *deep) {
-  const u64 l = lcp_extend<BITS>(t, p, q, (u64) Key<BITS>::SYMS, DIRECT_MAX_LCP);
+  const u64 l = lcp_extend<BITS>(t, p, q, (u64) Key<BITS>::KNOWN, DIRECT_MAX_LCP);
   if (l >= DIRECT_MAX_LCP) { *deep = true; return p < q; }
   const bool sp = is_special(t, p + l), sq = is_special(t, q + l);
   if (sp || sq) return (sp && sq) ? p < q : sq;   // a special is the larger one
@@ -2456,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_direct_ties(
     if (bwt != nullptr) bwt[i] = Pay<BITS>::to_bwt(Pay<BITS>::before(t, p));
     if (p == 0) stats->longest = index_offset + i;
     if (k > 0 && want_lcp) {
-      const u32 l = (u32) lcp_extend<BITS>(t, pos[k - 1], p, (u64) Key<BITS>::SYMS);
+      const u32 l = (u32) lcp_extend<BITS>(t, pos[k - 1], p, (u64) Key<BITS>::KNOWN);
       if (lcp != nullptr) lcp[i] = (u8) l;
       atomicAdd(&stats->dsum, (unsigned long long) l);
       atomicMax(&stats->dmax, l);
@@ -2555,7 +2561,7 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     const u64 p = pkey[s];
     const u64 i = pval[s];
     const u64 q = sa[i - 1];
-    u64 from = (u64) Key<BITS>::SYMS;
+    u64 from = (u64) Key<BITS>::KNOWN;
     if (e > 0 && l > from + (p - prevp)) from = l - (p - prevp);
     l = lcp_extend<BITS>(t, q, p, from);
     prevp = p;
@@ -3299,6 +3305,7 @@ struct MsdPartSrc {
   const unsigned long long *prev_key;   // device: largest key of the ranges below
   int has_prev;
 };
+template <int FMT>
 static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u64 density_n,
                          const MsdPartSrc *src, u32 **sa_out,
                          u64 **fkey, u32 **fval, u64 *local_entries) {
@@ -3320,6 +3327,8 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u6
   // ---- level A
   if (src != nullptr)
     k_msd_hist_a_keys<<<ntA, MS_THREADS, 0, st>>>(src->ck, N, w.hist);
+  else if (FMT == 1)
+    k_msd_hist_a5<<<ntA, MS_THREADS, 0, st>>>(c->text, N, w.hist);
   else
     k_msd_hist_a<<<ntA, MS_THREADS, 0, st>>>(c->text, N, w.hist);
   HIP_TRY(hipGetLastError());
@@ -3327,10 +3336,13 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u6
   k_msd_starts_a<<<1, 256, 0, st>>>(w.hist, (u32) N, w.startA);
   HIP_TRY(hipGetLastError());
   if (src != nullptr)
-    k_msd_scatter_a<true><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+    k_msd_scatter_a<1><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
         c->text, N, last_valid, w.hist, ntA, src->ck, src->cp32, ka, xa, pa);
+  else if (FMT == 1)
+    k_msd_scatter_a<2><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+        c->text, N, last_valid, w.hist, ntA, nullptr, nullptr, ka, xa, pa);
   else
-    k_msd_scatter_a<false><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
+    k_msd_scatter_a<0><<<((ntA + 7u) >> 3) * 8u, MS_THREADS, 0, st>>>(
         c->text, N, last_valid, w.hist, ntA, nullptr, nullptr, ka, xa, pa);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev[1], st));
@@ -3430,35 +3442,38 @@ static int msd_sort_emit(gtamd_esa_ctx *c, u32 want, u32 prefixlength, u64 N, u6
     HIP_TRY(hipEventRecord(c->ev_scatter[0], st));
     u32 bin_limit = MD_BIN_LIMIT_DEFAULT;
     if (const char *e = getenv("GTAMD_MSD_BIN_LIMIT")) { const long v = atol(e); if (v >= 2 && v <= 4096) bin_limit = (u32) v; }
-    k_msd_local<<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
+    k_msd_local<FMT><<<stride_grid(ntD), MS_THREADS, 0, st>>>(kf, pf, w.dtiles, ntD, cb,
                                                         fr != nullptr && fr[0] == '1', bin_limit,
                                                         w.crowdlist, w.counters, o);
     HIP_TRY(hipEventRecord(c->ev_scatter[1], st));
     HIP_TRY(hipGetLastError());
-    k_msd_local_radix<<<ntD < 2048u ? ntD : 2048u, MS_THREADS, 0, st>>>(kf, pf, w.dtiles,
+    k_msd_local_radix<FMT><<<ntD < 2048u ? ntD : 2048u, MS_THREADS, 0, st>>>(kf, pf, w.dtiles,
                                                                         w.crowdlist, w.counters,
                                                                         cb, o);
     HIP_TRY(hipGetLastError());
   }
   if (nbig > 0) {
-    k_msd_big<<<nbig < 2048u ? nbig : 2048u, MS_THREADS, 0, st>>>(kf, pf, ko, po, w.dtiles,
+    k_msd_big<FMT><<<nbig < 2048u ? nbig : 2048u, MS_THREADS, 0, st>>>(kf, pf, ko, po, w.dtiles,
                                                                 w.biglist, w.counters, cb, o);
     HIP_TRY(hipGetLastError());
   }
   for (u32 i = 0; i < ngiant; i++) {
-    // the 29 bits of K2 above the payload, least significant digit first
+    // the bits of K2 above the payload (29, or the code's 24), least significant digit first
     const MdTile g = giants[i];
     const u64 cnt = g.end - g.begin;
-    const int shifts[4] = {3, 11, 19, 27}, widths[4] = {8, 8, 8, 5};
+    // (an even number of passes: the run ends where it began, which is where
+    // k_msd_emit_run reads it)
+    const int shifts[4] = {FMT == 1 ? 8 : 3, FMT == 1 ? 14 : 11, FMT == 1 ? 20 : 19, FMT == 1 ? 26 : 27};
+    const int widths[4] = {FMT == 1 ? 6 : 8, FMT == 1 ? 6 : 8, FMT == 1 ? 6 : 8, FMT == 1 ? 6 : 5};
     int nev = 0;
     TRY(radix_sort_pairs<u32, u32>(kf + g.begin, pf + g.begin, ko + g.begin, po + g.begin, cnt,
                                    shifts, widths, 4, c->rws.as<u32>(), st, nullptr, &nev));
-    k_msd_emit_run<<<(u32) div_up(cnt, MS_TILE), MS_THREADS, 0, st>>>(kf, pf, giant_t[i], g.begin,
+    k_msd_emit_run<FMT><<<(u32) div_up(cnt, MS_TILE), MS_THREADS, 0, st>>>(kf, pf, giant_t[i], g.begin,
                                                                      (u32) cnt, g.s16, o);
     HIP_TRY(hipGetLastError());
   }
   if (ntD > 0) {
-    k_msd_seams<<<(ntD + 255) / 256, 256, 0, st>>>(w.dtiles, ntD, src != nullptr ? src->prev_key : nullptr,
+    k_msd_seams<FMT><<<(ntD + 255) / 256, 256, 0, st>>>(w.dtiles, ntD, src != nullptr ? src->prev_key : nullptr,
                                                    src != nullptr ? src->has_prev : 0, o);
     HIP_TRY(hipGetLastError());
   }
@@ -3522,7 +3537,9 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   bool msd = false;
   u32 *msd_sa = nullptr, *msd_fval = nullptr;
   u64 *msd_fkey = nullptr, msd_local = 0;
-  if (!dist && BITS == 2 && !WIDE && !(want & GTAMD_WANT_BCK) && N >= 64) {
+  // (the 5-bit alphabets: by the 40-bit code of nine symbols, esa_msd.h FMT 1; the
+  // statistics mask with prefixlength, which the code must be able to tell: <= 9)
+  if (!dist && !WIDE && !(want & GTAMD_WANT_BCK) && N >= 64 && (BITS == 2 || (prefixlength <= 9 && c->sigma <= 20))) {
     const char *e = getenv("GTAMD_MSD");
     msd = e != nullptr ? e[0] == '1' : N >= (1ull << 25);
   }
@@ -3543,7 +3560,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     HIP_TRY(hipEventRecord(c->ev[0], st));
     const char *fz = getenv("GTAMD_FUSED_PASS0");
     if (msd) {
-      TRY(msd_sort_emit(c, want, prefixlength, N, N, nullptr, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
+      TRY(msd_sort_emit<BITS == 5 ? 1 : 0>(c, want, prefixlength, N, N, nullptr, &msd_sa, &msd_fkey, &msd_fval,
+                                           &msd_local));
       HIP_TRY(hipEventRecord(c->ev_emitted, st));   // (what the joins below wait for)
     } else if (BITS == 2 && !(fz != nullptr && fz[0] == '0')) {
       const u32 ntiles = (u32) div_up(N, KP_TILE);
@@ -3652,7 +3670,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       src.index_offset = index_offset;
       src.prev_key = acc + 3;
       src.has_prev = has_prev;
-      TRY(msd_sort_emit(c, want, prefixlength, NL, N, &src, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
+      TRY(msd_sort_emit<0>(c, want, prefixlength, NL, N, &src, &msd_sa, &msd_fkey, &msd_fval, &msd_local));
       return 0;
     };
     fail = part_sort() != 0;
@@ -3899,7 +3917,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     for (u32 r = 0; r < R; r++) anyties += all[r];
   }
   u32 rounds = 0;
-  u64 m0 = 0, npairs = 0;
+  u64 m0 = 0, npairs = 0, m0_tied_all = 0;
   HIP_TRY(hipEventRecord(c->ev[4], st));
   HIP_TRY(hipEventRecord(c->ev[5], st));
   if (anyties > 0) {
@@ -4275,6 +4293,29 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           tiebits2, nwords, offw, carry, sa, uidx0, uidx, upos, ugrp);
       HIP_TRY(hipGetLastError());
     }
+    // ---- few suffixes left behind the pair path (random coincidences of three or
+    // more: a protein set, a uniform text -- 410 K of 10^9 residues): settled by
+    // direct comparison like the few ties of a small input; no rank table (its
+    // filter alone walks the whole suffix array: 2 ms at 10^9), no round
+    m0_tied_all = m0;                        // (what the statistics report)
+    if (!dist && m0 > 0 && m0 <= (NL / 512 > 4096 ? NL / 512 : 4096)) {
+      TRY(launch_emission());
+      HIP_TRY(hipStreamWaitEvent(st, c->ev_emitted, 0));
+      HIP_TRY(hipMemsetAsync(&c->d_stats->dfallback, 0, 4, st));
+      k_direct_ties<BITS, P><<<(u32) div_up(m0, 256), 256, 0, st>>>(
+          c->text, uidx0, ugrp, m0, sa, d_suf, d_lcp, d_bwt, want_lcp, index_offset, c->d_stats);
+      HIP_TRY(hipGetLastError());
+      TRY(fetch_stats(c));
+      if (c->h_stats->dfallback == 0) {
+        m0 = 0;
+        anyleft = 0;
+      } else {
+        // (a deep or a big group: the rounds take them all; the partial statistics
+        // of this attempt are dropped)
+        HIP_TRY(hipMemsetAsync(&c->d_stats->dsum, 0, 8, st));
+        HIP_TRY(hipMemsetAsync(&c->d_stats->dmax, 0, 4, st));
+      }
+    }
     // ---- rank table of a single build: the windows of positions the rounds can
     // touch (all of them when that is most of the text)
     int rk_wb = 0;
@@ -4323,7 +4364,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         w_list = w_sel + nww;
         HIP_TRY(hipMemsetAsync(w_need, 0, 2 * nww * 4, st));
         // offsets of the first rounds, as far as three windows reach
-        rk_h0 = (u64) K::SYMS << 9;
+        rk_h0 = (u64) K::KNOWN << 9;
         if (rk_h0 > (3ull << wb)) rk_h0 = 3ull << wb;
         if (m0 > 0) {
           k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, wb, rk_nwin,
@@ -4428,7 +4469,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       w_need = c->winbuf.as<u32>(); w_built = w_need + dw_nww; w_sel = w_built + dw_nww;
       h_need.assign(dw_nww, 0u); h_built.assign(dw_nww, 0u); h_all.assign((size_t) dw_nww * R, 0u);
       if (!fail) HIP_TRY(hipMemsetAsync(w_need, 0, 3 * dw_nww * 4, st));
-      rk_h0 = (u64) K::SYMS << 9;
+      rk_h0 = (u64) K::KNOWN << 9;
       if (rk_h0 > (3ull << rk_wb)) rk_h0 = 3ull << rk_wb;
       if (!fail && rk_windows && m0 > 0) {
         k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, rk_wb, rk_nwin,
@@ -4559,7 +4600,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     // ---- doubling rounds
     int gs[8], gw[8];
     const int gn = passes_for(nbl, gs, gw);
-    u64 m = m0, h = (u64) K::SYMS;
+    u64 m = m0, h = (u64) K::KNOWN;
     // nominal distance of the round tiles' starts: the rest of a tile is the
     // slack for the group that lies across (a group larger than the slack goes
     // through the global path, forty launches per round)
@@ -4877,7 +4918,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   c->stats.lcptabsum = want_lcp ? c->h_stats->lcpsum + c->h_stats->dsum : 0;
   c->stats.prefixlength = prefixlength;
   c->stats.refine_rounds = rounds;
-  c->stats.tied_suffixes = m0 + 2 * npairs + c->h_stats->smalldone;
+  c->stats.tied_suffixes = (m0_tied_all ? m0_tied_all : m0) + 2 * npairs + c->h_stats->smalldone;
   c->stats.pair_suffixes = 2 * npairs;
   c->stats.device_bytes = c->alloc_bytes;
   float ms = 0;

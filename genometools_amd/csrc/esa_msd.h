@@ -79,10 +79,115 @@ __device__ __forceinline__ u32 ms_xcd_tile(u32 b, u32 ntiles) {
   return (b & 7u) * per + (b >> 3);
 }
 
-// the 64-bit key (layout of Key<2>) from what levels A-C keep of it
+// ---------------------------------------------------------------------------
+// Two entry formats go through the same levels (FMT, a template parameter of the
+// kernels that look INTO the keys: level A and everything of level D):
+//
+// FMT 0, the 2-bit alphabet: the sorted part of Key<2> -- 20 symbols x 2 bit and
+//   the 5-bit dcode -- cut as 8 | 8 | 24 + dcode; X = dcode << 3 | payload (3 bits).
+// FMT 1, the 5-bit alphabets (protein): a 40-bit CODE of the suffix' first NINE
+//   symbols made for this sort: four pairs of symbols as 9-bit numbers 21 a + b
+//   (a symbol is a letter 0..19 or 20 = "behind the first special": the padding,
+//   larger than every letter and never a letter, so no dcode is needed to tell
+//   padded prefixes apart) and the 9th symbol's upper four bits (s >> 1: 0..10,
+//   monotone in s; 10 only for the padding).  Cut as 8 | 8 | 24; X = payload (5
+//   bits), K2 = low 24 code bits << 8 | X.  The 50 + 4 sorted bits of Key<5> do not
+//   fit the 32-bit word of levels C and D; 8 symbols + the class of the ninth do,
+//   and separate all but ~2 % of 10^9 residues with Swiss-Prot frequencies (eight
+//   symbols alone: 13 %).  Suffixes the sort leaves tied share MSD_KSYMS<FMT>
+//   symbols for sure: 20, or 8.
+// ---------------------------------------------------------------------------
+template <int FMT> struct MsdFmt;
+template <> struct MsdFmt<0> {
+  static constexpr int PB = 3;          // K2 bits below the sorted ones
+  static constexpr u32 KSYMS = 20;
+};
+template <> struct MsdFmt<1> {
+  static constexpr int PB = 8;
+  static constexpr u32 KSYMS = 8;
+};
+
+// what the seams keep of an entry: FMT 0 the 64-bit key (layout of Key<2>) from
+// what levels A-C keep of it; FMT 1 code << 8 | X
+template <int FMT>
 __device__ __forceinline__ u64 msd_full(u32 s16, u32 k2) {
+  if (FMT == 1) return ((u64) s16 << 32) | (u64) k2;
   return ((u64) s16 << 48) | ((u64) (k2 >> 8) << 24) | ((u64) ((k2 >> 3) & 31u) << 19) |
          (u64) (k2 & 7u);
+}
+
+// ---- FMT 1: the code of the 5-bit alphabets
+__device__ __forceinline__ u32 p5_first(u32 pair) { return (pair * 3121u) >> 16; }   // pair / 21, pair < 441
+// letters in front of the first special, as far as the code shows them: 0..8, or 9
+// for "nine or more"
+__device__ __forceinline__ u32 p5_letters(u64 code) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const u32 pr = (u32) (code >> (31 - 9 * k)) & 511u;
+    const u32 a = p5_first(pr);
+    if (a == 20u) return 2u * k;
+    if (pr - 21u * a == 20u) return 2u * k + 1u;
+  }
+  return ((u32) code & 15u) == 10u ? 8u : 9u;
+}
+// symbols two codes share (at most 8: the ninth is known by its class only)
+__device__ __forceinline__ u32 p5_common(u64 a, u64 b) {
+  const u64 x = a ^ b;
+  if ((x >> 4) == 0) return 8u;
+  const int lz = __clzll((long long) x) - 24;          // 0 .. 35: inside pair lz / 9
+  const int f = lz / 9;
+  const u32 pa = (u32) (a >> (31 - 9 * f)) & 511u, pb = (u32) (b >> (31 - 9 * f)) & 511u;
+  return 2u * (u32) f + (p5_first(pa) == p5_first(pb) ? 1u : 0u);
+}
+// code and payload of suffix p (Key<5>'s padding rule: everything from the first
+// special on counts as the largest symbol; a suffix that starts with a special
+// has the largest code)
+// (pay: the payload, and bit 5 = "the code shows a padding": fewer than nine letters)
+__device__ __forceinline__ u64 p5_code(const Text &t, u64 p, u32 &pay) {
+  pay = Pay<5>::before(t, p);
+  const u64 win = Sym<5>::window(t, p);                 // symbols p .. p+10 in the top bits
+  const u32 sp = (u32) sp_window(t, p) & 0x1FFu;
+  const int d = sp ? __ffs((int) sp) - 1 : 9;
+  if (sp) pay |= 32u;
+  u32 sym[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) sym[i] = i < d ? (u32) (win >> (59 - 5 * i)) & 31u : 20u;
+  u64 code = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) code = (code << 9) | (u64) (sym[2 * k] * 21u + sym[2 * k + 1]);
+  return (code << 4) | (u64) (sym[8] >> 1);
+}
+// the same for the suffixes p0 .. p0+7 (p0 a multiple of 8) as "keys" code << 24 |
+// X: away from specials the 16 symbols are taken from two windows and every pair
+// of neighbours is made once for the four codes it is part of
+__device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PER]) {
+  const u64 S = sp_window(t, p0);
+  if ((S & 0xFFFFull) != 0) {
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) {
+      u32 pay;
+      const u64 code = p5_code(t, p0 + (u64) g, pay);
+      key[g] = (code << 24) | (u64) pay;
+    }
+    return;
+  }
+  const u64 wa = Sym<5>::window(t, p0), wb = Sym<5>::window(t, p0 + 8);
+  u32 sym[16], pr[15];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    sym[i] = (u32) (wa >> (59 - 5 * i)) & 31u;
+    sym[8 + i] = (u32) (wb >> (59 - 5 * i)) & 31u;
+  }
+#pragma unroll
+  for (int i = 0; i < 15; i++) pr[i] = sym[i] * 21u + sym[i + 1];
+  u32 pay = Pay<5>::before(t, p0);
+#pragma unroll
+  for (int g = 0; g < KP_PER; g++) {
+    const u64 code = ((u64) pr[g] << 31) | ((u64) pr[g + 2] << 22) | ((u64) pr[g + 4] << 13) |
+                     ((u64) pr[g + 6] << 4) | (u64) (sym[g + 8] >> 1);
+    key[g] = (code << 24) | (u64) pay;
+    pay = sym[g];          // (no special among them: the symbol is its own payload code)
+  }
 }
 
 // keys of the suffixes p0 .. p0+7 (p0 a multiple of 8), bit for bit those of
@@ -188,6 +293,30 @@ __device__ __forceinline__ u32 ms_scan_excl(u32 v, u32 *lds8) {
 // ---------------------------------------------------------------------------
 // level A: keygen + partition on the first four symbols
 // ---------------------------------------------------------------------------
+// (5-bit alphabets: the same over the codes of FMT 1)
+__global__ __launch_bounds__(MS_THREADS) void k_msd_hist_a5(Text t, u64 N, u32 *__restrict__ hist) {
+  __shared__ u32 h[MS_WAVES][256];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < MS_WAVES * 256; i += MS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 p0 = (u64) blockIdx.x * MS_TILE + (u64) tid * KP_PER;
+  if (p0 < N) {
+    const int npos = N - p0 < KP_PER ? (int) (N - p0) : KP_PER;
+    u64 key[KP_PER];
+    p5_keys8(t, p0, key);
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++)
+      if (g < npos) atomicAdd(&h[w][(u32) (key[g] >> 56)], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < MS_WAVES; i++) c += h[i][tid];
+    hist[(u64) blockIdx.x * 256 + tid] = c;
+  }
+}
+
 __global__ __launch_bounds__(MS_THREADS) void k_msd_hist_a(Text t, u64 N,
                                                            u32 *__restrict__ hist) {
   __shared__ u32 h[MS_WAVES][256];
@@ -492,9 +621,11 @@ __global__ void k_msd_starts_a(const u32 *__restrict__ scanned, u32 N, u32 *__re
   if (d == 0) start[256] = N;
 }
 
-// FROMKEYS: the entries are the keys a part build has filtered from the text (ck,
-// their values cp32 or -- nullptr -- their numbers), not all suffixes of the text
-template <bool FROMKEYS>
+// SRC 0: all suffixes of a 2-bit text; SRC 1 (FROMKEYS): the entries are the keys a
+// part build has filtered from the text (ck, their values cp32 or -- nullptr --
+// their numbers); SRC 2: all suffixes of a 5-bit text, by their FMT 1 codes (as
+// "keys" code << 24 | payload: level-A digit and K1 lie where Key<2> has them)
+template <int SRC>
 __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     Text t, u64 N, u32 last_valid, const u32 *__restrict__ scanned, u32 ntiles,
     const u64 *__restrict__ ck, const u32 *__restrict__ cp32,
@@ -515,6 +646,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
   u32 gbase = 0;
   if (tid < 256) gbase = scanned[(u64) tile * 256 + tid];
+  constexpr bool FROMKEYS = SRC == 1;
   u64 key[MS_ITEMS];
   u32 rk[MS_ITEMS], val[MS_ITEMS];
   if (FROMKEYS) {
@@ -530,7 +662,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     u64 key8[KP_PER];
     const u64 p0 = tile_base + (u64) tid * KP_PER;
     if (p0 < N) {
-      dna_keys8(t, p0, key8);
+      if (SRC == 2) p5_keys8(t, p0, key8);
+      else dna_keys8(t, p0, key8);
     } else {
 #pragma unroll
       for (int g = 0; g < KP_PER; g++) key8[g] = ~0ull;
@@ -592,7 +725,8 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_scatter_a(
     const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
     s_k1[pos] = (u32) (key[j] >> 24);
     s_p[pos] = FROMKEYS ? val[j] : (u32) tile_base + e;
-    s_x[pos] = (u8) ((((u32) (key[j] >> 19) & 31u) << 3) | ((u32) key[j] & 7u));
+    s_x[pos] = SRC == 2 ? (u8) ((u32) key[j] & 63u)
+                        : (u8) ((((u32) (key[j] >> 19) & 31u) << 3) | ((u32) key[j] & 7u));
     s_d[pos] = (u8) d;
   }
   __syncthreads();
@@ -996,9 +1130,9 @@ __device__ __forceinline__ u32 k2_letters(u32 k2) {
 }
 // one quad of table entries (entries i0 .. i0+3 of the run, global index g0 ..);
 // INTERIOR: all four and the entry in front are inside the run
-template <bool INTERIOR>
+template <int FMT, bool INTERIOR>
 __device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val, int i0, u32 cnt,
-                                             u64 g0, u32 base, bool has_prev, u32 prevk2,
+                                             u64 g0, u32 base, bool has_prev, u32 prevk2, u32 s16,
                                              const MsdOut &o, MsdAcc &acc) {
   u32 k[4], pv[4];
 #pragma unroll
@@ -1010,20 +1144,31 @@ __device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val,
   }
   const u32 prevk = (INTERIOR || i0 > 0) ? s_key[i0 - 1] + base : prevk2;
   u32 lcpv[4] = {0, 0, 0, 0}, tiemask = 0;
-  u32 da = k2_letters(prevk);
+  const u64 chi = (u64) s16 << 24;                    // FMT 1: the code bits the run shares
+  // (FMT 1: X bit 5 says whether the code shows a padding at all -- 3 % of the suffixes
+  // of a protein set; the others have "nine or more" letters)
+  u32 da = FMT == 1 ? ((prevk & 32u) ? p5_letters(chi | (prevk >> 8)) : 9u) : k2_letters(prevk);
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int i = i0 + c;
     const bool ok = INTERIOR || (i >= 0 && i < (int) cnt);
     const bool have_a = INTERIOR || i > 0 || has_prev;
     const u32 a = (c == 0 || (!INTERIOR && i == 0)) ? prevk : k[c - 1], b = k[c];
-    if (!INTERIOR && c > 0 && i == 0) da = k2_letters(prevk);
-    const u32 db = k2_letters(b);
-    const u32 x = (a ^ b) >> 8;                       // symbols 8 .. 19
-    const u32 m = x ? 8u + ((u32) __clz((int) x) - 8u) / 2u : 20u;
+    if (!INTERIOR && c > 0 && i == 0)
+      da = FMT == 1 ? ((prevk & 32u) ? p5_letters(chi | (prevk >> 8)) : 9u) : k2_letters(prevk);
+    const u32 db = FMT == 1 ? ((b & 32u) ? p5_letters(chi | (b >> 8)) : 9u) : k2_letters(b);
+    const u32 x = (a ^ b) >> 8;                       // symbols 8 .. 19 / the code's low 24 bits
+    u32 m;
+    bool tie;
+    if (FMT == 1) {
+      m = p5_common(chi | (a >> 8), chi | (b >> 8));
+      tie = x == 0 && db == 9u;                       // the same code, nine letters or more
+    } else {
+      m = x ? 8u + ((u32) __clz((int) x) - 8u) / 2u : 20u;
+      tie = x == 0 && ((a | b) & 0xF8u) == 0;         // all 20 symbols, both dcodes 0
+    }
     u32 l = m < da ? m : da;
     l = l < db ? l : db;
-    bool tie = x == 0 && ((a | b) & 0xF8u) == 0;      // all 20 symbols, both dcodes 0
     if (!have_a) { l = 0; tie = false; }
     da = db;
     if (!ok) continue;
@@ -1051,7 +1196,8 @@ __device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val,
     if (o.bwt != nullptr) {
       u32 bw = 0;
 #pragma unroll
-      for (int c = 0; c < 4; c++) bw |= (u32) Pay<2>::to_bwt(k[c] & 7u) << (8 * c);
+      for (int c = 0; c < 4; c++)
+        bw |= (u32) (FMT == 1 ? Pay<5>::to_bwt(k[c] & 31u) : Pay<2>::to_bwt(k[c] & 7u)) << (8 * c);
       *reinterpret_cast<u32 *>(o.bwt + g0) = bw;
     }
   } else {
@@ -1062,14 +1208,15 @@ __device__ __forceinline__ u32 msd_emit_quad(const u32 *s_key, const u32 *s_val,
       if (o.suf != nullptr) o.suf[g0 + c] = pv[c];
       o.sa[g0 + c] = pv[c];
       if (o.lcp != nullptr) o.lcp[g0 + c] = (u8) lcpv[c];
-      if (o.bwt != nullptr) o.bwt[g0 + c] = Pay<2>::to_bwt(k[c] & 7u);
+      if (o.bwt != nullptr) o.bwt[g0 + c] = FMT == 1 ? Pay<5>::to_bwt(k[c] & 31u) : Pay<2>::to_bwt(k[c] & 7u);
     }
   }
   return tiemask;
 }
 
+template <int FMT>
 __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32 cnt, u64 gbeg,
-                                         u32 base, bool has_prev, u32 prevk2,
+                                         u32 base, bool has_prev, u32 prevk2, u32 s16,
                                          const MsdOut &o, u32 *s_bits, MsdAcc &acc) {
   static_assert(Key<2>::SYMS == 20 && Key<2>::DMAX == 31, "the layout msd_full spells out");
   const int tid = threadIdx.x;
@@ -1085,9 +1232,9 @@ __device__ __forceinline__ void msd_emit(const u32 *s_key, const u32 *s_val, u32
     const u64 g0 = gq + 4ull * q;
     u32 tiemask;
     if (i0 >= 1 && i0 + 4 <= (int) cnt)
-      tiemask = msd_emit_quad<true>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, o, acc);
+      tiemask = msd_emit_quad<FMT, true>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, s16, o, acc);
     else
-      tiemask = msd_emit_quad<false>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, o, acc);
+      tiemask = msd_emit_quad<FMT, false>(s_key, s_val, i0, cnt, g0, base, has_prev, prevk2, s16, o, acc);
     if (tiemask) {
       const u32 bo = 4u * q + (off64 - mis);   // bit of quad entry 0 in the LDS bitmap
       atomicOr(&s_bits[bo >> 5], tiemask << (bo & 31u));
@@ -1161,6 +1308,7 @@ __device__ __forceinline__ u32 md_base(const u32 *s_binw, u32 bin) {
   return (s_binw[bin >> 1] >> ((bin & 1u) * 16u)) & 0xFFFFu;
 }
 
+template <int FMT>
 __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
     u32 ntiles, int cb, int force_radix, u32 bin_limit, u32 *__restrict__ crowdlist,
@@ -1223,9 +1371,10 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
       const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
       const u32 e0 = (u32) w * wchunk + lane;      // entry of item j: e0 + 64 j
       // ---- counting pass
-      const int sb = nbits - 3;
-      const int binshift = sb > MD_BINBITS ? nbits - MD_BINBITS : 3;
-      const u32 lowmask = sb > MD_BINBITS ? (1u << (binshift - 3)) - 1u : 0u;
+      constexpr int PB = MsdFmt<FMT>::PB;
+      const int sb = nbits - PB;
+      const int binshift = sb > MD_BINBITS ? nbits - MD_BINBITS : PB;
+      const u32 lowmask = sb > MD_BINBITS ? (1u << (binshift - PB)) - 1u : 0u;
       for (int i = tid; i < MD_BINS / 8 + 2; i += MS_THREADS)
         reinterpret_cast<uint4 *>(s_binw)[i] = make_uint4(0, 0, 0, 0);
       lds_barrier();
@@ -1276,7 +1425,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
 #pragma unroll
         for (int j = 0; j < MD_ITEMS; j++)
           if ((u32) j < items && e0 + 64u * j < cnt)
-            s_c[b0[j] + rk[j]] = (((key[j] >> 3) & lowmask) << 12) | (e0 + 64u * j);
+            s_c[b0[j] + rk[j]] = (((key[j] >> PB) & lowmask) << 12) | (e0 + 64u * j);
         lds_barrier();
         // its place: the bin's start + the bin mates that are smaller.  The first
         // two mates in one go (a bin seldom has more), the rest one by one.
@@ -1291,7 +1440,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
         for (int j = 0; j < MD_ITEMS; j++) m1[j] = s_c[b0[j] + 1u < b1[j] ? b0[j] + 1u : b0[j]];
 #pragma unroll
         for (int j = 0; j < MD_ITEMS; j++) {
-          const u32 c = (((key[j] >> 3) & lowmask) << 12) | (e0 + 64u * j);
+          const u32 c = (((key[j] >> PB) & lowmask) << 12) | (e0 + 64u * j);
           u32 r = b0[j] + (m0[j] < c ? 1u : 0u) + (m1[j] < c ? 1u : 0u);   // (m1 = m0 if alone:
           if (b0[j] + 1u >= b1[j]) r = b0[j];                              //  then the place is b0)
           if (b1[j] - b0[j] > 2u)
@@ -1313,10 +1462,10 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
     fetch(tdn);
     if (!skip) {
       if (tid == 0) {
-        o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
-        o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
+        o.firstkey[t] = msd_full<FMT>(td.s16, s_key[0] + base);
+        o.lastkey[t] = msd_full<FMT>(td.s16, s_key[cnt - 1] + base);
       }
-      msd_emit(s_key, s_val, cnt, td.begin, base, false, 0u, o, s_bits, acc);
+      msd_emit<FMT>(s_key, s_val, cnt, td.begin, base, false, 0u, td.s16, o, s_bits, acc);
     }
     t = tn;
     td = tdn;
@@ -1328,6 +1477,7 @@ __global__ __launch_bounds__(MS_THREADS, 4) void k_msd_local(
 // the runs k_msd_local has left (a crowded bin) or never had (above its 2044
 // entries): stable LSD passes on 9-bit digits, ballot-ranked like the scatter
 // kernels, up to 4096 entries
+template <int FMT>
 __global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, const MdTile *__restrict__ tiles,
     const u32 *__restrict__ crowdlist, const u32 *__restrict__ counters, int cb, MsdOut o) {
@@ -1351,7 +1501,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
     const u32 span = td.pad >> 16;
     const u32 base = cb ? (td.pad & 0xFFFFu) << csh : 0u;
     const int nbits = cb ? csh + (span > 1u ? 32 - __clz((int) (span - 1u)) : 0) : 32;
-    const int npass = (nbits - 3 + MD_BITS - 1) / MD_BITS;
+    const int npass = (nbits - MsdFmt<FMT>::PB + MD_BITS - 1) / MD_BITS;
     const u32 items = (cnt + MS_THREADS - 1) / MS_THREADS, wchunk = items * 64u;
     u32 key[MS_ITEMS], val[MS_ITEMS], rk[MS_ITEMS];
 #pragma unroll
@@ -1366,7 +1516,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
       }
     }
     for (int p = 0; p < npass; p++) {
-      const int shift = 3 + MD_BITS * p;
+      const int shift = MsdFmt<FMT>::PB + MD_BITS * p;
       for (int i = tid; i < MS_WAVES * MD_RADIX / 2; i += MS_THREADS)
         reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
       lds_barrier();
@@ -1421,10 +1571,10 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
       }
     }
     if (tid == 0) {
-      o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
-      o.lastkey[t] = msd_full(td.s16, s_key[cnt - 1] + base);
+      o.firstkey[t] = msd_full<FMT>(td.s16, s_key[0] + base);
+      o.lastkey[t] = msd_full<FMT>(td.s16, s_key[cnt - 1] + base);
     }
-    msd_emit(s_key, s_val, cnt, td.begin, base, false, 0u, o, s_bits, acc);
+    msd_emit<FMT>(s_key, s_val, cnt, td.begin, base, false, 0u, td.s16, o, s_bits, acc);
   }
   __syncthreads();
   msd_acc_flush(acc, o.stats);
@@ -1433,6 +1583,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_local_radix(
 // oversize runs: one workgroup sorts a run in global memory, 8-bit digits,
 // ping-pong between (ka, pa) -- where the run lies and where the 32-bit
 // positions have to end up -- and the same index range of (kb, pb)
+template <int FMT>
 __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
     u32 *__restrict__ ka, u32 *__restrict__ pa, u32 *__restrict__ kb, u32 *__restrict__ pb,
     const MdTile *__restrict__ tiles, const u32 *__restrict__ biglist,
@@ -1457,11 +1608,11 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
     u32 base;
     int nbits;
     msd_run_bits(ka, td.begin, td.end, cb, base, nbits);
-    const int npass = nbits > 3 ? (nbits - 3 + 7) / 8 : 0;
+    const int npass = nbits > MsdFmt<FMT>::PB ? (nbits - MsdFmt<FMT>::PB + 7) / 8 : 0;
     u32 *sk = ka + td.begin, *sp = pa + td.begin, *dk = kb + td.begin, *dp = pb + td.begin;
     __syncthreads();   // (base was read from ka by every thread before anyone writes)
     for (int p = 0; p < npass; p++) {
-      const int shift = 3 + 8 * p;
+      const int shift = MsdFmt<FMT>::PB + 8 * p;
       if (tid < 256) s_cur[tid] = 0;
       __syncthreads();
       for (u32 e = tid; e < cnt; e += MS_THREADS)
@@ -1565,11 +1716,11 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
       }
       __syncthreads();
       if (tid == 0) {
-        if (c0 == 0) o.firstkey[t] = msd_full(td.s16, s_key[0] + base);
-        if (c0 + valid == cnt) o.lastkey[t] = msd_full(td.s16, s_key[valid - 1] + base);
+        if (c0 == 0) o.firstkey[t] = msd_full<FMT>(td.s16, s_key[0] + base);
+        if (c0 + valid == cnt) o.lastkey[t] = msd_full<FMT>(td.s16, s_key[valid - 1] + base);
       }
       const u32 lastk = s_key[valid - 1] + base;
-      msd_emit(s_key, s_val, valid, (u64) td.begin + c0, base, c0 > 0, prevkey, o, s_bits, acc);
+      msd_emit<FMT>(s_key, s_val, valid, (u64) td.begin + c0, base, c0 > 0, prevkey, td.s16, o, s_bits, acc);
       prevkey = lastk;
     }
   }
@@ -1577,6 +1728,7 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_big(
 }
 
 // table entries of a giant run the device-wide sort has put in order
+template <int FMT>
 __global__ __launch_bounds__(MS_THREADS) void k_msd_emit_run(
     const u32 *__restrict__ kin, const u32 *__restrict__ pin, u32 t, u32 begin, u32 cnt, u32 s16,
     MsdOut o) {
@@ -1599,17 +1751,18 @@ __global__ __launch_bounds__(MS_THREADS) void k_msd_emit_run(
   }
   __syncthreads();
   if (tid == 0) {
-    if (c0 == 0) o.firstkey[t] = msd_full(s16, s_key[0]);
-    if (c0 + valid == cnt) o.lastkey[t] = msd_full(s16, s_key[valid - 1]);
+    if (c0 == 0) o.firstkey[t] = msd_full<FMT>(s16, s_key[0]);
+    if (c0 + valid == cnt) o.lastkey[t] = msd_full<FMT>(s16, s_key[valid - 1]);
   }
   const u32 prevkey = c0 > 0 ? kin[(u64) begin + c0 - 1] : 0u;
-  msd_emit(s_key, s_val, valid, (u64) begin + c0, 0u, c0 > 0, prevkey, o, s_bits, acc);
+  msd_emit<FMT>(s_key, s_val, valid, (u64) begin + c0, 0u, c0 > 0, prevkey, s16, o, s_bits, acc);
   msd_acc_flush(acc, o.stats);
 }
 
 // lcp of every run's first entry with the last entry of the run in front of it;
 // a part build: of the slice's first entry with the largest key of the ranges
 // below (prev_key, if has_prev)
+template <int FMT>
 __global__ __launch_bounds__(256) void k_msd_seams(const MdTile *__restrict__ tiles, u32 ntiles,
                                                    const unsigned long long *__restrict__ prev_key_p,
                                                    int has_prev, MsdOut o) {
@@ -1628,9 +1781,15 @@ __global__ __launch_bounds__(256) void k_msd_seams(const MdTile *__restrict__ ti
         a = o.lastkey[u];
       }
       const u64 b = o.firstkey[t];
-      const u32 da = K::letters(a), db = K::letters(b);
-      const u64 x = (a ^ b) >> K::LOW_BITS;
-      const u32 m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;
+      u32 da, db, m;
+      if (FMT == 1) {        // (code << 8 | X)
+        da = p5_letters(a >> 8); db = p5_letters(b >> 8);
+        m = p5_common(a >> 8, b >> 8);
+      } else {
+        da = K::letters(a); db = K::letters(b);
+        const u64 x = (a ^ b) >> K::LOW_BITS;
+        m = x ? (u32) (__clzll((long long) x) - K::LOW_BITS) / 2u : (u32) K::SYMS;
+      }
       u32 l = m < da ? m : da;
       l = l < db ? l : db;
       if (o.lcp != nullptr) o.lcp[td.begin] = (u8) l;

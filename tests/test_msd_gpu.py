@@ -195,3 +195,99 @@ def test_depth_of_level_c_is_chosen_from_the_ranges(gpu, msd):
         enc = rng.choice(4, size=300000, p=p).astype(np.uint8)
         res = esa.suffixerator_tables(enc, 4)
         _assert_same_as_oracle(enc, 4, res)
+
+
+# ---------------------------------------------------------------------------
+# the 5-bit alphabets through the same levels (esa_msd.h, FMT 1: a 40-bit code of
+# nine symbols -- four pairs as 9-bit numbers, the ninth by its class)
+# ---------------------------------------------------------------------------
+PROTEIN_FIXTURES = sorted(k for k in GOLDEN if GOLDEN[k]["alphabet"] == "protein")
+
+
+@pytest.mark.parametrize("name", PROTEIN_FIXTURES)
+def test_protein_reference_fixtures(gpu, msd, name):
+    e = GOLDEN[name]
+    enc = ou.encode_fasta(ou.fixture_path(name), True)
+    res = esa.suffixerator_tables(enc, 20)
+    assert _md5(res.suf) == e["tables"]["suf"]["md5"]
+    assert _md5(res.lcp) == e["tables"]["lcp"]["md5"]
+    assert _md5(res.llv) == e["tables"]["llv"]["md5"]
+    assert _md5(res.bwt) == e["tables"]["bwt"]["md5"]
+    ss = ou.seqstats(enc, 20)
+    assert esa.prj_text(ss, res.stats) == e["prj"]
+
+
+def _protein_cases():
+    rng = np.random.default_rng(77)
+    yield "model_70k", synth.generate(synth.MODEL_PROTEIN, 3, 70001)
+    yield "model_1m", synth.generate(synth.MODEL_PROTEIN, 4, 1 << 20)
+    r = rng.integers(0, 20, 30000, dtype=np.uint8)
+    yield "copies", np.concatenate([r, [255], r[:20000], [254], r[5000:]]).astype(np.uint8)
+    yield "one_letter", np.full(20000, 7, dtype=np.uint8)
+    yield "two_letters", rng.integers(18, 20, 50000, dtype=np.uint8)          # the largest letters
+    yield "period_3", np.tile(np.array([0, 19, 5], dtype=np.uint8), 9000)
+    yield "all_wildcards", np.full(5000, 254, dtype=np.uint8)
+    yield "specials_everywhere", np.where(rng.random(60000) < 0.12, 254 + (rng.random(60000) < 0.5),
+                                          rng.integers(0, 20, 60000)).astype(np.uint8)
+    x = rng.integers(0, 20, 40000).astype(np.uint8)
+    x[8::9] = 255                                   # a special behind every eight letters
+    x[-1] = 3
+    yield "separator_every_9th", x
+    y = rng.integers(0, 20, 40000).astype(np.uint8)
+    y[9::10] = 254                                  # ... behind every nine: the class of the ninth
+    yield "wildcard_every_10th", y
+    yield "tiny", np.array([3, 19, 254, 0, 0], dtype=np.uint8)
+
+
+@pytest.mark.parametrize("name,enc", list(_protein_cases()), ids=[c[0] for c in _protein_cases()])
+@pytest.mark.parametrize("cbits", ["0", "8"])
+@pytest.mark.parametrize("big_max", ["4096", "524288"])
+def test_protein_cases(gpu, msd, big_max, cbits, name, enc):
+    msd.setenv("GTAMD_MSD_CBITS", cbits)
+    msd.setenv("GTAMD_MSD_BIG_MAX", big_max)
+    res = esa.suffixerator_tables(enc, 20)
+    _assert_same_as_oracle(enc, 20, res)
+    if enc.size >= 64:
+        assert res.timing["dominant_kernel"] == 1      # (it WAS the MSD sort)
+
+
+@pytest.mark.parametrize("radix", ["0", "1"])
+def test_protein_radix_fallback_and_prefixlength(gpu, msd, radix):
+    """the statistics of .prj mask the LCP sum with the prefix length: the code
+    must tell "at least k letters" for every k it is used with (k <= 9)"""
+    import ctypes
+    msd.setenv("GTAMD_MSD_RADIX", radix)
+    rng = np.random.default_rng(5)
+    enc = synth.generate(synth.MODEL_PROTEIN, 9, 300000)
+    enc[rng.integers(0, enc.size, 3000)] = 254        # many short stretches of letters
+    ora = ou.esa(enc, 20)
+    L = ou.lib()
+    for pl in (0, 1, 5, 8, 9):
+        with esa.EsaEngine(enc.size, 20) as eng:
+            eng.set_prefixlength(pl)
+            eng.set_sequence(enc)
+            eng.run()
+            res = eng.result()
+        assert res.timing["dominant_kernel"] == 1
+        assert np.array_equal(res.suf, ora["suf"]) and np.array_equal(res.lcp, ora["lcp"])
+        assert np.array_equal(res.bwt, ora["bwt"])
+        st = ou.EsaStats()
+        L.ora_esastats_compute(ou._p(enc), enc.size, ou._p(ora["suf"]), ou._p(ora["lcpfull"]),
+                               pl or res.stats["prefixlength"], ctypes.byref(st))
+        assert res.stats["lcptabsum"] == int(st.lcptabsum), pl
+        assert res.stats["maxbranchdepth"] == st.maxbranchdepth
+
+
+def test_protein_same_tables_as_the_lsd_sort(gpu, monkeypatch):
+    enc = synth.generate(synth.MODEL_PROTEIN, 21, 30_000_000)
+    out = {}
+    with esa.EsaEngine(enc.size, 20) as eng:
+        eng.set_sequence(enc)
+        for mode in ("0", "1"):
+            monkeypatch.setenv("GTAMD_MSD", mode)
+            eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT)
+            r = eng.result()
+            out[mode] = (_md5(r.suf), _md5(r.lcp), _md5(r.bwt), _md5(r.llv), dict(r.stats))
+    assert out["0"][:4] == out["1"][:4]
+    for k in ("longest", "largelcpvalues", "maxbranchdepth", "lcptabsum", "prefixlength"):
+        assert out["0"][4][k] == out["1"][4][k], k

@@ -147,6 +147,9 @@ ABI = {
     "gtamd_encoder_destroy": (None, [_P]),
     "gtamd_encoder_add_file": (_INT, [_P, ctypes.c_char_p, _P, _U64]),
     "gtamd_encoder_finish": (_INT, [_P]),
+    "gtamd_encoder_declined": (_INT, [_P]),
+    "gtamd_encoder_num_fastq_records": (_U64, [_P]),
+    "gtamd_encoder_get_fastq_records": (_INT, [_P, _P, _P, _P, _U64]),
     "gtamd_encoder_set_symbols": (_INT, [_P, _P, _U64]),
     "gtamd_encoder_length": (_U64, [_P]),
     "gtamd_encoder_device_symbols": (_P, [_P]),

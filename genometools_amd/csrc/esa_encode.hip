@@ -424,11 +424,135 @@ __global__ __launch_bounds__(EN_THREADS) void k_positions(
     if (flags & (1u << j)) out[at++] = base + j;
 }
 
+// ---------------------------------------------------------------------------
+// FASTQ on the device (src/core/seq_iterator_fastq.c:96-305, the block grammar):
+// the STRICT four-line form only -- "@name", one line of symbols, "+[name]", one
+// line of as many quality characters, every line ended by '\n', no blanks in the
+// symbol and quality lines.  That is what sequencers write, and it is the form
+// in which a record's parts are known from the line number alone: newlines are
+// counted per tile, a scan gives every byte its line, line mod 4 its role.
+// Anything else -- sequences or qualities over several lines, a missing last
+// newline, an illegal symbol, lengths that differ -- makes the walk say "not for
+// me" (FqGlobals.bad), and the host reader, which has the reference's messages for
+// all of that, takes the input (gtamd_encoder_declined).
+// ---------------------------------------------------------------------------
+struct FqGlobals {
+  unsigned long long bad;              // != 0: not the strict form / an illegal symbol
+  unsigned long long origdist[256];    // the original characters of the sequences
+};
+
+// walk of a tile: EMIT 0 newlines per tile; 1 (line numbers known) sequence symbols
+// per tile, the checks, the histogram; 2 the symbols and separators
+struct FqEmit {
+  u8 *enc;            // where this file's output starts
+  int seen_record;    // a record (of an earlier file) precedes this file's first
+};
+template <int EMIT>
+__global__ __launch_bounds__(EN_THREADS) void k_fq_tile(
+    const u8 *raw, u64 len, const u8 *lut, const u32 *t_nl, const u32 *t_sym, u32 *t_out,
+    FqGlobals *g, FqEmit em) {
+  __shared__ u32 lds[EN_THREADS / 64];
+  __shared__ u32 s_hist[256];
+  const u64 tile = blockIdx.x, first = tile * EN_TILE + (u64) threadIdx.x * EN_PER;
+  u8 b[EN_PER];
+  u32 nnl = 0;
+  if (EMIT == 1) { s_hist[threadIdx.x] = 0; __syncthreads(); }
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    b[j] = first + j < len ? raw[first + j] : (u8) 0;
+    nnl += first + j < len && b[j] == '\n';
+  }
+  u32 total;
+  const u32 nlbefore = block_scan_excl<SCAN_SUM, EN_THREADS>(nnl, &total, lds);
+  if (EMIT == 0) {
+    if (threadIdx.x == 0) t_out[tile] = total;
+    return;
+  }
+  u64 line = (u64) t_nl[tile] + nlbefore;
+  u32 nsym = 0, bad = 0;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    if (first + j >= len) break;
+    const u8 c = b[j];
+    if (c == '\n') { line++; continue; }
+    if (c == '\r') bad = 1;          // (what a carriage return means differs by line)
+    const u32 role = (u32) line & 3u;
+    if (role == 1u) {
+      const u8 code = lut[c];
+      if (code >= LUT_BLANK && code != GTAMD_WILDCARD) bad = 1;      // blank, or no symbol
+      else { nsym++; if (EMIT == 1) atomicAdd(&s_hist[c], 1u); }
+    } else if (role == 3u && c == ' ') bad = 1;
+  }
+  u32 tsym;
+  const u32 symbefore = block_scan_excl<SCAN_SUM, EN_THREADS>(nsym, &tsym, lds);
+  if (EMIT == 1) {
+    if (threadIdx.x == 0) t_out[tile] = tsym;
+    if (bad) atomicOr(&g->bad, 1ull);
+    __syncthreads();
+    if (s_hist[threadIdx.x]) atomicAdd(&g->origdist[threadIdx.x], (unsigned long long) s_hist[threadIdx.x]);
+    return;
+  }
+  // the symbols of record r lie behind those of the records before and the
+  // separators between them (one in front of every record but the first of all)
+  u64 so = (u64) t_sym[tile] + symbefore;
+  line = (u64) t_nl[tile] + nlbefore;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++) {
+    if (first + j >= len) break;
+    const u8 c = b[j];
+    const u64 r = line >> 2;
+    const bool linestart = first + j == 0 || (j ? b[j - 1] : raw[first - 1]) == '\n';
+    if (linestart && (line & 3u) == 0 && (r > 0 || em.seen_record))
+      em.enc[so + (em.seen_record ? r : r - 1)] = (u8) GTAMD_SEPARATOR;
+    if (c == '\n') { line++; continue; }
+    if ((line & 3u) == 1u) {
+      em.enc[so + (em.seen_record ? r + 1 : r)] = lut[c];
+      so++;
+    }
+  }
+}
+// positions of the newlines, in order (counts and offsets of k_fq_tile<0>)
+__global__ __launch_bounds__(EN_THREADS) void k_fq_newlines(const u8 *raw, u64 len,
+                                                            const u32 *t_nl, u32 *nl) {
+  __shared__ u32 lds[EN_THREADS / 64];
+  const u64 tile = blockIdx.x, first = tile * EN_TILE + (u64) threadIdx.x * EN_PER;
+  u32 mask = 0;
+#pragma unroll
+  for (int j = 0; j < EN_PER; j++)
+    if (first + j < len && raw[first + j] == '\n') mask |= 1u << j;
+  u32 total;
+  u32 at = t_nl[tile] + block_scan_excl<SCAN_SUM, EN_THREADS>((u32) __popc(mask), &total, lds);
+  for (int j = 0; j < EN_PER; j++)
+    if ((mask >> j) & 1u) nl[at++] = (u32) (first + j);
+}
+// one thread per record: '@' and '+' where they belong, the '+' line empty or the
+// name again, as many qualities as symbols, no empty sequence; the description's
+// bytes, and the record's lengths (for the file length table)
+__global__ __launch_bounds__(256) void k_fq_records(const u8 *raw, const u32 *nl, u64 nrec,
+                                                    u64 *desc_start, u64 *desc_end,
+                                                    u32 *seqlen, u32 *desclen, FqGlobals *g) {
+  const u64 k = (u64) blockIdx.x * 256 + threadIdx.x;
+  if (k >= nrec) return;
+  const u64 s0 = k ? (u64) nl[4 * k - 1] + 1 : 0, e0 = nl[4 * k], s1 = e0 + 1, e1 = nl[4 * k + 1],
+            s2 = e1 + 1, e2 = nl[4 * k + 2], s3 = e2 + 1, e3 = nl[4 * k + 3];
+  bool ok = e0 > s0 && raw[s0] == '@' && e2 > s2 && raw[s2] == '+' && e1 > s1 && e3 - s3 == e1 - s1;
+  if (ok && e2 - s2 > 1) {
+    ok = e2 - s2 == e0 - s0;
+    for (u64 i = 1; ok && i < e0 - s0; i++) ok = raw[s0 + i] == raw[s2 + i];
+  }
+  if (!ok) atomicOr(&g->bad, 2ull);
+  desc_start[k] = s0 + 1;
+  desc_end[k] = e0;
+  seqlen[k] = (u32) (e1 - s1);
+  desclen[k] = (u32) (e0 - s0 - 1);
+}
+
 struct InputFile {
   std::string name;
   const u8 *bytes;
   u64 length;
   u64 out_start, out_len, ndesc, desc_base;   // filled by finish
+  bool fastq;
 };
 
 template <typename T> int dev_alloc(T **p, u64 count) {
@@ -458,6 +582,10 @@ struct gtamd_encoder {
   gtamd_encode_summary sum;
   float total_ms, parse_ms, stats_ms;
   u64 input_bytes;
+  // FASTQ input: a record's sequence and description lengths (the file length
+  // table of the reference's FASTQ reader is made from them), in input order
+  std::vector<u32> rec_seqlen, rec_desclen, rec_file;
+  bool declined;           // the last finish met FASTQ input the device reader does not take
 };
 
 static void enc_free(gtamd_encoder *e) {
@@ -540,6 +668,7 @@ extern "C" int gtamd_encoder_add_file(gtamd_encoder *e, const char *name,
   InputFile f;
   f.name = name; f.bytes = bytes; f.length = length;
   f.out_start = f.out_len = f.ndesc = f.desc_base = 0;
+  f.fastq = length > 0 && bytes[0] == '@';
   e->files.push_back(f);
   e->finished = false;
   return 0;
@@ -593,6 +722,78 @@ static int encode_files(gtamd_encoder *e, u8 *d_raw, u8 *d_lut, u32 *d_tile,
     f.out_start = e->n; f.out_len = 0; f.ndesc = 0; f.desc_base = e->ndesc;
     if (ntiles == 0) continue;
     HIP_TRY(hipMemcpyAsync(d_raw, f.bytes, f.length, hipMemcpyHostToDevice, e->st));
+    if (f.fastq) {
+      // ---- the strict four-line form, or not for the device
+      FqGlobals *d_fq = nullptr;
+      u32 *d_nl = nullptr, *d_rs = nullptr, *d_rd = nullptr;
+      auto decline = [&]() -> int {
+        if (d_fq) (void) hipFree(d_fq);
+        if (d_nl) (void) hipFree(d_nl);
+        if (d_rs) (void) hipFree(d_rs);
+        if (d_rd) (void) hipFree(d_rd);
+        e->declined = true;
+        gtamd_set_error("FASTQ file '%s' is not in the strict four-line form the device reader "
+                        "takes (the host reader reads it)", f.name.c_str());
+        return -1;
+      };
+      if (f.bytes[f.length - 1] != '\n') return decline();
+      TRY(dev_alloc(&d_fq, 1));
+      HIP_TRY(hipMemsetAsync(d_fq, 0, sizeof(FqGlobals), e->st));
+      u32 *t_nlc = t_last, *t_nlo = t_state;
+      k_fq_tile<0><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(d_raw, f.length, d_lut, nullptr, nullptr, t_nlc,
+                                                          d_fq, FqEmit());
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, t_nlc, t_nlo, ntiles, false, d_ws, e->st));
+      k_fq_tile<1><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(d_raw, f.length, d_lut, t_nlo, nullptr, t_syms,
+                                                          d_fq, FqEmit());
+      HIP_TRY(hipGetLastError());
+      TRY(scan_u32(SCAN_SUM, t_syms, t_soff, ntiles, false, d_ws, e->st));
+      u32 last[4];
+      FqGlobals got;
+      HIP_TRY(hipStreamSynchronize(e->st));
+      HIP_TRY(hipMemcpy(&got, d_fq, sizeof got, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&last[0], t_nlo + ntiles - 1, 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&last[1], t_nlc + ntiles - 1, 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&last[2], t_soff + ntiles - 1, 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&last[3], t_syms + ntiles - 1, 4, hipMemcpyDeviceToHost));
+      const u64 nlines = (u64) last[0] + last[1], nsym = (u64) last[2] + last[3];
+      if (got.bad != 0 || nlines == 0 || (nlines & 3) != 0) return decline();
+      const u64 nrec = nlines / 4;
+      if (dev_alloc(&d_nl, nlines) != 0 || dev_alloc(&d_rs, nrec) != 0 || dev_alloc(&d_rd, nrec) != 0) {
+        (void) decline();
+        e->declined = false;
+        gtamd_set_error("cannot allocate device memory for the %llu records of '%s'",
+                        (unsigned long long) nrec, f.name.c_str());
+        return -1;
+      }
+      k_fq_newlines<<<(u32) ntiles, EN_THREADS, 0, e->st>>>(d_raw, f.length, t_nlo, d_nl);
+      HIP_TRY(hipGetLastError());
+      TRY(grow_desc(e, e->ndesc + nrec));
+      k_fq_records<<<(u32) div_up(nrec, 256), 256, 0, e->st>>>(d_raw, d_nl, nrec, e->d_desc_start + e->ndesc,
+                                                             e->d_desc_end + e->ndesc, d_rs, d_rd, d_fq);
+      HIP_TRY(hipGetLastError());
+      FqEmit em;
+      em.enc = e->d_enc + e->n;
+      em.seen_record = seen_record ? 1 : 0;
+      k_fq_tile<2><<<(u32) ntiles, EN_THREADS, 0, e->st>>>(d_raw, f.length, d_lut, t_nlo, t_soff, nullptr,
+                                                          d_fq, em);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(e->st));
+      HIP_TRY(hipMemcpy(&got, d_fq, 8, hipMemcpyDeviceToHost));
+      if (got.bad != 0) return decline();
+      const size_t r0 = e->rec_seqlen.size();
+      e->rec_seqlen.resize(r0 + nrec); e->rec_desclen.resize(r0 + nrec); e->rec_file.resize(r0 + nrec, (u32) fi);
+      HIP_TRY(hipMemcpy(e->rec_seqlen.data() + r0, d_rs, nrec * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(e->rec_desclen.data() + r0, d_rd, nrec * 4, hipMemcpyDeviceToHost));
+      (void) hipFree(d_fq); (void) hipFree(d_nl); (void) hipFree(d_rs); (void) hipFree(d_rd);
+      for (int c = 0; c < 256; c++) e->sum.originaldistribution[c] += got.origdist[c];
+      f.out_len = nsym + nrec - (seen_record ? 0 : 1);
+      f.ndesc = nrec;
+      e->n += f.out_len;
+      e->ndesc += nrec;
+      seen_record = true;
+      continue;
+    }
     FaGlobals init;
     memset(&init, 0, sizeof init);
     init.first_illegal = init.first_desc = NONE64;
@@ -748,6 +949,19 @@ extern "C" int gtamd_encoder_finish(gtamd_encoder *e) {
   }
   enc_free(e);
   e->finished = false;
+  e->declined = false;
+  e->rec_seqlen.clear(); e->rec_desclen.clear(); e->rec_file.clear();
+  // (the device reader takes FASTA files or FASTQ files, not both in one run: the
+  // reference's rules at the seam of the two formats stay with the host reader)
+  {
+    size_t nq = 0;
+    for (const InputFile &f : e->files) nq += f.fastq;
+    if (nq != 0 && nq != e->files.size()) {
+      e->declined = true;
+      gtamd_set_error("FASTA and FASTQ files in one run: the host reader reads them");
+      return -1;
+    }
+  }
   memset(&e->sum, 0, sizeof e->sum);
   e->input_bytes = total;
   const u64 max_tiles = div_up(longest, EN_TILE) + 1;
@@ -889,6 +1103,26 @@ extern "C" int gtamd_encoder_file_lengths(const gtamd_encoder *e, size_t file,
   GTAMD_ABI_END(-1)
 }
 
+extern "C" int gtamd_encoder_declined(const gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
+  return e != nullptr && e->declined ? 1 : 0;
+  GTAMD_ABI_END(0)
+}
+extern "C" uint64_t gtamd_encoder_num_fastq_records(const gtamd_encoder *e) {
+  GTAMD_ABI_BEGIN
+  return e != nullptr && e->finished ? (uint64_t) e->rec_seqlen.size() : 0;
+  GTAMD_ABI_END(0)
+}
+extern "C" int gtamd_encoder_get_fastq_records(const gtamd_encoder *e, uint32_t *file, uint32_t *seqlen,
+                                               uint32_t *desclen, uint64_t capacity) {
+  GTAMD_ABI_BEGIN
+  TRY(need_finished(e));
+  const size_t m = e->rec_seqlen.size();
+  if (m > capacity) { gtamd_set_error("%zu records, room for %llu", m, (unsigned long long) capacity); return -1; }
+  for (size_t k = 0; k < m; k++) { file[k] = e->rec_file[k]; seqlen[k] = e->rec_seqlen[k]; desclen[k] = e->rec_desclen[k]; }
+  return 0;
+  GTAMD_ABI_END(-1)
+}
 extern "C" uint64_t gtamd_encoder_num_descriptions(const gtamd_encoder *e) {
   GTAMD_ABI_BEGIN
   return e != nullptr && e->finished ? e->ndesc : 0;

@@ -171,7 +171,14 @@ __device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PE
     }
     return;
   }
-  const u64 wa = Sym<5>::window(t, p0), wb = Sym<5>::window(t, p0 + 8);
+  // (one division for the three places: p0, p0 + 8 and the symbol in front)
+  const u64 w0 = p0 / 12;
+  const int r0 = (int) (p0 - w0 * 12);
+  const u64 t0 = tb_word(t, w0), t1 = tb_word(t, w0 + 1), t2 = tb_word(t, w0 + 2);
+  const u64 wa = r0 <= 1 ? t0 << (5 * r0) : (t0 << (5 * r0)) | (t1 >> (5 * (12 - r0)));
+  const int r8 = r0 + 8 >= 12 ? r0 - 4 : r0 + 8;
+  const u64 ta = r0 + 8 >= 12 ? t1 : t0, tb = r0 + 8 >= 12 ? t2 : t1;
+  const u64 wb = r8 <= 1 ? ta << (5 * r8) : (ta << (5 * r8)) | (tb >> (5 * (12 - r8)));
   u32 sym[16], pr[15];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -180,7 +187,11 @@ __device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PE
   }
 #pragma unroll
   for (int i = 0; i < 15; i++) pr[i] = sym[i] * 21u + sym[i + 1];
-  u32 pay = Pay<5>::before(t, p0);
+  u32 pay = Pay<5>::UNDEF;
+  if (p0 > 0) {
+    const u32 c = r0 ? (u32) (t0 >> (59 - 5 * (r0 - 1))) & 31u : (u32) (tb_word(t, w0 - 1) >> 4) & 31u;
+    pay = (c < 2u && is_special(t, p0 - 1)) ? ((c & 1u) ? Pay<5>::SEP : Pay<5>::WILD) : c;
+  }
 #pragma unroll
   for (int g = 0; g < KP_PER; g++) {
     const u64 code = ((u64) pr[g] << 31) | ((u64) pr[g + 2] << 22) | ((u64) pr[g + 4] << 13) |

@@ -51,8 +51,9 @@ int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
   uint64_t *rawlen = calloc(numfiles ? numfiles : 1, sizeof *rawlen);
   gtamd_encoder *de = NULL;
   gtamd_encode_summary sum;
-  uint32_t *dfile = NULL;
-  uint64_t *dstart = NULL, *dend = NULL, ndesc, total = 0;
+  uint32_t *dfile = NULL, *rfile = NULL, *rseq = NULL, *rdesc = NULL;
+  gtamd_fastq_record *rec = NULL;
+  uint64_t *dstart = NULL, *dend = NULL, ndesc, total = 0, nrec = 0;
   char *dbuf = NULL;
   int rc = -1;
 
@@ -69,7 +70,10 @@ int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
     }
     if (gtamd_encoder_add_file(de, paths[f], raw[f], rawlen[f]) != 0) goto deverr;
   }
-  if (gtamd_encoder_finish(de) != 0) goto deverr;
+  if (gtamd_encoder_finish(de) != 0) {
+    if (gtamd_encoder_declined(de)) rc = GTAMD_DEVICE_DECLINED;
+    goto deverr;
+  }
   if (gtamd_encoder_get_summary(de, &sum) != 0) goto deverr;
   if (info != NULL) {
     info->numfiles = numfiles;
@@ -81,6 +85,18 @@ int gtamd_device_encode_files_alpha(const char *const *paths, size_t numfiles,
       if (gtamd_encoder_file_lengths(de, f, &info->filelengthtab[f].length,
                                      &info->filelengthtab[f].effectivelength) != 0)
         goto deverr;
+    if ((nrec = gtamd_encoder_num_fastq_records(de)) > 0) {
+      /* FASTQ: the table is booked per buffer fill of the reference's reader */
+      rfile = malloc(4 * nrec); rseq = malloc(4 * nrec); rdesc = malloc(4 * nrec);
+      rec = malloc(nrec * sizeof *rec);
+      if (rfile == NULL || rseq == NULL || rdesc == NULL || rec == NULL) goto nomem;
+      if (gtamd_encoder_get_fastq_records(de, rfile, rseq, rdesc, nrec) != 0) goto deverr;
+      for (uint64_t k = 0; k < nrec; k++) {
+        rec[k].seqlen = rseq[k]; rec[k].desclen = rdesc[k]; rec[k].file = rfile[k];
+      }
+      memset(info->filelengthtab, 0, numfiles * sizeof *info->filelengthtab);
+      gtamd_fastq_filelengths(rec, nrec, numfiles - 1, info->filelengthtab);
+    }
   }
   if (desc != NULL) {
     /* the descriptions, NUL-separated, carriage returns dropped
@@ -112,6 +128,7 @@ nomem:
 done:
   if (raw != NULL) for (size_t f = 0; f < numfiles; f++) free(raw[f]);
   free(raw); free(rawlen); free(dfile); free(dstart); free(dend); free(dbuf);
+  free(rfile); free(rseq); free(rdesc); free(rec);
   gtamd_encoder_destroy(de);
   if (rc != 0 && info != NULL) gtamd_encinfo_free(info);
   return rc;

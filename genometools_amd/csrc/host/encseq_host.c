@@ -156,7 +156,7 @@ void gtamd_read_input_error(int code, const char *path, char *err, size_t errlen
                         : "out of memory while reading '%s'", path);
 }
 
-typedef struct { uint64_t seqlen, desclen; size_t file; } fastq_record;
+typedef gtamd_fastq_record fastq_record;
 
 typedef struct {
   const uint8_t *map;
@@ -409,8 +409,8 @@ void gtamd_encinfo_free(gtamd_encinfo *info)
    an output buffer of 8192 symbols per call and books what it read per call,
    including the description lengths and the quirks at buffer boundaries
    (src/core/sequence_buffer_fastq.c:42-191, OUTBUFSIZE sequence_buffer_rep.h:30) */
-static void fastq_filelengths(const fastq_record *rec, size_t nrec, size_t lastfile,
-                              gtamd_filelength *tab)
+void gtamd_fastq_filelengths(const gtamd_fastq_record *rec, size_t nrec, size_t lastfile,
+                             gtamd_filelength *tab)
 {
   const uint64_t OUTBUF = 8192;
   uint64_t overflow = 0;
@@ -536,7 +536,7 @@ int gtamd_encode_files_orig(const char *const *paths, size_t numfiles,
   }
   if (orig != NULL) *orig = obuf.p;
   if (info != NULL && st.nrec > 0)
-    fastq_filelengths(st.rec, st.nrec, numfiles - 1, info->filelengthtab);
+    gtamd_fastq_filelengths(st.rec, st.nrec, numfiles - 1, info->filelengthtab);
   free(st.rec);
   /* a header that ends with the file (no newline) still counts */
   if (desc != NULL && (dbuf.len == 0 || dbuf.p[dbuf.len - 1] != 0)) (void) bb_push(&dbuf, 0);

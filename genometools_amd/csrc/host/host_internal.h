@@ -50,6 +50,12 @@ int gtamd_write_esq_sections(const char *indexname, const char *const *paths,
                              int write_ssp, const gtamd_esq_sections *sec,
                              char *err, size_t errlen);
 
+/* FASTQ: what the file length table needs of every record, and the table as the
+   reference's FASTQ reader books it (encseq_host.c) */
+typedef struct { uint64_t seqlen, desclen; size_t file; } gtamd_fastq_record;
+void gtamd_fastq_filelengths(const gtamd_fastq_record *rec, size_t nrec, size_t lastfile,
+                             gtamd_filelength *tab);
+
 /* one input file, whole, decompressed when its name ends in ".gz"; 0 or a code
    for gtamd_read_input_error */
 int gtamd_read_input_file(const char *path, uint8_t **data, uint64_t *len);

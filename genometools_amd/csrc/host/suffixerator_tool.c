@@ -451,6 +451,7 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
   gtamd_encoder *de = NULL;
   int rc = -1, host_encoder = 0, suftabuint = 0, clipdesc = 0, lossless = 0;
   const char *reader = "host";
+  int device_rc = 0;
   uint8_t *orig = NULL;
   double t0 = now_s(), t_seq, t_build, t_create;
 
@@ -592,12 +593,16 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
   }
   if (inputindex != NULL) {
     reader = "index";   /* (read above) */
-  } else if (want != 0 && !host_encoder && !lossless && !gtamd_input_is_fastq(db, numdb)) {
-    /* FASTA, tables requested: read and encode on the device; the symbols stay
-       in HBM for the engine and come to the host only where a file needs them */
+  } else if (want != 0 && !host_encoder && !lossless &&
+             (device_rc = gtamd_device_encode_files_alpha(db, numdb, &alpha, &de, &desc, &desclen, &info,
+                                                          err, errlen)) != GTAMD_DEVICE_DECLINED) {
+    /* tables requested: FASTA, and FASTQ in its four-line form, are read and
+       encoded on the device; the symbols stay in HBM for the engine and come to
+       the host only where a file needs them.  (FASTQ the device reader declines
+       -- sequences over several lines and whatever is malformed -- goes to the
+       host reader below, which has the reference's messages.) */
     reader = "device";
-    if (gtamd_device_encode_files_alpha(db, numdb, &alpha, &de, &desc, &desclen, &info, err, errlen) != 0)
-      return -1;
+    if (device_rc != 0) return -1;
     n = gtamd_encoder_length(de);
     if (gtamd_write_esq_device_alpha(indexname, db, numdb, de, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);

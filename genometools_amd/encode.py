@@ -7,7 +7,9 @@ kernels of csrc/esa_encode.hip (C ABI include/gtamd_encode.h): the symbols stay
 in HBM -- `EsaEngine.set_sequence_device` takes them from there -- and the
 numbers the reference derives while reading come back as a summary.
 
-No CPU implementation here; FASTQ input goes through the C host layer.
+FASTQ in its four-line form is encoded on the device too; other FASTQ the device
+reader declines (`DeviceDeclined`), and the C host layer's reader takes it
+(include/gtamd_host.h).  No CPU implementation here.
 """
 import ctypes
 
@@ -17,8 +19,14 @@ from . import _lib
 from ._lib import EncodeSummary, EsaError
 
 
+class DeviceDeclined(EsaError):
+    """FASTQ input the device reader does not take (include/gtamd_encode.h): the
+    host reader is to read it"""
+
+
 class DeviceEncoder:
-    """encodes (multi-)FASTA files on the device; protein selects the alphabet"""
+    """encodes (multi-)FASTA files, or four-line FASTQ files, on the device; protein
+    selects the alphabet"""
 
     def __init__(self, protein=False, device=0):
         self._lib = _lib.load()
@@ -69,8 +77,20 @@ class DeviceEncoder:
             self._check(self._lib.gtamd_encoder_add_file(
                 self._enc, str(name).encode(), raw.ctypes.data if raw.size else None,
                 raw.size))
-        self._check(self._lib.gtamd_encoder_finish(self._enc))
+        if self._lib.gtamd_encoder_finish(self._enc) != 0:
+            msg = self._lib.gtamd_esa_last_error().decode()
+            raise (DeviceDeclined if self._lib.gtamd_encoder_declined(self._enc) else EsaError)(msg)
         return self
+
+    def fastq_records(self):
+        """(file, sequence length, description length) per FASTQ record, as arrays;
+        empty for FASTA input.  The file length table of FASTQ input is booked
+        from these by the host layer (gtamd_device_encode_files)."""
+        k = self._lib.gtamd_encoder_num_fastq_records(self._enc)
+        out = [np.empty(k, dtype=np.uint32) for _ in range(3)]
+        self._check(self._lib.gtamd_encoder_get_fastq_records(
+            self._enc, out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, k))
+        return tuple(out)
 
     @property
     def length(self):
@@ -97,6 +117,10 @@ class DeviceEncoder:
         return out
 
     def file_lengths(self):
+        """GtFilelengthvalues per FASTA file"""
+        if self._lib.gtamd_encoder_num_fastq_records(self._enc) > 0:
+            raise EsaError("the file length table of FASTQ input is booked per buffer fill: "
+                           "gtamd_device_encode_files (include/gtamd_host.h) makes it")
         out = []
         for i in range(len(self._buffers)):
             a, b = ctypes.c_uint64(), ctypes.c_uint64()

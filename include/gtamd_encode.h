@@ -17,8 +17,15 @@
 
   The reference reads the input byte by byte, twice; here one file is one
   device buffer and every step is a tile-parallel kernel (tile-local state
-  machine + scans over tile summaries).  FASTQ input stays with the host
-  reader (include/gtamd_host.h).
+  machine + scans over tile summaries).  FASTQ input (a file that starts with
+  '@'; src/core/seq_iterator_fastq.c:96-305) is encoded on the device in its
+  STRICT FOUR-LINE form -- name, symbols, '+' line, qualities, one line each,
+  '\n' line ends, no blanks -- where the line number alone says what a byte is;
+  everything else about FASTQ (sequences over several lines, a missing last
+  newline, malformed blocks, FASTA and FASTQ mixed) the device reader DECLINES:
+  gtamd_encoder_finish fails, gtamd_encoder_declined() says why, and the caller
+  hands the input to the host reader (include/gtamd_host.h), which has the
+  reference's behaviour and messages for all of it.
 
   Conventions as in gtamd_esa.h: 0 / -1, message from gtamd_esa_last_error(),
   worded like the reference's ("illegal character 'X': file \"f\", line 3",
@@ -68,6 +75,18 @@ int gtamd_encoder_add_file(gtamd_encoder *enc, const char *name,
 
 /* Encode all files added so far into one sequence. */
 int gtamd_encoder_finish(gtamd_encoder *enc);
+/* 1 if the last gtamd_encoder_finish failed because the input is FASTQ the
+   device reader does not take (see above): not an error of the input, the host
+   reader is to read it. */
+int gtamd_encoder_declined(const gtamd_encoder *enc);
+/* FASTQ input: per record, in input order, the file it came from and the
+   lengths of its sequence and its description -- what the reference's FASTQ
+   reader books into the file length table per buffer fill
+   (src/core/sequence_buffer_fastq.c:42-191).  0 records for FASTA input. */
+uint64_t gtamd_encoder_num_fastq_records(const gtamd_encoder *enc);
+int gtamd_encoder_get_fastq_records(const gtamd_encoder *enc, uint32_t *file,
+                                    uint32_t *seqlen, uint32_t *desclen,
+                                    uint64_t capacity);
 
 /* Instead of add_file/finish: n already encoded symbols from host memory (the
    host reader's output, e.g. of FASTQ input) become the encoder's sequence;

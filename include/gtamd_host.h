@@ -149,14 +149,17 @@ int gtamd_write_esq(const char *indexname, const char *const *paths,
                     char *err, size_t errlen);
 
 /* The same two steps with the device encoder (include/gtamd_encode.h) for
-   FASTA input: the files are read whole and encoded on the GPU; *enc (destroy
+   FASTA input and FASTQ input in the four-line form: the files are read whole and encoded on the GPU; *enc (destroy
    with gtamd_encoder_destroy) holds the symbols in HBM, ready for
    gtamd_esa_set_sequence_bytes(ctx, gtamd_encoder_device_symbols(*enc), n, 1);
    descriptions and file information come back as from gtamd_encode_files_info.
    gtamd_write_esq_device writes INDEX.esq/.ssp from sections packed on the
    device, byte-identical to gtamd_write_esq; *ss (may be NULL) receives the
-   sequence statistics.  gtamd_input_is_fastq: 1 if a file starts with '@'
-   (FASTQ stays with the host reader). */
+   sequence statistics.  gtamd_device_encode_files returns
+   GTAMD_DEVICE_DECLINED (err says why) for FASTQ the device reader does not
+   take: gtamd_encode_files_info then reads it.  gtamd_input_is_fastq: 1 if a
+   file starts with '@'. */
+#define GTAMD_DEVICE_DECLINED (-2)
 int gtamd_input_is_fastq(const char *const *paths, size_t numfiles);
 int gtamd_device_encode_files(const char *const *paths, size_t numfiles,
                               int protein, gtamd_encoder **enc,

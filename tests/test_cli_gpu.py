@@ -179,17 +179,26 @@ def test_cli_several_input_files(cli, key, encoder, tmp_path):
                 assert hashlib.md5(f.read()).hexdigest() == e["seqfiles"][ext]["md5"], ext
 
 
-@pytest.mark.parametrize("name", sorted(n for n in GOLDEN if not n.endswith(".fastq")))
+# FASTQ fixtures not in the four-line form: the device reader declines them
+FASTQ_FOR_THE_HOST = {"test10_multiline.fastq", "test5_tricky.fastq"}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
 def test_cli_device_and_host_reader_write_the_same_index(cli, name, tmp_path):
-    """every FASTA fixture through both readers; the device path (default) is
-    the one compared with the reference's sequence-side files"""
+    """every fixture through both readers; the device path (default) is the one
+    compared with the reference's sequence-side files.  FASTQ in the four-line
+    form is read on the device, the rest of FASTQ on the host (the tool says
+    which reader it was)"""
     e = GOLDEN[name]
     src = ou.fixture_path(name)
     out = {}
     for encoder in ("device", "host"):
         idx = str(tmp_path / encoder)
-        subprocess.run([cli, "-" + e["alphabet"], "-suf", "-encoder", encoder, "-indexname", idx,
-                        "-db", os.path.basename(src)], check=True, cwd=os.path.dirname(src))
+        r = subprocess.run([cli, "-" + e["alphabet"], "-suf", "-v", "-encoder", encoder, "-indexname",
+                            idx, "-db", os.path.basename(src)], check=True, cwd=os.path.dirname(src),
+                           stdout=subprocess.PIPE, text=True)
+        used = "host" if encoder == "host" or name in FASTQ_FOR_THE_HOST else "device"
+        assert "(%s reader)" % used in r.stdout
         out[encoder] = {ext: hashlib.md5(open(idx + "." + ext, "rb").read()).hexdigest()
                         for ext in ("suf", "prj", "des", "sds", "md5", "esq", "ssp")
                         if os.path.exists(idx + "." + ext)}

@@ -242,3 +242,141 @@ def test_capacity_is_checked(gpu, tmp_path):
         assert (sep == guard).all()
         assert lib.gtamd_encoder_get_separators(de._enc, sep.ctypes.data, 23) == 0
         assert np.array_equal(sep, np.flatnonzero(enc == 255).astype(np.uint64))
+
+
+# ---- FASTQ on the device -----------------------------------------------------
+def _device_encode_via_host(host, paths, protein):
+    """gtamd_device_encode_files (include/gtamd_host.h): the host layer's use of
+    the device reader, with the file length table booked as the reference's FASTQ
+    reader does; returns None if the device reader declined"""
+    arr = (ctypes.c_char_p * len(paths))(*[p.encode() for p in paths])
+    de = ctypes.c_void_p()
+    dptr, dlen = ctypes.c_void_p(), ctypes.c_uint64()
+    info = EncInfo()
+    err = ctypes.create_string_buffer(2048)
+    host.gtamd_device_encode_files.restype = ctypes.c_int
+    rc = host.gtamd_device_encode_files(arr, len(paths), int(protein), ctypes.byref(de),
+                                        ctypes.byref(dptr), ctypes.byref(dlen), ctypes.byref(info),
+                                        err, 2048)
+    if rc == -2:
+        return None
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    from genometools_amd import _lib
+    lib = _lib.load()
+    n = lib.gtamd_encoder_length(de)
+    enc = np.empty(n, dtype=np.uint8)
+    assert lib.gtamd_encoder_copy_symbols(de, enc.ctypes.data, 0, n) == 0
+    desc = ctypes.string_at(dptr, dlen.value).split(b"\0")[:-1]
+    fl = np.ctypeslib.as_array(ctypes.cast(info.filelengthtab, ctypes.POINTER(ctypes.c_uint64)),
+                               shape=(2 * len(paths),)).copy().reshape(-1, 2)
+    orig = list(info.originaldistribution)
+    host.gtamd_encinfo_free(ctypes.byref(info))
+    lib.gtamd_encoder_destroy(de)
+    ctypes.CDLL(None).free(dptr)
+    return enc, desc, orig, [tuple(int(x) for x in row) for row in fl]
+
+
+def _fastq(rng, nrec, minlen, maxlen, alphabet="ACGTNacgtn", plusname=0.3):
+    out = []
+    for k in range(nrec):
+        ln = int(rng.integers(minlen, maxlen + 1))
+        name = b"r%d len=%d @x +y" % (k, ln) if k % 7 else b""
+        seq = "".join(rng.choice(list(alphabet), size=ln)).encode()
+        # qualities may start with '@' or '+' and contain any printable character
+        qual = bytes(rng.integers(33, 127, size=ln, dtype=np.uint8))
+        if k % 3 == 0:
+            qual = b"@" + qual[1:]
+        elif k % 3 == 1:
+            qual = b"+" + qual[1:]
+        out.append(b"@" + name + b"\n" + seq + b"\n+" + (name if rng.random() < plusname else b"") +
+                   b"\n" + qual + b"\n")
+    return b"".join(out)
+
+
+FASTQ_STRICT = [[ou.fixture_path("test1.fastq")], [ou.fixture_path("fastq_long.fastq")],
+                [os.path.join(ou.GOLDEN_DIR, "multi", "long_reads.fastq")],
+                [os.path.join(ou.GOLDEN_DIR, "multi", f) for f in ("reads_a.fastq", "reads_b.fastq")],
+                [os.path.join(ou.GOLDEN_DIR, "multi", f) for f in ("reads_b.fastq", "reads_a.fastq",
+                                                                   "reads_b.fastq")]]
+
+
+@pytest.mark.parametrize("paths", FASTQ_STRICT, ids=lambda p: "+".join(os.path.basename(x) for x in p))
+def test_device_fastq_reader_matches_host_reader(gpu, host, paths):
+    """symbols, descriptions, original characters and the file length table (booked
+    per 8192-symbol buffer fill, src/core/sequence_buffer_fastq.c:42-191) of the
+    reference's fixtures"""
+    got = _device_encode_via_host(host, paths, False)
+    assert got is not None
+    want = _host_encode(host, paths, False)
+    assert np.array_equal(got[0], want[0])
+    assert got[1:] == want[1:]
+
+
+def test_device_fastq_reader_generated_files(gpu, host, tmp_path):
+    """records around the tile size of the kernels (4096 bytes) and the buffer size
+    of the reference's reader (8192 symbols); '@' and '+' leading quality lines;
+    empty names; repeated names on the '+' line; several files"""
+    rng = np.random.default_rng(11)
+    shapes = [(1, 1, 1), (5, 1, 3), (3, 4090, 4100), (40, 8185, 8200), (2000, 30, 250),
+              (7, 20000, 30000), (300, 1, 2)]
+    paths = []
+    for i, (nrec, lo, hi) in enumerate(shapes):
+        p = tmp_path / ("g%d.fastq" % i)
+        p.write_bytes(_fastq(rng, nrec, lo, hi))
+        paths.append(str(p))
+        got = _device_encode_via_host(host, [str(p)], False)
+        want = _host_encode(host, [str(p)], False)
+        assert got is not None and np.array_equal(got[0], want[0]), shapes[i]
+        assert got[1:] == want[1:], shapes[i]
+    got = _device_encode_via_host(host, paths, False)
+    want = _host_encode(host, paths, False)
+    assert got is not None and np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    # protein
+    p = tmp_path / "p.fastq"
+    p.write_bytes(_fastq(rng, 50, 10, 500, alphabet="ACDEFGHIKLMNPQRSTVWYXBZ"))
+    got, want = _device_encode_via_host(host, [str(p)], True), _host_encode(host, [str(p)], True)
+    assert got is not None and np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    # the summary over FASTQ symbols, and the encoder's own interface
+    with encode.DeviceEncoder() as de:
+        de.encode(paths[:3])
+        s, sym = de.summary(), de.symbols()
+        file, seqlen, desclen = de.fastq_records()
+        assert file.size == sum(sh[0] for sh in shapes[:3]) and s["numofsequences"] == file.size
+        assert int(seqlen.sum()) + file.size - 1 == de.length
+        assert [len(d) for d in de.descriptions()] == desclen.tolist()
+    for k, v in _expected_summary(sym, 4).items():
+        assert s[k] == v, k
+
+
+def test_device_fastq_reader_declines_what_is_not_four_lines(gpu, host, tmp_path):
+    """... and the host reader then reads it, or has the reference's message"""
+    ok = b"@a\nACGT\n+\nIIII\n"
+    cases = {
+        "multiline": b"@a\nAC\nGT\n+\nII\nII\n",
+        "no_last_newline": b"@a\nACGT\n+\nIIII",
+        "crlf": b"@a\r\nACGT\r\n+\r\nIIII\r\n",
+        "blank_in_sequence": b"@a\nAC GT\n+\nIIII\n",
+        "blank_in_qualities": b"@a\nACGT\n+\nII II\n",
+        "short_qualities": ok + b"@b\nACGT\n+\nIII\n",
+        "long_qualities": b"@a\nACGT\n+\nIIIII\n" + ok,
+        "other_name": b"@a\nACGT\n+b\nIIII\n",
+        "illegal_symbol": ok + b"@b\nACXT\n+\nIIII\n",
+        "empty_sequence": b"@a\n\n+\n\n",
+        "no_at": ok + b"b\nACGT\n+\nIIII\n",
+        "no_plus": b"@a\nACGT\nIIII\nIIII\n",
+        "three_lines": ok + b"@b\nACGT\n+\n",
+        "blank_line_between": ok + b"\n" + ok,
+    }
+    for name, raw in cases.items():
+        p = tmp_path / (name + ".fastq")
+        p.write_bytes(raw)
+        assert _device_encode_via_host(host, [str(p)], False) is None, name
+        with pytest.raises(encode.DeviceDeclined):
+            encode.DeviceEncoder().encode([str(p)])
+    # FASTA and FASTQ in one run stay with the host reader too
+    q, a = tmp_path / "ok.fastq", tmp_path / "ok.fna"
+    q.write_bytes(ok)
+    a.write_bytes(b">x\nACGT\n")
+    assert _device_encode_via_host(host, [str(q), str(a)], False) is None
+    assert _device_encode_via_host(host, [str(q)], False) is not None

@@ -52,7 +52,8 @@ class EsaStats(ctypes.Structure):
                 ("pair_suffixes", ctypes.c_uint64),
                 ("device_bytes", ctypes.c_uint64),
                 ("msd_big_entries", ctypes.c_uint64),
-                ("msd_crowded_entries", ctypes.c_uint64)]
+                ("msd_crowded_entries", ctypes.c_uint64),
+                ("rank_entries_built", ctypes.c_uint64)]
 
 
 class EsaTiming(ctypes.Structure):

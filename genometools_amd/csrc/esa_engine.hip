@@ -1344,11 +1344,15 @@ __global__ __launch_bounds__(256) void k_heads(
 constexpr int RW_BITS = 15;
 constexpr int RW_THREADS = 1024;
 
-// winlist != nullptr: only some windows are built (see below); bucket k of the
-// partitioned pairs is window winlist[k]
+// winlist != nullptr: only some windows are built (see below) -- windows of 2^fb
+// positions, renumbered in ascending order to "compact positions" (k_win_filter):
+// bucket k of the partitioned pairs holds the compact positions [k << wb, ...), i.e.
+// the selected windows k << (wb - fb) ... of the list, and every one of them goes
+// to its own place in the table
 __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
     const u32 *__restrict__ pos, const u32 *__restrict__ heads, u64 N, int wb,
-    int split, u32 nbuckets, u32 *__restrict__ rank, const u32 *__restrict__ winlist) {
+    int split, u32 nbuckets, u32 *__restrict__ rank, const u32 *__restrict__ winlist,
+    int fb, u32 nfine, u64 M) {
   __shared__ u32 s_win[1 << RW_BITS];
   u32 bucket = blockIdx.x, half = 0;
   if (split == 2) {
@@ -1358,11 +1362,11 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
   if (bucket >= nbuckets) return;   // whole workgroup
   const int sb = wb - (split == 2 ? 1 : 0);   // position bits inside a window
   const u32 smask = (1u << sb) - 1u;
-  const u64 in_first = (u64) bucket << wb;                 // where the window's pairs are
-  const u64 first = (u64) (winlist != nullptr ? winlist[bucket] : bucket) << wb;
-  const u64 end = first + (1ull << wb) < N ? first + (1ull << wb) : N;
+  const u64 first = (u64) bucket << wb;                    // where the window's pairs are
+  const u64 total = winlist != nullptr ? M : N;
+  const u64 end = first + (1ull << wb) < total ? first + (1ull << wb) : total;
   const u64 cnt = end - first;
-  const u32 *bp = pos + in_first, *bh = heads + in_first;
+  const u32 *bp = pos + first, *bh = heads + first;
   // four pairs per lane and step while whole groups are left (first is a
   // multiple of 4 whenever wb >= 2; both arrays are 16-byte aligned then)
   const u64 cnt4 = (wb >= 2) ? (cnt & ~3ull) : 0;
@@ -1380,7 +1384,29 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
   }
   __syncthreads();
   const u64 wfirst = first + ((u64) half << sb);
-  if (wfirst >= N) return;
+  if (wfirst >= total) return;
+  if (winlist != nullptr) {
+    // (fb <= sb: whole selected windows; the last window of the text may be short)
+    const u32 f0 = (u32) (wfirst >> fb), fmask = (1u << fb) - 1u;
+    if (fb >= 2) {
+      for (u32 i = threadIdx.x * 4u; i < (1u << sb); i += RW_THREADS * 4u) {
+        const u32 fw = f0 + (i >> fb);
+        if (fw >= nfine) break;
+        const u64 dst = ((u64) winlist[fw] << fb) + (i & fmask);
+        if (dst + 4 <= N) *reinterpret_cast<uint4 *>(rank + dst) = *reinterpret_cast<const uint4 *>(s_win + i);
+        else
+          for (int g = 0; g < 4 && dst + g < N; g++) rank[dst + g] = s_win[i + g];
+      }
+    } else {
+      for (u32 i = threadIdx.x; i < (1u << sb); i += RW_THREADS) {
+        const u32 fw = f0 + (i >> fb);
+        if (fw >= nfine) break;
+        const u64 dst = ((u64) winlist[fw] << fb) + (i & fmask);
+        if (dst < N) rank[dst] = s_win[i];
+      }
+    }
+    return;
+  }
   const u64 wend = wfirst + (1ull << sb) < N ? wfirst + (1ull << sb) : N;
   const u64 wcnt = wend - wfirst;
   u32 *out = rank + wfirst;
@@ -1393,12 +1419,20 @@ __global__ __launch_bounds__(RW_THREADS) void k_rank_window(
 // Only the windows the doubling rounds can touch are built.  After the pair
 // path the suffixes still tied are a small part of the text (1.7 % of the
 // human-like 3 Gbp: high-copy repeat families), and a round reads rank[p + h]
-// and writes rank[p] for those suffixes p only -- positions that cluster in a
-// fifth of the 64 K-position windows.  So: mark the windows of p .. p + H for
-// the first rounds' offsets, keep the (position, head) pairs of marked windows
-// (one streaming pass over the suffix array), partition and scatter only
-// those.  A later round whose offset reaches an unbuilt window has it built
-// first (k_win_check; never happens while h <= H).  38 -> 13 ms at 3 Gbp.
+// and writes rank[p] for those suffixes p only -- positions that cluster: in
+// half of the windows of 64 K positions, but in a fourteenth of the windows of
+// 8 K (RW_FINE).  So: mark the windows of p .. p + H for the first rounds'
+// offsets, keep the (position, head) pairs of marked windows (one streaming
+// pass over the suffix array), partition and scatter only those.  The
+// granularity of the selection is independent of the size of the LDS window:
+// the positions of the selected windows are renumbered densely ("compact
+// positions": number of the window in the list << fb | offset inside), the
+// partition and the LDS scatter work on those, and k_rank_window sends every
+// window of 2^fb entries to its place in the table.  A later round whose offset
+// reaches an unbuilt window has it built first (k_win_check; never happens
+// while h <= H).  Whole table 38 ms -> windows of 64 K 20 ms -> of 8 K 6 ms at
+// 3 Gbp.
+constexpr int RW_FINE = 13;
 template <typename P>
 __global__ __launch_bounds__(256) void k_win_mark(const P *__restrict__ upos, u64 m, u64 lo,
                                                   u64 hi, int wb, u64 nwin,
@@ -1429,12 +1463,13 @@ __global__ __launch_bounds__(256) void k_win_check(const P *__restrict__ upos, u
 }
 
 // one workgroup: the windows that are needed and not built yet, in ascending
-// order (winlist), as a bitmap (sel), their number; they count as built from
-// here on
+// order (winlist), as a bitmap (sel) with the number of selected windows before
+// every word (pref), their number; they count as built from here on
 __global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ need,
                                                      u32 *__restrict__ built, u64 nwords,
                                                      u32 *__restrict__ sel,
-                                                     u32 *__restrict__ winlist, Stats *stats) {
+                                                     u32 *__restrict__ winlist,
+                                                     u32 *__restrict__ pref, Stats *stats) {
   __shared__ u32 s_scan[16];
   const u64 per = (nwords + 1023) / 1024;
   const u64 w0 = (u64) threadIdx.x * per;
@@ -1446,6 +1481,7 @@ __global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ nee
   for (u64 w = w0; w < w1; w++) {
     u32 x = need[w] & ~built[w];
     sel[w] = x;
+    pref[w] = at;        // selected windows before this word
     built[w] |= x;
     while (x) {
       const int b = __ffs(x) - 1;
@@ -1458,87 +1494,137 @@ __global__ __launch_bounds__(1024) void k_win_select(const u32 *__restrict__ nee
 
 // entries of the suffix array whose position lies in a selected window, together
 // with the heads of their tie groups, in any order (they are partitioned by
-// position next): a workgroup walks WF_TILES tiles of 4096 entries and reserves
-// room for each tile's entries with one atomic on the list's cursor
+// position next).  A workgroup walks WF_ITER spans of 16384 entries:
+//  * every lane loads four consecutive entries per step (the wave reads 1 KB in
+//    one piece), all loads of a span are issued before the first is used;
+//  * the bitmap of the selected windows is in LDS (LSEL; 45 KB for the windows of
+//    8 K positions of a 3 Gbp text): 3 G look-ups at random words through the
+//    vector memory path cost 6 ms at one lane per cycle, from LDS they disappear
+//    behind the loads (tools/microbench/winfilter.hip: read only 1.8 ms, with
+//    global look-ups 7.7, with LDS look-ups 1.8);
+//  * the selected entries of a span go through a queue in LDS and leave it one per
+//    thread: dense stores, no idle lanes, nothing loaded twice -- with the entries
+//    written where the threads found them (a lane has one selected entry of sixteen)
+//    every 4-byte store went to memory as a write of its own (14 GB written for
+//    1.7 GB of entries, PMC) and the kernel took 9-12 ms instead of 3.5;
+//  * one atomic on the list's cursor per span reserves the room.
+// P: positions of 32 bits, or of 64 (part builds of n >= 2^32); cap: room in the
+// list -- a workgroup that would write behind it stops and sets stats->count2 (the
+// caller takes another way then); pref != nullptr: the list gets compact positions
+// (see k_rank_window) instead of positions.
 constexpr int WF_THREADS = 1024;
 constexpr int WF_Q = 4;                                   // uint4 loads per thread
-constexpr u64 WF_SPAN = (u64) WF_THREADS * 4 * WF_Q;      // 16384 entries per workgroup
-
-// (64 registers, not 67: two workgroups of 1024 threads fit a CU, so one computes
-// while the other waits for its loads or for the cursor)
-// P: positions of 32 bits, or of 64 (part builds of n >= 2^32); cap: room in the
-// list -- a workgroup that would write behind it writes nothing and sets
-// stats->count2 (the caller takes another way then)
+constexpr u64 WF_SPAN = (u64) WF_THREADS * 4 * WF_Q;      // 16384 entries
+constexpr int WF_ITER = 8;
+constexpr int WF_QUEUE = 2048;                            // entries of the queue
+constexpr u64 WF_LDS_MAX = 60 * 1024;      // bitmap + prefix counts a workgroup takes to LDS
 template <typename P>
+__device__ __forceinline__ void wf_load4(const P *__restrict__ sa, u64 i0, u64 NL, P v[4]) {
+  if (i0 + 4 <= NL) {
+    if (sizeof(P) == 4) {
+      const uint4 x = *reinterpret_cast<const uint4 *>(sa + i0);
+      v[0] = (P) x.x; v[1] = (P) x.y; v[2] = (P) x.z; v[3] = (P) x.w;
+    } else {
+      const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(sa + i0);
+      const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(sa + i0 + 2);
+      v[0] = (P) v0.x; v[1] = (P) v0.y; v[2] = (P) v1.x; v[3] = (P) v1.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = i0 + k < NL ? sa[i0 + k] : (P) 0;
+  }
+}
+// dynamic LDS: [LSEL: bitmap padded to groups of four words | selected windows before
+// every group] | queue of positions | queue of indices inside the span
+template <typename P>
+static size_t wf_lds_bytes(u64 nww, bool lsel) {
+  const u64 nww4 = (nww + 3) & ~3ull;
+  return (size_t) ((lsel ? nww4 * 4 + nww4 : 0) + 16 + WF_QUEUE * (sizeof(P) + 2));
+}
+template <typename P, bool LSEL>
 __global__ __launch_bounds__(WF_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_win_filter(
-    const P *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel,
-    const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
+    const P *__restrict__ sa, u64 NL, int wb, const u32 *__restrict__ sel, u32 nww,
+    const u32 *__restrict__ pref, const u64 *__restrict__ tiebits, const u32 *__restrict__ carry,
     P *__restrict__ fpos, u32 *__restrict__ fhead, u64 cap, Stats *stats) {
-  // One walk.  Every lane loads four consecutive entries per step (the wave
-  // reads 1 KB in one piece), all steps' loads are issued before the first is
-  // used; ONE atomic per 16384 entries reserves the workgroup's room in the
-  // list (one per 4096 entries was an 8.7 ms queue on the cursor's address).
+  extern __shared__ __attribute__((aligned(16))) u32 s_dyn[];
   __shared__ u32 s_scan[WF_THREADS / 64];
   __shared__ u32 s_base;
-  const u64 first = (u64) blockIdx.x * WF_SPAN;
-  P p[WF_Q][4];
-  u32 mask[WF_Q];
-#pragma unroll
-  for (int q = 0; q < WF_Q; q++) {
-    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
-    if (i0 + 4 <= NL) {
-      if (sizeof(P) == 4) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(sa + i0);
-        p[q][0] = (P) v.x; p[q][1] = (P) v.y; p[q][2] = (P) v.z; p[q][3] = (P) v.w;
-      } else {
-        const ulonglong2 v0 = *reinterpret_cast<const ulonglong2 *>(sa + i0);
-        const ulonglong2 v1 = *reinterpret_cast<const ulonglong2 *>(sa + i0 + 2);
-        p[q][0] = (P) v0.x; p[q][1] = (P) v0.y; p[q][2] = (P) v1.x; p[q][3] = (P) v1.y;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) p[q][k] = i0 + k < NL ? sa[i0 + k] : (P) 0;
-    }
+  const u32 nww4 = (nww + 3u) & ~3u;
+  u32 *s_sel = s_dyn, *s_pref4 = s_dyn + nww4;
+  P *s_qpos = reinterpret_cast<P *>(s_dyn + (LSEL ? nww4 + nww4 / 4 : 0u) + ((LSEL ? nww4 / 4 : 0u) & 1u));
+  unsigned short *s_qidx = reinterpret_cast<unsigned short *>(s_qpos + WF_QUEUE);
+  if (LSEL) {
+    for (u32 i = threadIdx.x; i < nww4; i += WF_THREADS) s_sel[i] = i < nww ? sel[i] : 0u;
+    if (pref != nullptr)
+      for (u32 i = threadIdx.x; i < nww4 / 4; i += WF_THREADS) s_pref4[i] = pref[4 * i];
+    __syncthreads();
   }
-  u32 mine = 0;
+  const u32 *selw = LSEL ? s_sel : sel;
+  for (int it = 0; it < WF_ITER; it++) {
+    const u64 first = ((u64) blockIdx.x * WF_ITER + it) * WF_SPAN;
+    if (first >= NL) break;       // (whole workgroup)
+    P p[WF_Q][4];
 #pragma unroll
-  for (int q = 0; q < WF_Q; q++) {
-    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
+    for (int q = 0; q < WF_Q; q++)
+      wf_load4(sa, first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4, NL, p[q]);
     u32 m = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const u32 w = (u32) (p[q][k] >> wb);      // (2^40 positions, windows of >= 2^16)
-      if (i0 + k < NL) m |= ((sel[w >> 5] >> (w & 31)) & 1u) << k;
-    }
-    mask[q] = m;
-    mine += (u32) __popc(m);
-  }
-  u32 tot;
-  u32 o = block_scan_excl<SCAN_SUM, WF_THREADS>(mine, &tot, s_scan);
-  if (threadIdx.x == 0) {
-    u32 b = tot ? atomicAdd(&stats->count, tot) : 0u;
-    if ((u64) b + tot > cap) { stats->count2 = 1u; b = ~0u; }
-    s_base = b;
-  }
-  __syncthreads();
-  if (s_base == ~0u) return;
-  o += s_base;
+    for (int q = 0; q < WF_Q; q++) {
+      const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
 #pragma unroll
-  for (int q = 0; q < WF_Q; q++) {
-    if (mask[q] == 0) continue;
-    const u64 i0 = first + (u64) q * (WF_THREADS * 4) + (u64) threadIdx.x * 4;
-    // the heads of the tie groups: the four entries share a bitmap word; head of
-    // an entry = head of the one before unless it starts a group
-    const u64 t = tiebits[i0 >> 6];
-    u32 h = group_head(tiebits, carry, i0);
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (k > 0 && !((t >> ((i0 + k) & 63)) & 1ull)) h = (u32) (i0 + k);
-      if ((mask[q] >> k) & 1u) {
-        fpos[o] = p[q][k];
-        fhead[o] = h;
-        o++;
+      for (int k = 0; k < 4; k++) {
+        const u32 w = (u32) (p[q][k] >> wb);      // (2^40 positions, windows of >= 2^13)
+        if (i0 + k < NL) m |= ((selw[w >> 5] >> (w & 31)) & 1u) << (4 * q + k);
       }
+    }
+    u32 tot;
+    const u32 excl = block_scan_excl<SCAN_SUM, WF_THREADS>((u32) __popc(m), &tot, s_scan);
+    if (threadIdx.x == 0) {
+      u32 b = tot ? atomicAdd(&stats->count, tot) : 0u;
+      if ((u64) b + tot > cap) { stats->count2 = 1u; b = ~0u; }
+      s_base = b;
+    }
+    for (u32 r0 = 0; r0 < tot; r0 += WF_QUEUE) {      // (one round unless a span has many)
+      u32 o = excl - r0;          // (wraps for the entries of earlier rounds: then o >= WF_QUEUE)
+#pragma unroll
+      for (int q = 0; q < WF_Q; q++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if ((m >> (4 * q + k)) & 1u) {
+            if (o < (u32) WF_QUEUE) {
+              s_qpos[o] = p[q][k];
+              s_qidx[o] = (unsigned short) (q * (WF_THREADS * 4) + threadIdx.x * 4 + k);
+            }
+            o++;
+          }
+      }
+      __syncthreads();
+      if (s_base == ~0u) return;          // (whole workgroup)
+      const u32 nq = tot - r0 < (u32) WF_QUEUE ? tot - r0 : (u32) WF_QUEUE;
+      const u64 base = (u64) s_base + r0;
+      for (u32 j = threadIdx.x; j < nq; j += WF_THREADS) {
+        P v = s_qpos[j];
+        if (pref != nullptr) {
+          // the compact position: windows before this one in the list | offset
+          const u32 w = (u32) (v >> wb), x = w >> 5;
+          u32 d;
+          if (LSEL) {
+            // (prefix counts of every fourth word; the words between by popcount)
+            const uint4 g = *reinterpret_cast<const uint4 *>(s_sel + (x & ~3u));
+            const u32 low = (1u << (w & 31)) - 1u, jj = x & 3u;
+            d = s_pref4[x >> 2] + (u32) __popc(g.x & (jj == 0 ? low : ~0u)) +
+                (u32) __popc(g.y & (jj == 1 ? low : (jj > 1 ? ~0u : 0u))) +
+                (u32) __popc(g.z & (jj == 2 ? low : (jj > 2 ? ~0u : 0u))) +
+                (u32) __popc(g.w & (jj == 3 ? low : 0u));
+          } else {
+            d = pref[x] + (u32) __popc(sel[x] & ((1u << (w & 31)) - 1u));
+          }
+          v = (P) (((u64) d << wb) | ((u64) v & ((1ull << wb) - 1ull)));
+        }
+        fpos[base + j] = v;
+        fhead[base + j] = group_head(tiebits, carry, first + s_qidx[j]);
+      }
+      __syncthreads();
     }
   }
 }
@@ -3917,7 +4003,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     for (u32 r = 0; r < R; r++) anyties += all[r];
   }
   u32 rounds = 0;
-  u64 m0 = 0, npairs = 0, m0_tied_all = 0;
+  u64 m0 = 0, npairs = 0, m0_tied_all = 0, rank_built = 0;
   HIP_TRY(hipEventRecord(c->ev[4], st));
   HIP_TRY(hipEventRecord(c->ev[5], st));
   if (anyties > 0) {
@@ -4353,31 +4439,35 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         return -1;
       }
       const int split = wb > wmax ? 2 : 1;
-      rk_wb = wb;
-      rk_nwin = div_up(N, 1ull << wb);
+      // the windows that are selected are finer than the windows the LDS takes
+      const int fb = wmax < RW_FINE ? wmax : RW_FINE;
+      rk_wb = fb;
+      rk_nwin = div_up(N, 1ull << fb);
       const u64 nww = rk_nwin / 32 + 2;
       const char *we = getenv("GTAMD_RANK_ALL_WINDOWS");           // A/B switch
       const bool all_windows = (we != nullptr && we[0] == '1') || pb == 0;
+      u32 *w_pref = nullptr;
       if (!all_windows) {
-        TRY(ensure_buf(c, c->winbuf, (3 * nww + rk_nwin + 16) * 4, "the rank windows"));
+        TRY(ensure_buf(c, c->winbuf, (4 * nww + rk_nwin + 16) * 4, "the rank windows"));
         w_need = c->winbuf.as<u32>(); w_built = w_need + nww; w_sel = w_built + nww;
-        w_list = w_sel + nww;
+        w_pref = w_sel + nww;
+        w_list = w_pref + nww;
         HIP_TRY(hipMemsetAsync(w_need, 0, 2 * nww * 4, st));
-        // offsets of the first rounds, as far as three windows reach
+        // offsets of the first rounds
         rk_h0 = (u64) K::KNOWN << 9;
         if (rk_h0 > (3ull << wb)) rk_h0 = 3ull << wb;
         if (m0 > 0) {
-          k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, wb, rk_nwin,
+          k_win_mark<P><<<(u32) div_up(m0, 256), 256, 0, st>>>(upos, m0, 0, rk_h0, fb, rk_nwin,
                                                               w_need);
           HIP_TRY(hipGetLastError());
         }
         rk_windows = true;
       }
       const GroupHeadValues headgen = {tiebits2, carry, nwords, 0u};
-      build_rank = [=, &rk_windows](bool first) -> int {
+      build_rank = [=, &rk_windows, &rank_built](bool first) -> int {
         u64 nsel = 0;
         if (rk_windows) {
-          k_win_select<<<1, 1024, 0, st>>>(w_need, w_built, nww, w_sel, w_list, c->d_stats);
+          k_win_select<<<1, 1024, 0, st>>>(w_need, w_built, nww, w_sel, w_list, w_pref, c->d_stats);
           HIP_TRY(hipGetLastError());
           TRY(fetch_stats(c));
           nsel = c->h_stats->count;
@@ -4385,7 +4475,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           if (first && nsel * 2 > rk_nwin) rk_windows = false;   // most of the text: all of it
           if (debug)
             fprintf(stderr, "gtamd: rank table: %llu of %llu windows of 2^%d positions%s\n",
-                    (unsigned long long) nsel, (unsigned long long) rk_nwin, wb,
+                    (unsigned long long) nsel, (unsigned long long) rk_nwin, fb,
                     rk_windows ? "" : " -> whole table");
         }
         if (!rk_windows) {
@@ -4415,31 +4505,50 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
           const u32 nbuckets = (u32) div_up(NL, 1ull << wb);
           const u32 grid = split == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
           k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, NL, wb, split, nbuckets, rank32,
-                                                     nullptr);
+                                                     nullptr, 0, 0u, 0);
           HIP_TRY(hipGetLastError());
+          rank_built = NL;
           return 0;
         }
-        // the pairs of the selected windows, partitioned by window
+        // the pairs of the selected windows, with compact positions, partitioned down
+        // to the windows the LDS takes
         HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 4, st));
-        k_win_filter<u32><<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
-            spos, NL, wb, w_sel, tiebits2, carry, ppos, phead, ~0ull, c->d_stats);
+        if ((nww + 4) * 5 <= WF_LDS_MAX) {
+          // (more than the 64 KB a kernel gets without asking)
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_win_filter<u32, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int) wf_lds_bytes<u32>(nww, true)));
+          k_win_filter<u32, true><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<u32>(nww, true), st>>>(
+              spos, NL, fb, w_sel, (u32) nww, w_pref, tiebits2, carry, ppos, phead, ~0ull, c->d_stats);
+        } else
+          k_win_filter<u32, false><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<u32>(nww, false), st>>>(
+              spos, NL, fb, w_sel, (u32) nww, w_pref, tiebits2, carry, ppos, phead, ~0ull, c->d_stats);
         HIP_TRY(hipGetLastError());
         TRY(fetch_stats(c));
         const u64 M = c->h_stats->count;   // nsel windows (the last one of the text is short)
+        if (M == 0) return 0;
+        rank_built += M;
+        int mb = bits_for(((u64) nsel << fb) - 1);
+        if (mb < fb) mb = fb;
+        int pbm = mb > wmax ? mb - wmax : 0;
+        if (pbm > 16) pbm = 16;
+        const int wbm = mb - pbm;          // (<= wmax + 1, as mb <= nb)
+        const int splitm = wbm > wmax ? 2 : 1;
         const u32 *wpos = ppos, *whead = phead;
-        if (pb > 8) {
-          const int s0 = nb - pb, w0 = pb - 8, s1 = nb - 8, w1 = 8;
+        if (pbm > 8) {
+          const int s0 = mb - pbm, w0 = pbm - 8, s1 = mb - 8, w1 = 8;
           TRY(radix_partition_u32(ppos, phead, qpos, qhead, M, s0, w0, pws, st));
           TRY(radix_sort_pairs<u32, u32>(qpos, qhead, ppos, phead, M, &s1, &w1, 1, pws, st,
                                          nullptr, nullptr));
-        } else {
-          const int s0 = nb - pb, w0 = pb;
+        } else if (pbm > 0) {
+          const int s0 = mb - pbm, w0 = pbm;
           TRY(radix_partition_u32(ppos, phead, qpos, qhead, M, s0, w0, pws, st));
           wpos = qpos; whead = qhead;
         }
-        const u32 grid = split == 2 ? (((u32) nsel + 7u) / 8u) * 16u : (u32) nsel;
-        k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, N, wb, split, (u32) nsel, rank32,
-                                                   w_list);
+        const u32 nbuckets = (u32) div_up(M, 1ull << wbm);
+        const u32 grid = splitm == 2 ? ((nbuckets + 7u) / 8u) * 16u : nbuckets;
+        k_rank_window<<<grid, RW_THREADS, 0, st>>>(wpos, whead, N, wbm, splitm, nbuckets, rank32,
+                                                   w_list, fb, (u32) nsel, M);
         HIP_TRY(hipGetLastError());
         return 0;
       };
@@ -4530,8 +4639,8 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         u64 M = 0;
         if (!fail && d_sel != nullptr && NL > 0 && list_cap > 0) {
           HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 8, st));     // count, count2
-          k_win_filter<P><<<(u32) div_up(NL, WF_SPAN), WF_THREADS, 0, st>>>(
-              sa, NL, rk_wb, d_sel, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
+          k_win_filter<P, false><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<P>(0, false), st>>>(
+              sa, NL, rk_wb, d_sel, 0u, nullptr, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
           HIP_TRY(hipGetLastError());
           TRY(fetch_stats(c));
           listed = c->h_stats->count2 == 0;
@@ -4946,6 +5055,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
   c->timing.scatter_read_items = c->timing.scatter_items;
   c->timing.scatter_written_items = msd ? msd_local - c->h_stats->crowded : NL;
   c->stats.msd_crowded_entries = msd ? c->h_stats->crowded : 0;
+  c->stats.rank_entries_built = rank_built;
   c->timing.dominant_kernel = msd ? 1u : 0u;
   c->timing.alloc_ms = c->alloc_ms;
   c->want = want;

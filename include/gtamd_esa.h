@@ -79,6 +79,10 @@ typedef struct {
      fallback because one bin of its counting pass was crowded */
   uint64_t msd_big_entries;
   uint64_t msd_crowded_entries;
+  /* rank table of the doubling rounds (single builds): entries of the table that
+     were built -- the windows of positions the rounds can touch -- of n + 1; 0
+     if no round was needed */
+  uint64_t rank_entries_built;
 } gtamd_esa_stats;
 
 /* per-stage device time of the last run, measured with HIP events on the

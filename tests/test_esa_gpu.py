@@ -325,6 +325,30 @@ def test_rank_table_window_shapes(gpu, monkeypatch, wbits, n):
     _assert_same_as_oracle(enc, 4, res)
 
 
+@pytest.mark.parametrize("wbits,n,later", [(15, 3_000_000, False), (8, 600_000, False), (4, 600_000, False),
+                                           (10, 900_000, True), (5, 900_000, True)])
+def test_rank_table_of_selected_windows(gpu, monkeypatch, wbits, n, later):
+    """only the windows of positions the rounds can touch are built (k_win_mark,
+    k_win_filter with compact positions, k_rank_window per selected window): a random
+    text with a few blocks in several copies -- the tied suffixes lie in a small part
+    of the text; `later`: copies longer than the first rounds reach, so that windows
+    are added between rounds (k_win_check); the last window of the text among them"""
+    monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", str(wbits))
+    monkeypatch.setenv("GTAMD_NO_PAIRS", "1")
+    rng = np.random.default_rng(wbits * 1000 + n % 997)
+    enc = rng.integers(0, 4, size=n).astype(np.uint8)
+    blk = 40_000 if later else 3_000
+    src = enc[1000:1000 + blk].copy()
+    for at in (n // 3, n // 2 + 17, n - blk):        # (the last copy ends the text)
+        enc[at:at + blk] = src
+    enc[n // 5] = 254
+    res = esa.suffixerator_tables(enc, 4)
+    st = res.stats
+    assert st["refine_rounds"] > 0
+    assert 0 < st["rank_entries_built"] < (n + 1) // 2
+    _assert_same_as_oracle(enc, 4, res)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 70_001, 1_000_003])
 def test_keygen_with_and_without_fused_first_pass(gpu, monkeypatch, fused, n):

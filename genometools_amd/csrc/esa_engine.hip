@@ -4639,8 +4639,16 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         u64 M = 0;
         if (!fail && d_sel != nullptr && NL > 0 && list_cap > 0) {
           HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 8, st));     // count, count2
-          k_win_filter<P, false><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<P>(0, false), st>>>(
-              sa, NL, rk_wb, d_sel, 0u, nullptr, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
+          // (the bitmap of the windows of 64 K positions: 6 KB for 3 Gbp -- in LDS whenever it fits)
+          if ((dw_nww + 4) * 5 <= WF_LDS_MAX) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_win_filter<P, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int) wf_lds_bytes<P>(dw_nww, true)));
+            k_win_filter<P, true><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<P>(dw_nww, true), st>>>(
+                sa, NL, rk_wb, d_sel, (u32) dw_nww, nullptr, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
+          } else
+            k_win_filter<P, false><<<(u32) div_up(NL, WF_SPAN * WF_ITER), WF_THREADS, wf_lds_bytes<P>(0, false), st>>>(
+                sa, NL, rk_wb, d_sel, 0u, nullptr, tiebits2, carry, fpos, fhead, list_cap, c->d_stats);
           HIP_TRY(hipGetLastError());
           TRY(fetch_stats(c));
           listed = c->h_stats->count2 == 0;

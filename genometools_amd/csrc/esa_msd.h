@@ -162,15 +162,6 @@ __device__ __forceinline__ u64 p5_code(const Text &t, u64 p, u32 &pay) {
 // of neighbours is made once for the four codes it is part of
 __device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PER]) {
   const u64 S = sp_window(t, p0);
-  if ((S & 0xFFFFull) != 0) {
-#pragma unroll
-    for (int g = 0; g < KP_PER; g++) {
-      u32 pay;
-      const u64 code = p5_code(t, p0 + (u64) g, pay);
-      key[g] = (code << 24) | (u64) pay;
-    }
-    return;
-  }
   // (one division for the three places: p0, p0 + 8 and the symbol in front)
   const u64 w0 = p0 / 12;
   const int r0 = (int) (p0 - w0 * 12);
@@ -179,6 +170,9 @@ __device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PE
   const int r8 = r0 + 8 >= 12 ? r0 - 4 : r0 + 8;
   const u64 ta = r0 + 8 >= 12 ? t1 : t0, tb = r0 + 8 >= 12 ? t2 : t1;
   const u64 wb = r8 <= 1 ? ta << (5 * r8) : (ta << (5 * r8)) | (tb >> (5 * (12 - r8)));
+  // the 16 stored symbols p0 .. p0+15 (a special is stored as 0 or 1; behind the end
+  // of the text whatever the words hold: the bit of position n is set in S, nothing
+  // behind the first special of a suffix is looked at)
   u32 sym[16], pr[15];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -192,12 +186,28 @@ __device__ __forceinline__ void p5_keys8(const Text &t, u64 p0, u64 (&key)[KP_PE
     const u32 c = r0 ? (u32) (t0 >> (59 - 5 * (r0 - 1))) & 31u : (u32) (tb_word(t, w0 - 1) >> 4) & 31u;
     pay = (c < 2u && is_special(t, p0 - 1)) ? ((c & 1u) ? Pay<5>::SEP : Pay<5>::WILD) : c;
   }
+  const bool clean = (S & 0xFFFFull) == 0;       // no special among the 16 positions
 #pragma unroll
   for (int g = 0; g < KP_PER; g++) {
-    const u64 code = ((u64) pr[g] << 31) | ((u64) pr[g + 2] << 22) | ((u64) pr[g + 4] << 13) |
-                     ((u64) pr[g + 6] << 4) | (u64) (sym[g + 8] >> 1);
-    key[g] = (code << 24) | (u64) pay;
-    pay = sym[g];          // (no special among them: the symbol is its own payload code)
+    u64 code = ((u64) pr[g] << 31) | ((u64) pr[g + 2] << 22) | ((u64) pr[g + 4] << 13) |
+               ((u64) pr[g + 6] << 4) | (u64) (sym[g + 8] >> 1);
+    u32 x = pay;
+    const u32 sp = (u32) (S >> g) & 0x1FFu;      // specials among the suffix' first nine
+    if (!clean && sp != 0) {
+      // (p5_code: everything from the first special on is the padding symbol 20.  One
+      // lane in twenty of a protein set comes here, so nearly every wave does: the
+      // symbols are the ones at hand, no window is read again)
+      const int d = __ffs((int) sp) - 1;
+      u32 q[9];
+#pragma unroll
+      for (int i = 0; i < 9; i++) q[i] = i < d ? sym[g + i] : 20u;
+      code = ((u64) (q[0] * 21u + q[1]) << 31) | ((u64) (q[2] * 21u + q[3]) << 22) |
+             ((u64) (q[4] * 21u + q[5]) << 13) | ((u64) (q[6] * 21u + q[7]) << 4) | (u64) (q[8] >> 1);
+      x |= 32u;
+    }
+    key[g] = (code << 24) | (u64) x;
+    // the payload of the next suffix: this symbol, or which special it is
+    pay = (!clean && ((S >> g) & 1ull)) ? ((sym[g] & 1u) ? Pay<5>::SEP : Pay<5>::WILD) : sym[g];
   }
 }
 

@@ -11,16 +11,20 @@ its packed form.  N=1 workload: BASELINE.json configs[2], 3 Gbp human-like DNA
 N>1 (one process per GPU, torch.distributed / RCCL): the SAME sequence is
 replicated on every GPU (750 MB packed) and the suffix array is sharded into N
 lexicographic ranges (the reference's -parts idea); rank r builds slice r of
-every table.  Per-rank work falls with N: a rank makes the keys of its 1/N text
-tile and alltoallv's the (key, position) pairs to the range owners; the rank
-table of the doubling rounds is cut by text position (queries, answers and new
-ranks by alltoallv over xGMI, enqueued on the engine's stream).  Total work is
+every table.  A rank filters the suffixes of its key range from the replicated
+text (no exchange for the first sort) and sorts them most significant digit
+first; the rank table of the doubling rounds is cut by text position (first
+ranks of the windows the rounds can reach, then per round one fused alltoallv of
+new ranks + queries and one of answers over xGMI, enqueued on the engine's
+stream).  Total work is
 fixed, so the line says "scaling": "strong" and value = n / (max over ranks of
 the step time).
 
 The JSON line carries, besides the contract fields:
-  roofline      the dominant kernel (radix scatter pass): algorithmic bytes per
-                launch (24 B per (key,position) pair moved: 12 in + 12 out)
+  roofline      the dominant kernel (k_msd_local, level D of the MSD first sort:
+                8 B read per entry of a run it takes, 14.125 B written per entry
+                it sorts itself; the LSD scatter pass elsewhere: 12 in + 12 out):
+                algorithmic bytes per launch
                 / average launch duration measured with HIP events on the
                 engine's stream; `traffic` = HBM bytes per launch from the PMC
                 counters (profiles/traffic.json, only if it was measured on
@@ -213,10 +217,10 @@ def main():
                                       {0: "configs[1] shape", 1: "configs[2]",
                                        2: "configs[4] shape"}[a.model]),
                        "parallelism": "1 device" if world == 1 else
-                                      "%d lexicographic range parts: each rank keys its text "
-                                      "tile, alltoallv of pairs to the range owners, rank "
-                                      "table cut by position (alltoallv queries/answers/"
-                                      "updates)" % world,
+                                      "%d lexicographic range parts: each rank filters its key "
+                                      "range from the replicated text (no exchange for the first "
+                                      "sort), rank table cut by position (per round one fused "
+                                      "alltoallv of new ranks + queries, one of answers)" % world,
                        "pair_suffixes": st.get("pair_suffixes", 0),
                        "xgmi_bytes_per_step": exchanged / max(a.steps + a.warmup, 1),
                        "tied_suffixes": st["tied_suffixes"],

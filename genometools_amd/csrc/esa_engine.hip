@@ -205,6 +205,46 @@ __device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l,
   }
 }
 
+// The same for matches that can be long (the pair comparison, the LCP walk: copies
+// of thousands of symbols): FOUR windows per step on the 2-bit text.  A step of
+// lcp_extend is one round trip to memory for 32 symbols, and nothing of the next
+// step can be issued before this one has decided -- a wave whose one lane walks a
+// copy of 4 K symbols sits through 128 of them.  Here the ten text words and the six
+// bitmap words of 128 symbols are in flight together (reading behind the first
+// difference is harmless: the accessors return 0 behind the text).
+template <int BITS, int W = 4>
+__device__ u64 lcp_extend_long(const Text &t, u64 p, u64 q, u64 l) {
+  static_assert(W == 4 || W == 8, "windows per step");
+  if (BITS != 2) return lcp_extend<BITS>(t, p, q, l);
+  for (;;) {
+    const u64 P = p + l, Q = q + l;
+    const u64 wp = P >> 5, wq = Q >> 5;
+    const int op = (int) (P & 31) * 2, oq = (int) (Q & 31) * 2;
+    u64 tp[W + 1], tq[W + 1], sp[W / 2 + 1], sq[W / 2 + 1];
+#pragma unroll
+    for (int i = 0; i <= W; i++) { tp[i] = tb_word(t, wp + i); tq[i] = tb_word(t, wq + i); }
+    const u64 swp = P >> 6, swq = Q >> 6;
+    const int sop = (int) (P & 63), soq = (int) (Q & 63);
+#pragma unroll
+    for (int i = 0; i <= W / 2; i++) { sp[i] = sp_word(t, swp + i); sq[i] = sp_word(t, swq + i); }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const u64 a = op ? (tp[k] << op) | (tp[k + 1] >> (64 - op)) : tp[k];
+      const u64 b = oq ? (tq[k] << oq) | (tq[k + 1] >> (64 - oq)) : tq[k];
+      const u64 x = a ^ b;
+      const int m = x ? __clzll((long long) x) / 2 : 32;
+      // special bits of the 64 positions from P + 64 (k / 2) / from Q + ...
+      const u64 Sp = sop ? (sp[k / 2] >> sop) | (sp[k / 2 + 1] << (64 - sop)) : sp[k / 2];
+      const u64 Sq = soq ? (sq[k / 2] >> soq) | (sq[k / 2 + 1] << (64 - soq)) : sq[k / 2];
+      const u32 sb = (u32) ((Sp | Sq) >> (32 * (k & 1)));
+      const int ds = sb ? __ffs((int) sb) - 1 : 32;
+      const int step = m < ds ? m : ds;
+      l += (u64) step;
+      if (step < 32) return l;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // pack: bytes -> packed words + special bitmap
 // ---------------------------------------------------------------------------
@@ -1912,12 +1952,12 @@ __global__ __launch_bounds__(256) void k_pair_emit(
 // here, the tables get their entries from k_pair_apply, which walks the pairs
 // in TABLE order (in text order its five accesses per pair were five random
 // lines: 18 ms for 170 M pairs)
-constexpr int PR_LINE = 16;     // records a thread loads at once (a chunk is a multiple of it)
-template <int BITS, typename P>
+constexpr int PR_LINE_MAX = 16; // records a thread loads at once at most (a chunk is a multiple of it)
+template <int BITS, typename P, int PR_LINE>
 __global__ __launch_bounds__(256) void k_pair_resolve(
     Text t, const P *__restrict__ pkey, const u64 *__restrict__ pval, u64 nrec, u64 np,
     const u32 *__restrict__ pidx, P *__restrict__ sa, u32 *__restrict__ res, Stats *stats,
-    int chunk) {
+    int chunk, int longext) {
   // records with ordinal < np are pairs (their LCP is a table entry: counted in
   // the statistics); the others are pairs of members of small groups
   __shared__ unsigned long long s_sum[4], s_large[4];
@@ -1996,7 +2036,9 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
         }
       }
       if (!known) {
-        l = lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::KNOWN);
+        l = longext == 2 ? lcp_extend_long<BITS, 8>(t, a, b, (u64) Key<BITS>::KNOWN)
+            : longext ? lcp_extend_long<BITS, 4>(t, a, b, (u64) Key<BITS>::KNOWN)
+                      : lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::KNOWN);   // (A/B: GTAMD_PAIR_LONG=0/1/2)
         // the first difference decides: a special is larger than every letter,
         // two specials compare by position
         const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
@@ -2649,7 +2691,7 @@ __global__ __launch_bounds__(256) void k_lcp_chunks(
     const u64 q = sa[i - 1];
     u64 from = (u64) Key<BITS>::KNOWN;
     if (e > 0 && l > from + (p - prevp)) from = l - (p - prevp);
-    l = lcp_extend<BITS>(t, q, p, from);
+    l = lcp_extend_long<BITS>(t, q, p, from);
     prevp = p;
     const u32 lv = l < 0x7FFFFFFFull ? (u32) l : 0x7FFFFFFFu;
     lcp[i] = (u8) (lv < GTAMD_LCPOVERFLOW ? lv : GTAMD_LCPOVERFLOW);
@@ -4190,9 +4232,22 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       // 32 / 128 / 512 pairs per thread: 4.7 / 4.7 / 5.6 / 11.5 ms)
       int pair_chunk = (int) (nrec >> 20 < 16 ? 16 : (nrec >> 20 > 128 ? 128 : nrec >> 20));
       if (const char *e = getenv("GTAMD_PAIR_CHUNK")) { const int v = atoi(e); if (v >= 4 && v <= 1024) pair_chunk = v; }
-      pair_chunk = (pair_chunk + PR_LINE - 1) / PR_LINE * PR_LINE;    // (whole lines of records per thread)
-      k_pair_resolve<BITS, P><<<stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256)), 256, 0, st>>>(
-          c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk);
+      pair_chunk = (pair_chunk + PR_LINE_MAX - 1) / PR_LINE_MAX * PR_LINE_MAX;    // (whole lines of records per thread)
+      {
+        int line = PR_LINE_MAX, longext = 1;
+        if (const char *e = getenv("GTAMD_PAIR_LONG")) longext = e[0] == '2' ? 2 : e[0] != '0';
+        if (const char *e = getenv("GTAMD_PAIR_LINE")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) line = v; }
+        const u32 grid = stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256));
+        if (line == 4)
+          k_pair_resolve<BITS, P, 4><<<grid, 256, 0, st>>>(
+              c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk, longext);
+        else if (line == 8)
+          k_pair_resolve<BITS, P, 8><<<grid, 256, 0, st>>>(
+              c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk, longext);
+        else
+          k_pair_resolve<BITS, P, 16><<<grid, 256, 0, st>>>(
+              c->text, pk_sorted, pv_sorted, nrec, npairs, pidx, sa, pres, c->d_stats, pair_chunk, longext);
+      }
       HIP_TRY(hipGetLastError());
       if (nsmall > 0) {
         k_small_combine<P><<<(u32) div_up(nsmall, 256), 256, 0, st>>>(

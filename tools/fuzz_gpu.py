@@ -2,9 +2,12 @@
 """Differential fuzzing on the GPU box: random structured sequences (repeats,
 tandem repeats, special runs, separators; DNA and protein) through
   * the engine (all tables + bucket table, random prefix length),
-  * DNA: the same build through the MSD first sort (forced, random depth),
+  * the same build through the MSD first sort (forced; DNA: random depth; protein:
+    the 40-bit code of esa_msd.h), with random rank-window sizes and, one case in
+    four, without the pair path (everything through the doubling rounds),
   * a part build with 2..5 parts (thread transport on one device),
-  * the device FASTA reader (random line widths, CRLF, blank lines),
+  * the device FASTA reader (random line widths, CRLF, blank lines) and the device
+    FASTQ reader (four-line records, random qualities),
   * the packed-index builder (INDEX.bdx image: random block size, blocks per
     bucket, locate interval and mode, -sprank, both flavours),
 each compared with the CPU oracle / host reader.  Dev tool; stops at the first
@@ -114,16 +117,20 @@ def check_pck(rng, enc, sigma, ora):
     assert got == want, "packed index %r" % (kw,)
 
 
-def check_msd(rng, enc, ora):
-    """the most-significant-digit-first sort of big DNA builds (esa_msd.h), forced
+def check_msd(rng, enc, ora, sigma=4):
+    """the most-significant-digit-first sort of big builds (esa_msd.h), forced
     at this size, with a random depth of level C, a random limit of the
-    one-workgroup path and, one case in four, the LDS radix fallback in every run"""
+    one-workgroup path and, one case in four, the LDS radix fallback in every run;
+    the rank table of the rounds in windows of a random size, one case in four
+    without the pair path"""
     env = {"GTAMD_MSD": "1", "GTAMD_MSD_CBITS": str(int(rng.integers(0, 9))),
            "GTAMD_MSD_BIG_MAX": str(int(rng.choice([4096, 8192, 524288]))),
-           "GTAMD_MSD_RADIX": "1" if rng.integers(0, 4) == 0 else "0"}
+           "GTAMD_MSD_RADIX": "1" if rng.integers(0, 4) == 0 else "0",
+           "GTAMD_RANK_WINDOW_BITS": str(int(rng.choice([3, 4, 6, 9, 15]))),
+           "GTAMD_NO_PAIRS": "1" if rng.integers(0, 4) == 0 else "0"}
     os.environ.update(env)
     try:
-        with esa.EsaEngine(enc.size, 4) as eng:
+        with esa.EsaEngine(enc.size, sigma) as eng:
             eng.set_sequence(enc)
             eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT)
             res = eng.result()
@@ -192,6 +199,22 @@ def check_encoder(rng, enc, sigma, tmp):
             out.write(open("/proc/self/maps").read())
         raise
     assert np.array_equal(want, enc), "fuzzer wrote a FASTA that does not decode back"
+    # the same sequences as four-line FASTQ records
+    qpath = os.path.join(tmp, "f.fastq")
+    with open(qpath, "wb") as f:
+        start = 0
+        for i, end in enumerate(cuts):
+            seq = enc[start:end]
+            txt = bytes(wild[int(rng.integers(0, len(wild)))] if c == 254 else letters[c] for c in seq)
+            name = b"read%d x=%d" % (i, int(rng.integers(0, 99))) if rng.integers(0, 5) else b""
+            qual = bytes(rng.integers(33, 127, size=len(txt), dtype=np.uint8))
+            f.write(b"@" + name + b"\n" + txt + b"\n+" + (name if rng.integers(0, 3) == 0 else b"") + b"\n" +
+                    qual + b"\n")
+            start = end + 1
+    with encode.DeviceEncoder(protein=protein) as de:
+        de.encode([qpath])
+        assert np.array_equal(de.symbols(), enc), "device FASTQ reader symbols"
+        assert int(de.fastq_records()[1].sum()) + len(cuts) - 1 == enc.size
     with encode.DeviceEncoder(protein=protein) as de:
         de.encode([path])
         assert np.array_equal(de.symbols(), enc), "device reader symbols"
@@ -223,8 +246,8 @@ def main():
                 os.environ.pop("GTAMD_FORCE_WIDE", None)
             try:
                 ora = check_engine(rng, enc, sigma)
-                if sigma == 4 and case % 7 != 3 and enc.size >= 64:
-                    check_msd(rng, enc, ora)
+                if case % 7 != 3 and enc.size >= 64:
+                    check_msd(rng, enc, ora, sigma)
                 if case % 3 == 0:
                     check_parts(rng, enc, sigma, ora)
                 if enc.size <= 20000 and case % 2 == 0:

@@ -499,6 +499,112 @@ __global__ __launch_bounds__(512) void k_pattern_wc(u32 ngroups, u32 *__restrict
   }
 }
 
+// ---- variant T8: tiles of 8192 entries, 1024 threads, 2 workgroups per CU (75 KB of LDS):
+// runs of 32 entries per digit and tile
+constexpr int T8_TILE = 8192, T8_THREADS = 1024, T8_WAVES = 16, T8_PAD = 1032;
+__global__ __launch_bounds__(T8_THREADS) void k_hist_a8(Text t, u64 N, u32 *__restrict__ hist) {
+  __shared__ u32 h[T8_WAVES][256];
+  const int tid = threadIdx.x, w = tid >> 6;
+  for (int i = tid; i < T8_WAVES * 256; i += T8_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  const u64 p0 = (u64) blockIdx.x * T8_TILE + (u64) tid * KP_PER;
+  if (p0 < N) {
+    u64 key[KP_PER];
+    dna_keys8(t, p0, key);
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) atomicAdd(&h[w][(u32) (key[g] >> 56)], 1u);
+  }
+  __syncthreads();
+  if (tid < 256) {
+    u32 c = 0;
+    for (int i = 0; i < T8_WAVES; i++) c += h[i][tid];
+    hist[(u64) blockIdx.x * 256 + tid] = c;
+  }
+}
+__global__ __launch_bounds__(T8_THREADS) void k_scatter_a8(
+    Text t, u64 N, const u32 *__restrict__ scanned, u32 ntiles,
+    u32 *__restrict__ k1out, u8 *__restrict__ xout, u32 *__restrict__ pout) {
+  __shared__ u64 s_t[8 * T8_PAD];                 // 66 KB: transposition, then staging
+  __shared__ u16 s_cnt_mem[T8_WAVES * 256];
+  __shared__ u32 s_obase[256];
+  __shared__ u32 s_scan[T8_WAVES];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const u32 tile = ms_xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  const u64 tile_base = (u64) tile * T8_TILE;
+  for (int i = tid; i < T8_WAVES * 256 / 2; i += T8_THREADS) reinterpret_cast<u32 *>(s_cnt_mem)[i] = 0;
+  u32 gbase = 0;
+  if (tid < 256) gbase = scanned[(u64) tile * 256 + tid];
+  u64 key[8];
+  u32 rk[8];
+  {
+    u64 key8[KP_PER];
+    const u64 p0 = tile_base + (u64) tid * KP_PER;
+    if (p0 < N) dna_keys8(t, p0, key8);
+    else for (int g = 0; g < KP_PER; g++) key8[g] = ~0ull;
+#pragma unroll
+    for (int g = 0; g < KP_PER; g++) s_t[g * T8_PAD + tid] = key8[g];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 e = (u32) w * 512 + (u32) j * 64 + lane;
+    key[j] = s_t[(e & 7u) * T8_PAD + (e >> 3)];
+  }
+  __syncthreads();
+  ms_vu16 *cnt_w = (ms_vu16 *) s_cnt_mem + w * 256;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 d = (u32) (key[j] >> 56);
+    u32 intra, group;
+    ms_match<8>(d, intra, group);
+    const u32 old = cnt_w[d];
+    if (intra == 0) cnt_w[d] = (u16) (old + group);
+    rk[j] = ((old + intra) << 8) | d;
+  }
+  __syncthreads();
+  {
+    ms_vu16 *s_cnt = (ms_vu16 *) s_cnt_mem;
+    u32 c[T8_WAVES];
+    u32 tot = 0;
+    if (tid < 256) {
+#pragma unroll
+      for (int i = 0; i < T8_WAVES; i++) { c[i] = s_cnt[i * 256 + tid]; tot += c[i]; }
+    }
+    u32 all;
+    u32 dbase = block_scan_excl<T8_THREADS>(tot, &all, s_scan);
+    if (tid < 256) {
+      s_obase[tid] = gbase - dbase;
+#pragma unroll
+      for (int i = 0; i < T8_WAVES; i++) { s_cnt[i * 256 + tid] = (u16) dbase; dbase += c[i]; }
+    }
+  }
+  __syncthreads();
+  u32 *s_k1 = reinterpret_cast<u32 *>(s_t);
+  u16 *s_p = reinterpret_cast<u16 *>(s_k1 + T8_TILE);
+  u8 *s_x = reinterpret_cast<u8 *>(s_p + T8_TILE);
+  u8 *s_d = s_x + T8_TILE;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 e = (u32) w * 512 + (u32) j * 64 + lane;
+    const u32 d = rk[j] & 255u;
+    const u32 pos = (u32) cnt_w[d] + (rk[j] >> 8);
+    s_k1[pos] = (u32) (key[j] >> 24);
+    s_p[pos] = (u16) e;
+    s_x[pos] = (u8) ((((u32) (key[j] >> 19) & 31u) << 3) | ((u32) key[j] & 7u));
+    s_d[pos] = (u8) d;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const u32 e = (u32) j * T8_THREADS + tid;
+    const u32 g = s_obase[s_d[e]] + e;
+    k1out[g] = s_k1[e];
+    pout[g] = (u32) tile_base + s_p[e];
+    xout[g] = s_x[e];
+  }
+}
+
 int main() {
   const u64 N = 1ull << 31;                     // symbols = entries
   const u32 ntiles = (u32) (N / MS_TILE);
@@ -552,6 +658,18 @@ int main() {
   timeit("direct keys: 2 keygen", false, [&] { k_scatter_a<2, true><<<ntiles, MS_THREADS>>>(t, N, MS_TILE, scanned, ntiles, k1, x, p, sink); });
   timeit("direct keys: 3 + ranking", false, [&] { k_scatter_a<3, true><<<ntiles, MS_THREADS>>>(t, N, MS_TILE, scanned, ntiles, k1, x, p, sink); });
   timeit("direct keys: 6 all", true, [&] { k_scatter_a<6, true><<<ntiles, MS_THREADS>>>(t, N, MS_TILE, scanned, ntiles, k1, x, p, sink); });
+  {
+    // tiles of 8192: their own histogram and column scan
+    const u32 nt8 = (u32) (N / T8_TILE);
+    k_hist_a8<<<nt8, T8_THREADS>>>(t, N, hist);
+    k_colscan<<<256, 1024>>>(hist, nt8, binstart, scanned);
+    CK(hipDeviceSynchronize());
+    timeit("T8 tiles of 8192, 1024 threads", true, [&] { k_scatter_a8<<<nt8, T8_THREADS>>>(t, N, scanned, nt8, k1, x, p); });
+    // (back to tiles of 4096 for what follows)
+    k_hist_a<<<ntiles, MS_THREADS>>>(t, N, hist);
+    k_colscan<<<256, 1024>>>(hist, ntiles, binstart, scanned);
+    CK(hipDeviceSynchronize());
+  }
   for (u32 g : {256u * 3, 256u * 6, 256u * 12, 256u * 48}) {
     char nm[96];
     snprintf(nm, sizeof nm, "P  interleaved, grid %u, prefetch", g);

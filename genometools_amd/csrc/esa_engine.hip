@@ -3724,9 +3724,11 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       // suffix of the WHOLE text: every part computes the same counts (integer
       // sums) and so the same cuts -- nothing to agree on
       u32 *hist = c->h_hist;
-      const u64 stride = N > (1ull << 30) ? 64 : (N > (1u << 24) ? 16 : 1);
+      // (a sample of 10^7 suffixes puts the cuts within 0.1 % of where all of them
+      // would; every workgroup flushes its 16 K counters with atomics: few workgroups)
+      const u64 stride = N > (1ull << 30) ? 256 : (N > (1u << 24) ? 16 : 1);
       HIP_TRY(hipMemsetAsync(c->d_parthist, 0, PART_BINS * 4, st));
-      k_key_hist<BITS><<<1024, 256, 0, st>>>(c->text, 0, N, stride, c->d_parthist);
+      k_key_hist<BITS><<<N > (1ull << 30) ? 512 : 1024, 256, 0, st>>>(c->text, 0, N, stride, c->d_parthist);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(hist, c->d_parthist, PART_BINS * 4, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));

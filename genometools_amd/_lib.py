@@ -127,6 +127,7 @@ ABI = {
     "gtamd_comm_rccl_create": (_P, [_P, _U32, _U32, _INT]),
     "gtamd_comm_attach": (_INT, [_P, _U32, _P, _INT]),
     "gtamd_comm_abort": (None, [_P]),
+    "gtamd_esa_set_comm_abort": (_INT, [_P, _P, _P]),
     "gtamd_comm_destroy": (None, [_P]),
     "gtamd_esa_set_sequence_bytes": (_INT, [_P, _P, _U64, _INT]),
     "gtamd_esa_set_sequence_packed": (_INT, [_P, _P, _P, _U64]),

@@ -265,7 +265,9 @@ extern "C" int gtamd_comm_attach(gtamd_comm *g, uint32_t part, gtamd_esa_ctx *ct
   if (gtamd_esa_set_part(ctx, part, g->numparts) != 0) return -1;
   if (g->kind == 0) {
     g->views[part].g = g; g->views[part].part = part; g->views[part].device = device;
-    return gtamd_esa_set_comm(ctx, th_allgather, th_alltoallv, &g->views[part]);
+    if (gtamd_esa_set_comm(ctx, th_allgather, th_alltoallv, &g->views[part]) != 0) return -1;
+    // (a run that fails on one part breaks the barrier for all)
+    return gtamd_esa_set_comm_abort(ctx, [](void *u) { th_break((gtamd_comm *) u); }, g);
   }
   if (part != g->rank) { gtamd_set_error("this process is rank %u of the RCCL transport, not part %u", g->rank, part); return -1; }
   return gtamd_esa_set_comm(ctx, rc_allgather, rc_alltoallv, g);

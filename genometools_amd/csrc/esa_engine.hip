@@ -2841,6 +2841,8 @@ struct gtamd_esa_ctx {
   u32 part, numparts;
   gtamd_allgather_fn comm_allgather;
   gtamd_alltoallv_fn comm_alltoallv;
+  void (*comm_abort)(void *);   // called when a part build fails: the other parts must not wait
+  void *comm_abort_user;
   void *comm_user;
   u64 NL, index_offset;    // entries and offset of this part's slice
   u32 *d_parthist;         // PART_BINS counters
@@ -3002,6 +3004,17 @@ extern "C" int gtamd_esa_set_comm(gtamd_esa_ctx *c, gtamd_allgather_fn ag,
   c->comm_allgather = ag;
   c->comm_alltoallv = a2a;
   c->comm_user = user;
+  c->comm_abort = nullptr;
+  c->comm_abort_user = nullptr;
+  return 0;
+  GTAMD_ABI_END(-1)
+}
+
+extern "C" int gtamd_esa_set_comm_abort(gtamd_esa_ctx *c, void (*abort_fn)(void *), void *user) {
+  GTAMD_ABI_BEGIN
+  if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  c->comm_abort = abort_fn;
+  c->comm_abort_user = user;
   return 0;
   GTAMD_ABI_END(-1)
 }
@@ -5131,6 +5144,17 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
 extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
   GTAMD_ABI_BEGIN
   if (c == nullptr) { gtamd_set_error("null context"); return -1; }
+  // A part that fails between two collectives (an allocation, a launch) -- or before
+  // the first -- has left the others waiting in the next one: the transport is told
+  // (gtamd_esa_set_comm_abort; the library's thread transport registers itself), also
+  // when an exception ends the run.
+  struct AbortOnFailure {
+    gtamd_esa_ctx *c;
+    bool ok;
+    ~AbortOnFailure() {
+      if (!ok && c->numparts > 1 && c->comm_abort != nullptr) c->comm_abort(c->comm_abort_user);
+    }
+  } guard = {c, false};
   if (!c->have_text) { gtamd_set_error("no sequence set"); return -1; }
   if ((want & 15u) == 0) { gtamd_set_error("nothing requested"); return -1; }
   HIP_TRY(hipSetDevice(c->device));
@@ -5146,9 +5170,13 @@ extern "C" int gtamd_esa_run(gtamd_esa_ctx *c, uint32_t want) {
                     (unsigned long long) c->n);
     return -1;
   }
+  int rc;
   if (c->bits == 2)
-    return wide ? run_impl<2, true>(c, want, dist) : run_impl<2, false>(c, want, dist);
-  return wide ? run_impl<5, true>(c, want, dist) : run_impl<5, false>(c, want, dist);
+    rc = wide ? run_impl<2, true>(c, want, dist) : run_impl<2, false>(c, want, dist);
+  else
+    rc = wide ? run_impl<5, true>(c, want, dist) : run_impl<5, false>(c, want, dist);
+  guard.ok = rc == 0;
+  return rc;
   GTAMD_ABI_END(-1)
 }
 

@@ -189,6 +189,13 @@ typedef int (*gtamd_alltoallv_fn)(void *user, const void *send,
                                   uint32_t elem_bytes, void *stream);
 int gtamd_esa_set_comm(gtamd_esa_ctx *ctx, gtamd_allgather_fn allgather,
                        gtamd_alltoallv_fn alltoallv, void *user);
+/* What gtamd_esa_run calls when a part build fails on THIS part outside the
+   agreed failures (a launch error, an exception between two collectives): the
+   transport's way of telling the other parts not to wait for it -- they return -1
+   from their next collective.  After gtamd_esa_set_comm (which clears it); the
+   library's thread transport registers itself in gtamd_comm_attach.  Without it a
+   failing part leaves the others blocked, as a failing MPI rank would. */
+int gtamd_esa_set_comm_abort(gtamd_esa_ctx *ctx, void (*abort_fn)(void *user), void *user);
 
 /* ---- transports that ship with the library ----------------------------- */
 /* (genometools_amd/csrc/esa_comm.hip)  A C caller needs no Python and no torch

@@ -143,3 +143,40 @@ def test_pairs_in_some_parts_only(gpu, parts):
     per_part = _check(enc, 4, parts)
     assert sum(1 for s in per_part if s["pair_suffixes"] > 0) == 1
     assert sum(1 for s in per_part if s["tied_suffixes"] == 0) >= 1
+
+
+@pytest.mark.timeout(120)
+def test_a_failing_part_does_not_leave_the_others_waiting(gpu):
+    """the library's thread transport (csrc/esa_comm.hip): a part whose run fails --
+    here before its first collective: it never got a sequence -- tells the transport
+    (gtamd_esa_set_comm_abort, registered by gtamd_comm_attach), and the other part
+    returns -1 from its next collective instead of blocking in it"""
+    import threading
+    from genometools_amd import _lib, esa
+    lib = _lib.load()
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 9, 300000)
+    comm = lib.gtamd_comm_threads_create(2)
+    assert comm
+    ctxs = [lib.gtamd_esa_create(0, enc.size, 4) for _ in range(2)]
+    try:
+        assert all(ctxs)
+        for r, c in enumerate(ctxs):
+            assert lib.gtamd_comm_attach(comm, r, c, 0) == 0
+        assert lib.gtamd_esa_set_sequence_bytes(ctxs[0], enc.ctypes.data, enc.size, 0) == 0
+        rc = [None, None]
+
+        def run(r):
+            rc[r] = lib.gtamd_esa_run(ctxs[r], esa.WANT_SUF | esa.WANT_LCP)
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(60)
+        assert not any(t.is_alive() for t in th), "a part is still waiting"
+        assert rc == [-1, -1]
+    finally:
+        for c in ctxs:
+            if c:
+                lib.gtamd_esa_destroy(c)
+        lib.gtamd_comm_destroy(comm)

@@ -605,6 +605,29 @@ __global__ __launch_bounds__(T8_THREADS) void k_scatter_a8(
   }
 }
 
+// ---- do two partial writes of a line merge in the L2?  Aligned runs of 16 entries, every run
+// written in two halves: HOW 0 by the same workgroup, one half after the other (a barrier
+// between); HOW 1 the second half by the workgroup of the NEXT tile (as the real kernel's
+// unaligned runs are: the neighbour completes the line)
+template <int HOW>
+__global__ __launch_bounds__(512) void k_pattern_halves(u32 ntiles, u32 *__restrict__ a, u32 *__restrict__ b,
+                                                        u8 *__restrict__ x, u64 binsize) {
+  const u32 tile = ms_xcd_tile(blockIdx.x, ntiles);
+  if (tile >= ntiles) return;
+  for (int half = 0; half < 2; half++) {
+    const u32 t2 = HOW == 1 && half == 1 ? (tile + 1 < ntiles ? tile + 1 : 0u) : tile;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const u32 e = (u32) j * 512 + threadIdx.x;
+      if (((e % 16) < 8) == (half == 0)) {
+        const u64 g = (u64) (e / 16) * binsize + (u64) t2 * 16 + (e % 16);
+        a[g] = e; b[g] = tile; x[g] = (u8) e;
+      }
+    }
+    if (HOW == 0) __syncthreads();
+  }
+}
+
 int main() {
   const u64 N = 1ull << 31;                     // symbols = entries
   const u32 ntiles = (u32) (N / MS_TILE);
@@ -696,6 +719,8 @@ int main() {
     pat("write-combining pattern, 8 tiles a workgroup", [&] { k_pattern_wc<8><<<(u32) (N / 4096 / 8), 512>>>((u32) (N / 4096 / 8), ab, ab + N + 64, x, N / 256); });
     pat("write-combining pattern, 16 tiles a workgroup", [&] { k_pattern_wc<16><<<(u32) (N / 4096 / 16), 512>>>((u32) (N / 4096 / 16), ab, ab + N + 64, x, N / 256); });
     pat("write-combining pattern, 64 tiles a workgroup", [&] { k_pattern_wc<64><<<(u32) (N / 4096 / 64), 512>>>((u32) (N / 4096 / 64), ab, ab + N + 64, x, N / 256); });
+    pat("aligned runs in two halves, same workgroup", [&] { k_pattern_halves<0><<<(u32) (N / 4096), 512>>>((u32) (N / 4096), ab, ab + N + 64, x, N / 256); });
+    pat("aligned runs in two halves, second by the neighbour", [&] { k_pattern_halves<1><<<(u32) (N / 4096), 512>>>((u32) (N / 4096), ab, ab + N + 64, x, N / 256); });
     pat("pattern 4096: u64+u8", [&] { k_pattern<4096, 1><<<(u32) (N / 4096), 512>>>((u32) (N / 4096), ab, ab + N, x, N / 256); });
     pat("pattern 4096: u32+u32", [&] { k_pattern<4096, 2><<<(u32) (N / 4096), 512>>>((u32) (N / 4096), ab, ab + N, x, N / 256); });
     pat("pattern 4096: u64", [&] { k_pattern<4096, 3><<<(u32) (N / 4096), 512>>>((u32) (N / 4096), ab, ab + N, x, N / 256); });

@@ -212,10 +212,23 @@ __device__ u64 lcp_extend(const Text &t, u64 p, u64 q, u64 l,
 // copy of 4 K symbols sits through 128 of them.  Here the ten text words and the six
 // bitmap words of 128 symbols are in flight together (reading behind the first
 // difference is harmless: the accessors return 0 behind the text).
+// p_first (may be nullptr): whether suffix p comes before suffix q -- the first
+// difference decides, a special is larger than every letter, two specials compare
+// by position.  The symbols and special bits at the first difference are in the words
+// the step has loaded: asking the text again would be one more round trip to memory
+// per comparison.
 template <int BITS, int W = 4>
-__device__ u64 lcp_extend_long(const Text &t, u64 p, u64 q, u64 l) {
+__device__ u64 lcp_extend_long(const Text &t, u64 p, u64 q, u64 l, bool *p_first = nullptr) {
   static_assert(W == 4 || W == 8, "windows per step");
-  if (BITS != 2) return lcp_extend<BITS>(t, p, q, l);
+  if (BITS != 2) {
+    l = lcp_extend<BITS>(t, p, q, l);
+    if (p_first != nullptr) {
+      const bool spa = is_special(t, p + l), spb = is_special(t, q + l);
+      *p_first = (spa || spb) ? ((spa && spb) ? p < q : spb)
+                              : Sym<BITS>::at(t, p + l) < Sym<BITS>::at(t, q + l);
+    }
+    return l;
+  }
   for (;;) {
     const u64 P = p + l, Q = q + l;
     const u64 wp = P >> 5, wq = Q >> 5;
@@ -240,7 +253,15 @@ __device__ u64 lcp_extend_long(const Text &t, u64 p, u64 q, u64 l) {
       const int ds = sb ? __ffs((int) sb) - 1 : 32;
       const int step = m < ds ? m : ds;
       l += (u64) step;
-      if (step < 32) return l;
+      if (step < 32) {
+        if (p_first != nullptr) {
+          const int at = 32 * (k & 1) + step;           // bit of the deciding position in Sp, Sq
+          const bool spa = (Sp >> at) & 1ull, spb = (Sq >> at) & 1ull;
+          *p_first = (spa || spb) ? ((spa && spb) ? p < q : spb)
+                                  : ((a >> (62 - 2 * step)) & 3ull) < ((b >> (62 - 2 * step)) & 3ull);
+        }
+        return l;
+      }
     }
   }
 }
@@ -2036,14 +2057,16 @@ __global__ __launch_bounds__(256) void k_pair_resolve(
         }
       }
       if (!known) {
-        l = longext == 2 ? lcp_extend_long<BITS, 8>(t, a, b, (u64) Key<BITS>::KNOWN)
-            : longext ? lcp_extend_long<BITS, 4>(t, a, b, (u64) Key<BITS>::KNOWN)
-                      : lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::KNOWN);   // (A/B: GTAMD_PAIR_LONG=0/1/2)
-        // the first difference decides: a special is larger than every letter,
-        // two specials compare by position
-        const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
-        a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
-                               : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
+        if (longext) {
+          l = lcp_extend_long<BITS, 4>(t, a, b, (u64) Key<BITS>::KNOWN, &a_first);
+        } else {                                     // (A/B: GTAMD_PAIR_LONG=0)
+          l = lcp_extend<BITS>(t, a, b, (u64) Key<BITS>::KNOWN);
+          // the first difference decides: a special is larger than every letter,
+          // two specials compare by position
+          const bool spa = is_special(t, a + l), spb = is_special(t, b + l);
+          a_first = (spa || spb) ? ((spa && spb) ? a < b : spb)
+                                 : Sym<BITS>::at(t, a + l) < Sym<BITS>::at(t, b + l);
+        }
       }
 #pragma unroll
       for (int k = RING - 1; k > 0; k--) { ra[k] = ra[k - 1]; rb[k] = rb[k - 1]; rl[k] = rl[k - 1]; rf[k] = rf[k - 1]; }
@@ -4250,7 +4273,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
       pair_chunk = (pair_chunk + PR_LINE_MAX - 1) / PR_LINE_MAX * PR_LINE_MAX;    // (whole lines of records per thread)
       {
         int line = PR_LINE_MAX, longext = 1;
-        if (const char *e = getenv("GTAMD_PAIR_LONG")) longext = e[0] == '2' ? 2 : e[0] != '0';
+        if (const char *e = getenv("GTAMD_PAIR_LONG")) longext = e[0] != '0';
         if (const char *e = getenv("GTAMD_PAIR_LINE")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16) line = v; }
         const u32 grid = stride_grid(div_up(div_up(nrec, (u64) pair_chunk), 256));
         if (line == 4)

@@ -392,10 +392,15 @@ __device__ __forceinline__ void rs_scatter_tile(
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    // (the lane reads OUTSIDE the branch: in a part-filled tile lane j, which holds the
+    // word of item j, may itself have no entry of that item -- read from a lane that
+    // sits out the branch, the word came back as 0 and the entries of a group that
+    // reaches into the table's last word got themselves as their heads)
+    const u64 gen_t = VG::active ? __shfl(vg_t, j, 64) : 0ull;
+    const u32 gen_c = VG::active ? __shfl(vg_c, j, 64) : 0u;
     if (FULL || e < valid) {
       key[j] = keys_in[e];
-      val[j] = VG::active ? (V) vg.make(first + e, __shfl(vg_t, j, 64), __shfl(vg_c, j, 64))
-                          : vals_in[e];
+      val[j] = VG::active ? (V) vg.make(first + e, gen_t, gen_c) : vals_in[e];
     } else {
       key[j] = (K) ~(K) 0;
       val[j] = 0;
@@ -745,10 +750,15 @@ __device__ __forceinline__ void rs_partition_tile(
 #pragma unroll
   for (int j = 0; j < RS_ITEMS; j++) {
     const u32 e = (u32) w * RS_WAVE_CHUNK + (u32) j * 64 + lane;
+    // (the lane reads OUTSIDE the branch: in a part-filled tile lane j, which holds the
+    // word of item j, may itself have no entry of that item -- read from a lane that
+    // sits out the branch, the word came back as 0 and the entries of a group that
+    // reaches into the table's last word got themselves as their heads)
+    const u64 gen_t = VG::active ? __shfl(vg_t, j, 64) : 0ull;
+    const u32 gen_c = VG::active ? __shfl(vg_c, j, 64) : 0u;
     if (FULL || e < valid) {
       key[j] = keys_in[e];
-      val[j] = VG::active ? (V) vg.make(first + e, __shfl(vg_t, j, 64), __shfl(vg_c, j, 64))
-                          : vals_in[e];
+      val[j] = VG::active ? (V) vg.make(first + e, gen_t, gen_c) : vals_in[e];
     } else {
       key[j] = 0;
       val[j] = 0;

@@ -349,6 +349,29 @@ def test_rank_table_of_selected_windows(gpu, monkeypatch, wbits, n, later):
     _assert_same_as_oracle(enc, 4, res)
 
 
+@pytest.mark.parametrize("n,sigma", [(70_337, 4), (70_337 + 512, 4), (70_337, 20), (2948, 20)])
+def test_tie_group_that_reaches_the_last_word_of_the_table(gpu, monkeypatch, n, sigma):
+    """the largest suffixes tied -- a run of the largest letter, and nothing but the
+    terminator behind them in the table -- with a table length that leaves the last
+    64-entry chunk of the rank-table partition with fewer entries than its item number:
+    the lane that held the chunk's tie-bitmap word sat out the branch in which the
+    others read it (round 3, found by the fuzzer with small rank windows: the heads
+    of those entries were the entries themselves, the rounds did not converge)"""
+    if n == 2948:
+        monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", "6")
+    # (the whole table, as a text with ties everywhere gets it: its first partition pass
+    # makes the heads on the fly)
+    monkeypatch.setenv("GTAMD_RANK_ALL_WINDOWS", "1")
+    rng = np.random.default_rng(n + sigma)
+    enc = rng.integers(0, sigma - 1, size=n).astype(np.uint8)     # (the largest letter is kept out ...)
+    run = 1219 if n < 5000 else 3000
+    at = n // 4
+    enc[at:at + run] = sigma - 1                                  # (... but for one long run)
+    res = esa.suffixerator_tables(enc, sigma)
+    assert res.stats["refine_rounds"] > 0
+    _assert_same_as_oracle(enc, sigma, res)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 4095, 4096, 4097, 70_001, 1_000_003])
 def test_keygen_with_and_without_fused_first_pass(gpu, monkeypatch, fused, n):

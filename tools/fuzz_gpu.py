@@ -130,6 +130,7 @@ def check_msd(rng, enc, ora, sigma=4):
            "GTAMD_NO_PAIRS": "1" if rng.integers(0, 4) == 0 else "0"}
     os.environ.update(env)
     try:
+      try:
         with esa.EsaEngine(enc.size, sigma) as eng:
             eng.set_sequence(enc)
             eng.run(esa.WANT_SUF | esa.WANT_LCP | esa.WANT_BWT)
@@ -139,6 +140,9 @@ def check_msd(rng, enc, ora, sigma=4):
             for k in ("longest", "largelcpvalues", "maxbranchdepth"):
                 assert res.stats[k] == ora["stats"][k], "msd %s %s" % (k, env)
             assert res.stats["lcptabsum"] == int(ora["stats"]["lcptabsum"]), "msd lcptabsum %s" % env
+      except Exception:
+        print("check_msd: sigma %d %s" % (sigma, env), flush=True)
+        raise
     finally:
         for k in env:
             os.environ.pop(k, None)

@@ -33,6 +33,8 @@ from genometools_amd import encode, esa, pck  # noqa: E402
 
 def random_sequence(rng, sigma):
     n = int(rng.choice([1, 2, 3, 17, 64, 255, 256, 257, 1000, 4096, 4097, 9000, 20000]))
+    if rng.integers(0, 25) == 0:          # several tiles of every kernel, now and then
+        n = int(rng.choice([70000, 140000]))
     n = max(1, int(n * rng.uniform(0.5, 1.0)))
     kind = rng.integers(0, 4)
     if kind == 0:                       # low entropy: few letters
@@ -121,12 +123,18 @@ def check_msd(rng, enc, ora, sigma=4):
     """the most-significant-digit-first sort of big builds (esa_msd.h), forced
     at this size, with a random depth of level C, a random limit of the
     one-workgroup path and, one case in four, the LDS radix fallback in every run;
-    the rank table of the rounds in windows of a random size, one case in four
-    without the pair path"""
+    the rank table of the rounds in windows of a random size (one case in three the
+    whole table), random chunks of the pair comparison, the pairs' table entries at
+    random places of the flow, a random crowded-bin limit, one case in four without
+    the pair path"""
     env = {"GTAMD_MSD": "1", "GTAMD_MSD_CBITS": str(int(rng.integers(0, 9))),
            "GTAMD_MSD_BIG_MAX": str(int(rng.choice([4096, 8192, 524288]))),
            "GTAMD_MSD_RADIX": "1" if rng.integers(0, 4) == 0 else "0",
            "GTAMD_RANK_WINDOW_BITS": str(int(rng.choice([3, 4, 6, 9, 15]))),
+           "GTAMD_RANK_ALL_WINDOWS": "1" if rng.integers(0, 3) == 0 else "0",
+           "GTAMD_PAIR_CHUNK": str(int(rng.choice([4, 16, 32, 128]))),
+           "GTAMD_APPLY_EARLY": str(int(rng.integers(0, 3))),
+           "GTAMD_MSD_BIN_LIMIT": str(int(rng.choice([2, 16, 128]))),
            "GTAMD_NO_PAIRS": "1" if rng.integers(0, 4) == 0 else "0"}
     os.environ.update(env)
     try:

@@ -4499,6 +4499,10 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
     // touch (all of them when that is most of the text)
     int rk_wb = 0;
     u64 rk_nwin = 0, rk_h0 = 0;
+    // (tests: the window bitmap of k_win_filter read from global memory, as a text of more
+    // than 3.9 G symbols has it)
+    const char *wfe = getenv("GTAMD_WIN_FILTER_LDS");
+    const bool wf_global = wfe != nullptr && wfe[0] == '0';
     bool rk_windows = false;          // only some windows are built
     u32 *w_need = nullptr, *w_built = nullptr, *w_sel = nullptr, *w_list = nullptr;
     // builds the windows that are needed and not built (all == the whole table)
@@ -4606,7 +4610,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         // the pairs of the selected windows, with compact positions, partitioned down
         // to the windows the LDS takes
         HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 4, st));
-        if ((nww + 4) * 5 <= WF_LDS_MAX) {
+        if ((nww + 4) * 5 <= WF_LDS_MAX && !wf_global) {
           // (more than the 64 KB a kernel gets without asking)
           HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_win_filter<u32, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -4733,7 +4737,7 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         if (!fail && d_sel != nullptr && NL > 0 && list_cap > 0) {
           HIP_TRY(hipMemsetAsync(&c->d_stats->count, 0, 8, st));     // count, count2
           // (the bitmap of the windows of 64 K positions: 6 KB for 3 Gbp -- in LDS whenever it fits)
-          if ((dw_nww + 4) * 5 <= WF_LDS_MAX) {
+          if ((dw_nww + 4) * 5 <= WF_LDS_MAX && !wf_global) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_win_filter<P, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int) wf_lds_bytes<P>(dw_nww, true)));

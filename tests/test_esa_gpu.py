@@ -327,7 +327,8 @@ def test_rank_table_window_shapes(gpu, monkeypatch, wbits, n):
 
 @pytest.mark.parametrize("wbits,n,later", [(15, 3_000_000, False), (8, 600_000, False), (4, 600_000, False),
                                            (10, 900_000, True), (5, 900_000, True)])
-def test_rank_table_of_selected_windows(gpu, monkeypatch, wbits, n, later):
+@pytest.mark.parametrize("lds", ["1", "0"])
+def test_rank_table_of_selected_windows(gpu, monkeypatch, wbits, n, later, lds):
     """only the windows of positions the rounds can touch are built (k_win_mark,
     k_win_filter with compact positions, k_rank_window per selected window): a random
     text with a few blocks in several copies -- the tied suffixes lie in a small part
@@ -335,6 +336,7 @@ def test_rank_table_of_selected_windows(gpu, monkeypatch, wbits, n, later):
     are added between rounds (k_win_check); the last window of the text among them"""
     monkeypatch.setenv("GTAMD_RANK_WINDOW_BITS", str(wbits))
     monkeypatch.setenv("GTAMD_NO_PAIRS", "1")
+    monkeypatch.setenv("GTAMD_WIN_FILTER_LDS", lds)     # (0: the bitmap from global memory)
     rng = np.random.default_rng(wbits * 1000 + n % 997)
     enc = rng.integers(0, 4, size=n).astype(np.uint8)
     blk = 40_000 if later else 3_000

@@ -132,6 +132,7 @@ def check_msd(rng, enc, ora, sigma=4):
            "GTAMD_MSD_RADIX": "1" if rng.integers(0, 4) == 0 else "0",
            "GTAMD_RANK_WINDOW_BITS": str(int(rng.choice([3, 4, 6, 9, 15]))),
            "GTAMD_RANK_ALL_WINDOWS": "1" if rng.integers(0, 3) == 0 else "0",
+           "GTAMD_WIN_FILTER_LDS": "0" if rng.integers(0, 3) == 0 else "1",
            "GTAMD_PAIR_CHUNK": str(int(rng.choice([4, 16, 32, 128]))),
            "GTAMD_APPLY_EARLY": str(int(rng.integers(0, 3))),
            "GTAMD_MSD_BIN_LIMIT": str(int(rng.choice([2, 16, 128]))),
@@ -158,9 +159,20 @@ def check_msd(rng, enc, ora, sigma=4):
 
 def check_parts(rng, enc, sigma, ora):
     parts = int(rng.integers(2, 6))
-    tabs = thread_comm.build_in_parts(enc, sigma, parts)[0]
-    for name in ("suf", "lcp", "llv", "bwt"):
-        assert np.array_equal(tabs[name], ora[name]), "parts=%d %s" % (parts, name)
+    env = {"GTAMD_WIN_FILTER_LDS": "0" if rng.integers(0, 3) == 0 else "1",
+           "GTAMD_PAIR_CHUNK": str(int(rng.choice([4, 16, 32, 128]))),
+           "GTAMD_NO_PAIRS": "1" if rng.integers(0, 5) == 0 else "0"}
+    os.environ.update(env)
+    try:
+        tabs = thread_comm.build_in_parts(enc, sigma, parts)[0]
+        for name in ("suf", "lcp", "llv", "bwt"):
+            assert np.array_equal(tabs[name], ora[name]), "parts=%d %s %s" % (parts, name, env)
+    except Exception:
+        print("check_parts: parts %d sigma %d %s" % (parts, sigma, env), flush=True)
+        raise
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
 
 
 def check_encoder(rng, enc, sigma, tmp):

@@ -432,9 +432,13 @@ void gtamd_fastq_filelengths(const gtamd_fastq_record *rec, size_t nrec, size_t 
         rd = add = 0; filenum = newfile;
       }
       if (r == nrec) { complete = 1; out--; add--; break; }
-      for (uint64_t c = 0; c < rec[r].seqlen; c++) {
-        if (out >= OUTBUF) overflow++;
-        else { out++; add++; rd++; }
+      {
+        /* (symbol by symbol in the reference: what fits the buffer is booked,
+           the rest overflows into the next call) */
+        const uint64_t room = out < OUTBUF ? OUTBUF - out : 0;
+        const uint64_t k = rec[r].seqlen < room ? rec[r].seqlen : room;
+        out += k; add += k; rd += k;
+        overflow += rec[r].seqlen - k;
       }
       if (overflow == 0) {
         if (out >= OUTBUF) carry = 1;

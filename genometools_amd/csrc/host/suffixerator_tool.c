@@ -601,13 +601,16 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
        the host only where a file needs them.  (FASTQ the device reader declines
        -- sequences over several lines and whatever is malformed -- goes to the
        host reader below, which has the reference's messages.) */
+    double ts[4];
     reader = "device";
     if (device_rc != 0) return -1;
+    ts[0] = now_s();
     n = gtamd_encoder_length(de);
     if (gtamd_write_esq_device_alpha(indexname, db, numdb, de, &alpha, &info, out_ssp, sat, &ss, err, errlen) != 0) {
       free(desc); gtamd_encinfo_free(&info); gtamd_encoder_destroy(de);
       return -1;
     }
+    ts[1] = now_s();
     gtamd_encinfo_free(&info);
     if (clipdesc) gtamd_clip_descriptions(desc, &desclen);
     if ((out_des || out_sds) && gtamd_write_des_sds(indexname, desc, desclen, out_des, out_sds) != 0) {
@@ -615,6 +618,10 @@ static int suffixerator_run(int argc, const char **argv, char *err, size_t errle
       return fail(err, errlen, "cannot write description files of index '%s'", indexname);
     }
     free(desc);
+    ts[2] = now_s();
+    if (verbose)
+      printf("# device reader: files read and encoded %.3f s, .esq/.ssp %.3f, .des/.sds %.3f\n",
+             ts[0] - t0, ts[1] - ts[0], ts[2] - ts[1]);
     if (out_md5 || mirrored || readmode != 0) {
       /* MD5 sums and the -dir / -mirrored transforms work on host symbols */
       if ((enc = malloc(n ? n : 1)) == NULL || gtamd_encoder_copy_symbols(de, enc, 0, n) != 0) {

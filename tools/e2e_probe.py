@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--tables", default="-suf -lcp -bwt")
     ap.add_argument("--packedindex", action="store_true",
                     help="also time `packedindex mkindex` (FASTA -> INDEX.bdx) on the same file")
+    ap.add_argument("--fastq", type=int, default=0, metavar="READLEN",
+                    help="write the symbols as four-line FASTQ records of READLEN symbols instead "
+                         "of FASTA (the device FASTQ reader against the host reader)")
     ap.add_argument("--generate-only", action="store_true",
                     help="write DIR/genome.fna and stop (input for a profiler run)")
     a = ap.parse_args()
@@ -50,9 +53,36 @@ def main():
         torch.cuda.empty_cache()
         fa = os.path.join(a.dir, "genome.fna")
         t = time.time()
-        synth.write_fasta(fa, enc)
+        if a.fastq:
+            # reads of READLEN symbols cut from the sequence (separators and wildcards
+            # become N), a name and a quality line each; written in slabs
+            L = a.fastq
+            lut = np.frombuffer(b"ACGT" + b"N" * 252, dtype=np.uint8)
+            nrec = n // L
+            name_w = 12
+            rec = 1 + name_w + 1 + L + 1 + 1 + 1 + L + 1          # @name\n seq\n +\n qual\n
+            with open(fa, "wb") as f:
+                for r0 in range(0, nrec, 1 << 18):
+                    r1 = min(nrec, r0 + (1 << 18))
+                    k = r1 - r0
+                    slab = np.empty((k, rec), dtype=np.uint8)
+                    slab[:, 0] = ord("@")
+                    names = np.char.zfill(np.arange(r0, r1).astype("U"), name_w - 1).astype("S")
+                    slab[:, 1] = ord("r")
+                    slab[:, 2:1 + name_w] = np.frombuffer(b"".join(names.tolist()), dtype=np.uint8).reshape(k, name_w - 1)
+                    slab[:, 1 + name_w] = 10
+                    slab[:, 2 + name_w:2 + name_w + L] = lut[enc[r0 * L:r1 * L]].reshape(k, L)
+                    slab[:, 2 + name_w + L] = 10
+                    slab[:, 3 + name_w + L] = ord("+")
+                    slab[:, 4 + name_w + L] = 10
+                    slab[:, 5 + name_w + L:5 + name_w + 2 * L] = 33 + (np.arange(k * L, dtype=np.uint32).reshape(k, L) * 2654435761 >> 26 & 63).astype(np.uint8)
+                    slab[:, 5 + name_w + 2 * L] = 10
+                    f.write(slab.tobytes())
+            n = nrec * L
+        else:
+            synth.write_fasta(fa, enc)
         del enc
-        print("FASTA: %d symbols, %.1f MB, written in %.1f s" % (n, os.path.getsize(fa) / 1e6,
+        print("%s: %d symbols, %.1f MB, written in %.1f s" % ("FASTQ" if a.fastq else "FASTA", n, os.path.getsize(fa) / 1e6,
                                                                 time.time() - t), flush=True)
         if a.generate_only:
             a.dir = None
@@ -70,7 +100,7 @@ def main():
                 print(encoder, "FAILED", r.stderr)
                 return 1
             line = [l for l in r.stdout.splitlines()
-                    if l.startswith(("# seconds", "# device encoder"))]
+                    if l.startswith(("# seconds", "# device encoder", "# device reader"))]
             print("%s reader: wall %.2f s\n  %s" % (encoder, wall, "\n  ".join(line)),
                   flush=True)
             sums[encoder] = {ext: md5(idx + "." + ext) for ext in

@@ -136,6 +136,13 @@ def check_msd(rng, enc, ora, sigma=4):
            "GTAMD_PAIR_CHUNK": str(int(rng.choice([4, 16, 32, 128]))),
            "GTAMD_APPLY_EARLY": str(int(rng.integers(0, 3))),
            "GTAMD_MSD_BIN_LIMIT": str(int(rng.choice([2, 16, 128]))),
+           "GTAMD_MSD_PACK": str(int(rng.integers(0, 2))),
+           "GTAMD_MSD_PACK_CAP": str(int(rng.choice([1024, 2048, 4096]))),
+           "GTAMD_ROUND_STRIDE": str(int(rng.choice([512, 1024, 1536, 2048]))),
+           "GTAMD_NO_SMALL_GROUPS": "1" if rng.integers(0, 4) == 0 else "0",
+           "GTAMD_STABLE_PARTITION": str(int(rng.integers(0, 2))),
+           "GTAMD_PAIR_LINE": str(int(rng.choice([4, 8, 16]))),
+           "GTAMD_PAIR_LONG": str(int(rng.integers(0, 2))),
            "GTAMD_NO_PAIRS": "1" if rng.integers(0, 4) == 0 else "0"}
     os.environ.update(env)
     try:

@@ -569,3 +569,39 @@ def test_cli_gpus_refuses_what_needs_the_whole_table(cli, tmp_path):
     r = subprocess.run([cli, "-dna", "-suf", "-gpus", "0", "-db", ou.fixture_path("Atinsert.fna"),
                         "-indexname", str(tmp_path / "x")], capture_output=True, text=True)
     assert r.returncode == 1 and "1 to 128" in r.stderr
+
+
+def test_cli_fastq_reads_at_size_device_and_host_reader(cli, tmp_path):
+    """4 M symbols of the human-like model as 40 000 four-line reads of 100 with names and
+    pseudo-random qualities ('@' and '+' among them) in two files: the device FASTQ reader
+    (records across the 4096-byte tiles of its kernels, the file length table booked over
+    hundreds of buffer fills of the reference's reader) and the host reader write the same
+    files, tables included"""
+    import numpy as np
+    from genometools_amd import synth
+    n, L = 4_000_000, 100
+    enc = synth.generate(synth.MODEL_HUMANLIKE_DNA, 11, n)
+    lut = np.frombuffer(b"ACGT" + b"N" * 252, dtype=np.uint8)
+    sym = lut[enc].reshape(-1, L)
+    rng = np.random.default_rng(3)
+    names = []
+    for part, rows in (("a", sym[:25_000]), ("b", sym[25_000:])):
+        p = tmp_path / ("reads_%s.fastq" % part)
+        with open(p, "wb") as f:
+            for k, row in enumerate(rows):
+                name = b"read.%s.%d length=%d" % (part.encode(), k, L)
+                qual = bytes(rng.integers(33, 127, size=L, dtype=np.uint8))
+                f.write(b"@" + name + b"\n" + row.tobytes() + b"\n+" + (name if k % 5 == 0 else b"") +
+                        b"\n" + qual + b"\n")
+        names.append(p.name)
+    out = {}
+    for encoder in ("device", "host"):
+        idx = str(tmp_path / encoder)
+        r = subprocess.run([cli, "-dna", "-suf", "-lcp", "-bwt", "-v", "-encoder", encoder, "-indexname",
+                            idx, "-db"] + names, check=True, cwd=str(tmp_path), stdout=subprocess.PIPE,
+                           text=True)
+        assert "(%s reader)" % encoder in r.stdout
+        out[encoder] = {ext: hashlib.md5(open(idx + "." + ext, "rb").read()).hexdigest()
+                        for ext in ("suf", "lcp", "llv", "bwt", "prj", "des", "sds", "md5", "esq", "ssp")
+                        if os.path.exists(idx + "." + ext)}
+    assert out["device"] == out["host"] and len(out["device"]) >= 9

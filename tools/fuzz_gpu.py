@@ -229,7 +229,20 @@ def check_encoder(rng, enc, sigma, tmp):
                 verdict))
             out.write(open("/proc/self/maps").read())
         raise
-    assert np.array_equal(want, enc), "fuzzer wrote a FASTA that does not decode back"
+    if not np.array_equal(want, enc):
+        # the writer above and the oracle's reader disagree -- or a read saw something else
+        # than the file (round 1 met that once on a GPU box): keep what is needed to tell
+        with open(path, "rb") as f:
+            again = f.read()
+        second = ou.encode_fasta(path, protein)
+        with open(os.path.join(ROOT, "gpurun_out", "fuzz_decode_failure.fa"), "wb") as out:
+            out.write(again)
+        np.save(os.path.join(ROOT, "gpurun_out", "fuzz_decode_failure_first.npy"), want)
+        raise AssertionError("the FASTA the fuzzer wrote does not decode back: file stable %s, second "
+                             "decoding equals the sequence %s, first decoding equals the second %s, "
+                             "sizes %d %d %d" % (written == again, np.array_equal(second, enc),
+                                                 np.array_equal(second, want), enc.size, want.size,
+                                                 second.size))
     # the same sequences as four-line FASTQ records
     qpath = os.path.join(tmp, "f.fastq")
     with open(qpath, "wb") as f:

@@ -472,8 +472,8 @@ __global__ __launch_bounds__(EN_THREADS) void k_fq_tile(
   u32 nsym = 0, bad = 0;
 #pragma unroll
   for (int j = 0; j < EN_PER; j++) {
-    if (first + j >= len) break;
     const u8 c = b[j];
+    if (first + j >= len) continue;
     if (c == '\n') { line++; continue; }
     if (c == '\r') bad = 1;          // (what a carriage return means differs by line)
     const u32 role = (u32) line & 3u;
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(EN_THREADS) void k_fq_tile(
   line = (u64) t_nl[tile] + nlbefore;
 #pragma unroll
   for (int j = 0; j < EN_PER; j++) {
-    if (first + j >= len) break;
     const u8 c = b[j];
+    if (first + j >= len) continue;
     const u64 r = line >> 2;
     const bool linestart = first + j == 0 || (j ? b[j - 1] : raw[first - 1]) == '\n';
     if (linestart && (line & 3u) == 0 && (r > 0 || em.seen_record))

@@ -4867,11 +4867,10 @@ template <int BITS, bool WIDE> static int run_impl(gtamd_esa_ctx *c, u32 want, b
         mine[2 * R] = m;
         mine[2 * R + 1] = more;
         TRY(comm_allgather(c, 0, mine.data(), gathered.data(), (u32) (GW * 8)));
-        u64 left = 0, upd = 0;
+        u64 left = 0;
         for (u32 s = 0; s < R; s++) {
           left += gathered[(size_t) s * GW + 2 * R];
           more |= gathered[(size_t) s * GW + 2 * R + 1];
-          for (u32 r = 0; r < R; r++) upd += gathered[(size_t) s * GW + R + r];
         }
         if (left == 0) break;   // (ranks nobody will ask for need not travel)
         if (more) {

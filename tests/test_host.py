@@ -703,3 +703,68 @@ def test_packedindex_mkctxmap_option_errors(host, tmp_path):
     assert rc == -1 and ">= -1" in msg
     rc, msg = run(str(tmp_path / "nothere"))
     assert rc == -1 and "nothere.prj" in msg
+
+
+def test_fastq_file_length_table_per_record_equals_per_symbol(host):
+    """gtamd_fastq_filelengths books a record's symbols in one step; the reference's reader
+    (src/core/sequence_buffer_fastq.c:42-191) goes symbol by symbol through its 8192-symbol
+    output buffer -- restated here as it reads, with its quirks at the buffer boundaries --
+    and the two must agree on records of every length around the buffer size, over
+    several files"""
+    class Rec(ctypes.Structure):
+        _fields_ = [("seqlen", ctypes.c_uint64), ("desclen", ctypes.c_uint64), ("file", ctypes.c_size_t)]
+
+    def per_symbol(recs, lastfile, nfiles):
+        OUTBUF = 8192
+        tab = [[0, 0] for _ in range(nfiles)]
+        overflow, r, filenum, carry, complete = 0, 0, 0, 0, False
+        while not complete:
+            out = add = rd = 0
+            if carry:
+                out += 1; rd += 1; add += 1; carry = 0
+            if overflow > 0:
+                k = min(overflow, OUTBUF - out)
+                out += k; add += k; rd += k; overflow -= k
+                if overflow > 0:
+                    continue
+                out += 1; rd += 1
+            while True:
+                newfile = recs[r][2] if r < len(recs) else lastfile
+                if filenum != newfile:
+                    tab[filenum][0] += rd; tab[filenum][1] += add
+                    rd = add = 0; filenum = newfile
+                if r == len(recs):
+                    complete = True; out -= 1; add -= 1
+                    break
+                for _ in range(recs[r][0]):
+                    if out >= OUTBUF:
+                        overflow += 1
+                    else:
+                        out += 1; add += 1; rd += 1
+                if overflow == 0:
+                    if out >= OUTBUF:
+                        carry = 1
+                    else:
+                        out += 1; add += 1
+                rd += recs[r][1] + 1
+                r += 1
+                if out >= OUTBUF:
+                    break
+            tab[filenum][0] += rd; tab[filenum][1] += add
+        return tab
+
+    rng = np.random.default_rng(19)
+    host.gtamd_fastq_filelengths.restype = None
+    for trial in range(60):
+        nfiles = int(rng.integers(1, 4))
+        nrec = int(rng.integers(1, 40))
+        lens = rng.choice([1, 2, 100, 4095, 8190, 8191, 8192, 8193, 16383, 16384, 16385, 30000], size=nrec)
+        nfiles = min(nfiles, nrec)
+        files = np.sort(np.concatenate([np.arange(nfiles), rng.integers(0, nfiles, size=nrec - nfiles)]))
+        recs = [(int(l), int(rng.integers(0, 30)), int(f)) for l, f in zip(lens, files)]
+        arr = (Rec * nrec)(*[Rec(*t) for t in recs])
+        tab = (ctypes.c_uint64 * (2 * nfiles))()
+        host.gtamd_fastq_filelengths(arr, nrec, nfiles - 1, tab)
+        want = per_symbol(recs, nfiles - 1, nfiles)
+        assert [list(tab[2 * f:2 * f + 2]) for f in range(nfiles)] == \
+            [[v % (1 << 64) for v in row] for row in want], (trial, recs)

@@ -25,8 +25,43 @@ def main():
     ap.add_argument("--n", type=float, default=3e9)
     ap.add_argument("--model", type=int, default=synth.MODEL_HUMANLIKE_DNA)
     ap.add_argument("--seed", type=int, default=43)
+    ap.add_argument("--fuzz-seconds", type=float, default=0,
+                    help="instead of one build: random sizes (2^25 .. 3.1 G symbols), models, seeds and "
+                         "engine switches for this long, every build checked exactly")
     a = ap.parse_args()
-    n = int(a.n)
+    if a.fuzz_seconds > 0:
+        return fuzz(a.fuzz_seconds, a.seed)
+    return check_one(int(a.n), a.model, a.seed)
+
+
+def fuzz(seconds, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    t0, cases = time.time(), 0
+    switches = {"GTAMD_RANK_ALL_WINDOWS": ["0", "0", "1"], "GTAMD_WIN_FILTER_LDS": ["1", "1", "0"],
+                "GTAMD_PAIR_CHUNK": ["16", "32", "128"], "GTAMD_APPLY_EARLY": ["0", "1", "2"],
+                "GTAMD_MSD_PACK": ["0", "1"], "GTAMD_ROUND_STRIDE": ["1024", "1536", "2048"],
+                "GTAMD_NO_SMALL_GROUPS": ["0", "0", "1"], "GTAMD_PAIR_LONG": ["0", "1"],
+                "GTAMD_STABLE_PARTITION": ["0", "1"], "GTAMD_MSD_BIN_LIMIT": ["32", "128", "512"]}
+    while time.time() - t0 < seconds:
+        model = int(rng.choice([0, 1, 1, 2, 3]))
+        top = 1.2e9 if model == 2 else 3.1e9
+        n = int(np.exp(rng.uniform(np.log(2 ** 25), np.log(top))))
+        env = {k: str(rng.choice(v)) for k, v in switches.items()}
+        os.environ.update(env)
+        print("case %d: model %d n %d seed %d %s" % (cases, model, n, int(seed) + cases, env), flush=True)
+        check_one(n, model, int(seed) + cases)
+        torch.cuda.empty_cache()          # (the next engine allocates outside torch)
+        cases += 1
+    print("scale fuzz ok: %d builds in %.0f s" % (cases, time.time() - t0))
+    return 0
+
+
+def check_one(n, model, seed):
+    class A:
+        pass
+    a = A()
+    a.model, a.seed = model, seed
     N = n + 1
     lib = _lib.load()
     buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")

@@ -28,13 +28,14 @@ def main():
     ap.add_argument("--fuzz-seconds", type=float, default=0,
                     help="instead of one build: random sizes (2^25 .. 3.1 G symbols), models, seeds and "
                          "engine switches for this long, every build checked exactly")
+    ap.add_argument("--fuzz-min", type=float, default=2 ** 25, help="smallest size of the random builds")
     a = ap.parse_args()
     if a.fuzz_seconds > 0:
-        return fuzz(a.fuzz_seconds, a.seed)
+        return fuzz(a.fuzz_seconds, a.seed, int(a.fuzz_min))
     return check_one(int(a.n), a.model, a.seed)
 
 
-def fuzz(seconds, seed):
+def fuzz(seconds, seed, nmin=2 ** 25):
     import numpy as np
     rng = np.random.default_rng(seed)
     t0, cases = time.time(), 0
@@ -46,7 +47,7 @@ def fuzz(seconds, seed):
     while time.time() - t0 < seconds:
         model = int(rng.choice([0, 1, 1, 2, 3]))
         top = 1.2e9 if model == 2 else 3.1e9
-        n = int(np.exp(rng.uniform(np.log(2 ** 25), np.log(top))))
+        n = int(np.exp(rng.uniform(np.log(min(nmin, top / 2)), np.log(top))))
         env = {k: str(rng.choice(v)) for k, v in switches.items()}
         os.environ.update(env)
         print("case %d: model %d n %d seed %d %s" % (cases, model, n, int(seed) + cases, env), flush=True)
